@@ -1,0 +1,192 @@
+/*
+ * bprcore.h — C ABI of libbprcore.so, the MI355X (gfx950) BPR-MF training engine.
+ *
+ * The reference (Nemexur/revisit-bpr) has no FFI: its hot path is a chain of stock torch ops
+ * called from Python.  Each entry point below therefore cites the reference *Python call site*
+ * it replaces (paths relative to the reference tree).  The binding a maintainer adds on the
+ * reference side is a ctypes stub — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
+ *   - Every pointer argument is a DEVICE pointer (HBM) unless the name ends in `_host`.
+ *   - The caller owns every buffer it passes in.  The library allocates only private scratch
+ *     inside `bpr_ctx` (grad accumulators of the strict path, adaptive-sampler order arrays,
+ *     scalar reduction slots) and frees it in bpr_ctx_destroy.
+ *   - Return value: 0 (BPR_OK) on success, negative bpr_status on failure; the message for the
+ *     calling thread is available from bpr_last_error().  The library never aborts.
+ *   - All calls are asynchronous with respect to the host and are ordered on the HIP stream the
+ *     ctx was created with (pass torch's current stream) — except bpr_ctx_create/destroy and the
+ *     `*_host` getters, which synchronise that stream.
+ *   - A ctx is single-threaded and tied to one HIP device + stream.
+ *   - Row 0 of both tables is the pad row (reference: nn.Embedding(padding_idx=0)); item ids
+ *     handed to the library are in [0, I), user ids in [0, U).  Ids are int32.
+ */
+#ifndef BPRCORE_H
+#define BPRCORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPRCORE_VERSION 100 /* 0.1.0 */
+
+typedef struct bpr_ctx bpr_ctx;
+
+typedef enum bpr_status {
+  BPR_OK = 0,
+  BPR_ERR_INVALID = -1,     /* bad argument / state (message says which) */
+  BPR_ERR_HIP = -2,         /* a HIP runtime call failed */
+  BPR_ERR_UNSUPPORTED = -3, /* valid request the engine does not implement (e.g. d not multiple of 4) */
+  BPR_ERR_NOMEM = -4
+} bpr_status;
+
+/* torch.optim.* kinds used by the reference configs
+ * (configs/RQ1/ours.yaml.j2:116-119, configs/RQ2/optimizers/*, configs/RQ3/time-split/ada-sampling-adam.yaml.j2:169-175) */
+typedef enum bpr_opt_kind {
+  BPR_OPT_SGD = 0,      /* torch.optim.SGD(lr)                               */
+  BPR_OPT_MOMENTUM = 1, /* torch.optim.SGD(lr, momentum, dampening, nesterov) */
+  BPR_OPT_ADAM = 2,     /* torch.optim.Adam(lr, betas, eps)                   */
+  BPR_OPT_RMSPROP = 3   /* torch.optim.RMSprop(lr, alpha, eps, momentum=0)    */
+} bpr_opt_kind;
+
+typedef struct bpr_opt_params {
+  float lr;
+  float momentum;  /* MOMENTUM */
+  float dampening; /* MOMENTUM */
+  int32_t nesterov;
+  float beta1, beta2; /* ADAM */
+  float eps;          /* ADAM (1e-8), RMSPROP (1e-8) */
+  float alpha;        /* RMSPROP smoothing constant (0.99) */
+} bpr_opt_params;
+
+/* How a step treats rows that occur several times in the same batch / chunk. */
+typedef enum bpr_mode {
+  /* Exact reference mini-batch semantics (revisit_bpr/models/bpr/model.py:40-68 + trainer.py:76-81):
+   * all B gradients evaluated at the pre-step parameters, duplicates accumulated, ONE optimizer
+   * step.  Two kernels (grad-accumulate, apply).  Launch-bound at B=256; used for parity. */
+  BPR_MODE_STRICT = 0,
+  /* Throughput path: one launch consumes a whole chunk of triples; every triple reads the latest
+   * rows it can see and applies its update immediately with per-element fp32 atomics
+   * (asynchronous SGD, bounded staleness).  SGD only. */
+  BPR_MODE_STREAM = 1
+} bpr_mode;
+
+typedef enum bpr_sampler_kind {
+  BPR_NEG_GIVEN = 0,   /* caller passes `neg` */
+  BPR_NEG_UNIFORM = 1, /* revisit_bpr/modules/neg_samplers.py:31-37 (UniformSampler.sample) */
+  BPR_NEG_ADAPTIVE = 2 /* revisit_bpr/modules/neg_samplers.py:74-124 (AdaptiveSampler.sample) */
+} bpr_sampler_kind;
+
+/* out_scalars layout written by bpr_forward_grad / bpr_step / bpr_train_stream (fp32, ADDED to —
+ * zero it first):  [0] bpr_loss = Σ −logσ(x)   [1] l2_reg   [2] Σ|x|   [3] number of triples */
+#define BPR_SCALARS 4
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int bpr_version(void);
+const char* bpr_last_error(void);
+/* hip_stream: a hipStream_t (may be NULL = default stream). */
+int bpr_ctx_create(bpr_ctx** out, int device_id, void* hip_stream);
+int bpr_ctx_destroy(bpr_ctx* ctx);
+int bpr_set_stream(bpr_ctx* ctx, void* hip_stream);
+
+/* ---- model state (reference: MF parameters, revisit_bpr/models/bpr/model.py:97-116) ------ */
+/* P [U,d], Q [I,d] row-major fp32, updated IN PLACE; item_bias [I] or NULL (MF(item_bias=...)).
+ * pad_user / pad_item: the nn.Embedding padding_idx of each table (−1 = none): gradient of that
+ * embedding row is dropped, as torch's embedding backward does. */
+int bpr_bind_tables(bpr_ctx* ctx, float* P, int64_t U, float* Q, int64_t I, int32_t d,
+                    float* item_bias, int32_t pad_user, int32_t pad_item);
+
+/* Seen-items CSR over users: indptr [U+1] int64, indices [nnz] int32 sorted ascending inside each
+ * row, no duplicates, no item 0.  Replaces the padded `seen_items` [B,S] batch tensor
+ * (experiments/bpr/dataset.py:142-190, example.py:33-68) for on-device sampling. */
+int bpr_bind_seen_csr(bpr_ctx* ctx, const int64_t* indptr, const int32_t* indices);
+
+/* Model.regularization alphas after the resolution rules of model.py:74-86 were applied by the host. */
+int bpr_set_reg(bpr_ctx* ctx, float alpha_user, float alpha_item, float alpha_neg);
+
+/* torch.optim hyper-parameters (read from optimizer.param_groups by the host shim each step). */
+int bpr_set_optimizer(bpr_ctx* ctx, int32_t kind, const bpr_opt_params* params);
+/* Optimizer state, same shapes as the tables (caller-owned so checkpoints keep working):
+ *   MOMENTUM: m_* = momentum_buffer;  ADAM: m_* = exp_avg, v_* = exp_avg_sq;  RMSPROP: v_* = square_avg.
+ * *_bias may be NULL when there is no item_bias.  All zero-initialised by the caller. */
+int bpr_bind_opt_state(bpr_ctx* ctx, float* m_P, float* v_P, float* m_Q, float* v_Q,
+                       float* m_bias, float* v_bias);
+
+/* ---- negative sampling -------------------------------------------------------------------- */
+/* Draw one negative per (user) uniformly over items the user has not seen, never item 0.
+ * Randomness: Philox4x32-10 keyed by `seed`, counter = offset + position in the batch, so a triple's
+ * negative does not depend on launch geometry or GPU count.  neg_out [B] int32. */
+int bpr_sample_uniform(bpr_ctx* ctx, const int32_t* users, int64_t B, uint64_t seed,
+                       uint64_t offset, int32_t* neg_out);
+
+/* AdaptiveSampler.update_stats (neg_samplers.py:126-132): snapshot the item table as per-factor
+ * descending item orders (private scratch, d*I int32) and sigma_f = unbiased std over rows 1.. */
+int bpr_adaptive_refresh(bpr_ctx* ctx);
+/* AdaptiveSampler.sample: factor ~ |p_uf|·sigma_f, rank ~ Geometric(p) clamped to #unseen,
+ * orientation by sign(p_uf), pick the rank-th unseen item of the snapshot order.
+ * factor_out / rank_out (int32 [B], nullable) expose the intermediate draws for parity tests;
+ * rank_out is the 0-based rank counted from the top, as in neg_samplers.py:96-100. */
+int bpr_sample_adaptive(bpr_ctx* ctx, const int32_t* users, int64_t B, float p, uint64_t seed,
+                        uint64_t offset, int32_t* neg_out, int32_t* factor_out, int32_t* rank_out);
+/* Deterministic half of AdaptiveSampler.sample (neg_samplers.py:109-121): given factor and rank
+ * (0-based from the top) return the rank-th unseen item in the snapshot order of that factor. */
+int bpr_adaptive_pick(bpr_ctx* ctx, const int32_t* users, const int32_t* factor,
+                      const int32_t* rank, int64_t B, int32_t* neg_out);
+/* Copy the snapshot to caller buffers (either may be NULL): order [d*I] int32, sigma [d] fp32. */
+int bpr_adaptive_get_snapshot(bpr_ctx* ctx, int32_t* order_out, float* sigma_out);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+/* BPR.forward train branch (model.py:48-68): logits_pos/neg [B] (nullable), scalars as above. No
+ * parameter is modified.  Used by the eval-free "forward only" callers and by parity tests. */
+int bpr_forward(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, const int32_t* neg,
+                int64_t B, float* out_logits_pos, float* out_logits_neg, float* out_scalars);
+
+/* STRICT phase A — BPR.forward + loss.backward() (model.py:48-68, trainer.py:76): as bpr_forward,
+ * and accumulates the per-row gradients of the batch into the ctx's private accumulators. */
+int bpr_forward_grad(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, const int32_t* neg,
+                     int64_t B, float* out_logits_pos, float* out_logits_neg, float* out_scalars);
+/* STRICT phase B — optimizer.step(); optimizer.zero_grad() (trainer.py:79-81): one optimizer step
+ * on every row touched since the last apply, then clears the accumulators. */
+int bpr_apply(bpr_ctx* ctx);
+/* Drop accumulated gradients without applying them (a forward that was never stepped). */
+int bpr_discard_grad(bpr_ctx* ctx);
+/* Copy accumulated gradients to dense caller buffers for tests (any may be NULL):
+ * gP [U,d], gQ [I,d], gbias [I].  Untouched rows read as zero. */
+int bpr_get_grad(bpr_ctx* ctx, float* gP, float* gQ, float* gbias);
+
+/* One reference training iteration (example.py:172-180): sample (if sampler != GIVEN) →
+ * forward → backward → optimizer step.  mode STRICT = phases A+B; mode STREAM = one fused launch
+ * (SGD only).  `neg` is read when sampler == BPR_NEG_GIVEN, otherwise (if non-NULL) it receives
+ * the sampled negatives.  seed/offset as in bpr_sample_uniform; adaptive_p = Geometric p. */
+int bpr_step(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t B,
+             int32_t mode, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
+             float* out_logits_pos, float* out_logits_neg, float* out_scalars);
+
+/* STREAM throughput entry (train_one_epoch's inner loop, example.py:172-180, over n triples in ONE
+ * launch): users/pos are the (already shuffled) triple stream resident in HBM.  `max_inflight`
+ * bounds how many triples are processed concurrently (0 = fill the chip); see DESIGN.md §staleness. */
+int bpr_train_stream(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
+                     int64_t n, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
+                     int64_t max_inflight, float* out_scalars);
+
+/* Dense-optimizer equivalence: torch's dense Adam / momentum move EVERY row on every
+ * step.  The strict path replays the missed zero-gradient steps lazily when a row is next
+ * touched; this brings all rows to the current step (call before eval / checkpoint / all-reduce). */
+int bpr_flush_lazy(bpr_ctx* ctx);
+/* Global optimizer step counter t (number of bpr_apply calls); settable for checkpoint resume. */
+int bpr_get_step_host(bpr_ctx* ctx, int64_t* step_host);
+int bpr_set_step(bpr_ctx* ctx, int64_t step);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+/* Average duration (ms) of the dominant kernel over the launches recorded since the last reset,
+ * measured with hipEvents on the ctx stream (bench.py's roofline.achieved uses this).
+ * bpr_timing_enable(ctx, 1) turns recording on (adds two event records per launch). */
+int bpr_timing_enable(bpr_ctx* ctx, int32_t on);
+int bpr_timing_read_host(bpr_ctx* ctx, double* avg_ms_host, int64_t* launches_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPRCORE_H */

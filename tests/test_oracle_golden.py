@@ -1,0 +1,241 @@
+"""Pin the CPU oracle against vectors produced by the reference itself (tests/golden/make_golden.py).
+
+Tolerances: the reference computes in fp32 with torch's CPU kernels; the oracle carries dot products
+and duplicate accumulation in double and rounds once.  After ONE step |Δw| <= 1e-6·max(1,|w|)
+(SURVEY §8c); after five steps the bound is relaxed to 5e-6.  Integer outputs are exact.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import metrics_np
+
+MATH_FILES = [
+    "math_13_uin_nobias", "math_42069_uin_nobias", "math_13_uin_bias", "math_13_all_nobias",
+    "math_13_item_only_bias", "math_42069_none_nobias",
+]
+REG = {
+    "uin": (0.0016, 0.0001, 0.00375),  # (user, item, neg)
+    "all": (0.00043, 0.00043, 0.00043),
+    "item_only": (0.0, 0.0025, 0.0025),  # neg defaults to item (model.py:86)
+    "none": (0.0, 0.0, 0.0),
+}
+OPTS = {
+    "sgd": oracle.make_opt(oracle.SGD, 0.05),
+    "sgd_nesterov": oracle.make_opt(oracle.MOMENTUM, 0.05, momentum=0.9, nesterov=True),
+    "sgd_momentum": oracle.make_opt(oracle.MOMENTUM, 0.05, momentum=0.5),
+    "adam_09": oracle.make_opt(oracle.ADAM, 0.01, betas=(0.9, 0.999)),
+    "adam_01": oracle.make_opt(oracle.ADAM, 0.01, betas=(0.1, 0.999)),
+    "adam_00": oracle.make_opt(oracle.ADAM, 0.01, betas=(0.0, 0.99)),
+    "rmsprop": oracle.make_opt(oracle.RMSPROP, 0.01, alpha=0.9),
+}
+
+
+def close(a, b, tol):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b)))
+
+
+def load(golden_dir, name):
+    g = np.load(golden_dir / f"{name}.npz")
+    reg = REG[name.split("_", 2)[2].rsplit("_", 1)[0]]
+    bias = name.endswith("_bias")
+    return g, reg, bias
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32_10
+    assert oracle.philox4x32_10([0, 0, 0, 0], [0, 0]) == [
+        0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert oracle.philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [
+        0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert oracle.philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344],
+                                [0xA4093822, 0x299F31D0]) == [
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+@pytest.mark.parametrize("name", MATH_FILES)
+def test_forward_matches_reference(golden_dir, name):
+    g, reg, bias = load(golden_dir, name)
+    P, Q = g["P0"].copy(), g["Q0"].copy()
+    b = g["b0"].copy() if bias else None
+    lp, ln, sc = oracle.forward(P, Q, b, i32(g["users0"]), i32(g["pos0"]), i32(g["neg0"]), reg)
+    assert close(lp, g["fwd_logits_pos"].reshape(-1), 1e-6)
+    assert close(ln, g["fwd_logits_neg"].reshape(-1), 1e-6)
+    assert close(lp - ln, g["fwd_logits"].reshape(-1), 1e-6)
+    assert close(sc[0], g["fwd_bpr_loss"], 1e-6)
+    assert close(sc[1], g["fwd_l2_reg"], 1e-6)
+    assert close(sc[0] + sc[1], g["fwd_loss"], 1e-6)
+
+
+@pytest.mark.parametrize("name", MATH_FILES)
+def test_dense_grad_matches_autograd(golden_dir, name):
+    g, reg, bias = load(golden_dir, name)
+    b = g["b0"].copy() if bias else None
+    gP, gQ, gb = oracle.dense_grad(g["P0"].copy(), g["Q0"].copy(), b, i32(g["users0"]),
+                                   i32(g["pos0"]), i32(g["neg0"]), reg)
+    assert close(gP, g["gP"], 1e-6)
+    assert close(gQ, g["gQ"], 1e-6)
+    assert np.all(gP[0] == 0) and np.all(gQ[0] == 0)  # padding_idx rows
+    if bias:
+        assert close(gb, g["gb"], 1e-6)
+
+
+@pytest.mark.parametrize("name", MATH_FILES)
+@pytest.mark.parametrize("opt_name", list(OPTS))
+def test_optimizer_steps_match_torch(golden_dir, name, opt_name):
+    g, reg, bias = load(golden_dir, name)
+    P, Q = g["P0"].copy(), g["Q0"].copy()
+    b = g["b0"].copy() if bias else None
+    st = {k: np.zeros_like(P) for k in ("mP", "vP")}
+    st.update({k: np.zeros_like(Q) for k in ("mQ", "vQ")})
+    st.update({k: np.zeros(Q.shape[0], np.float32) for k in ("mb", "vb")})
+    for s in range(5):
+        _, _, sc = oracle.step(P, Q, b, i32(g[f"users{s}"]), i32(g[f"pos{s}"]), i32(g[f"neg{s}"]),
+                               OPTS[opt_name], s + 1, st, reg)
+        tol = 1e-6 if s == 0 else 5e-6
+        assert close(sc[0] + sc[1], g[f"{opt_name}_loss{s + 1}"], 2e-5), (s, sc)
+        if s in (0, 4):
+            assert close(P, g[f"{opt_name}_P{s + 1}"], tol), (opt_name, s)
+            assert close(Q, g[f"{opt_name}_Q{s + 1}"], tol), (opt_name, s)
+            if bias:
+                assert close(b, g[f"{opt_name}_b{s + 1}"], tol), (opt_name, s)
+
+
+@pytest.mark.parametrize("name", MATH_FILES)
+def test_sparse_sgd_equals_dense_sgd(golden_dir, name):
+    g, reg, bias = load(golden_dir, name)
+    P, Q = g["P0"].copy(), g["Q0"].copy()
+    b = g["b0"].copy() if bias else None
+    for s in range(5):
+        oracle.step_sgd_sparse(P, Q, b, i32(g[f"users{s}"]), i32(g[f"pos{s}"]),
+                               i32(g[f"neg{s}"]), 0.05, reg)
+    assert close(P, g["sgd_P5"], 5e-6) and close(Q, g["sgd_Q5"], 5e-6)
+    if bias:
+        assert close(b, g["sgd_b5"], 5e-6)
+
+
+# ---- samplers ---------------------------------------------------------------------------------
+def seen_to_csr(users, seen, U):
+    rows = {}
+    for u, row in zip(users, seen):
+        rows[int(u)] = sorted(int(x) for x in row if x != 0)
+    indptr = np.zeros(U + 1, np.int64)
+    idx = []
+    for u in range(U):
+        idx.extend(rows.get(u, []))
+        indptr[u + 1] = len(idx)
+    return indptr, np.asarray(idx, np.int32)
+
+
+def test_sampling_weights_literal(golden_dir):
+    g = np.load(golden_dir / "sampler.npz")
+    w = oracle.sampling_weights(np.ones(g["Q"].shape[0], np.float32), g["seen"].copy())
+    assert close(w, g["weights"], 1e-7)
+
+
+def test_adaptive_stats_match_reference(golden_dir):
+    g = np.load(golden_dir / "sampler.npz")
+    QT, sigma = oracle.adaptive_stats(g["Q"].copy())
+    assert np.array_equal(QT, g["factor_to_items"])
+    assert close(sigma, g["factor_std"].reshape(-1), 1e-6)
+
+
+def test_adaptive_picks_match_reference(golden_dir):
+    """AdaptiveSampler.sample of the reference with injected (factor, r) vs both oracle forms."""
+    g = np.load(golden_dir / "sampler.npz")
+    P, Q, users, seen = g["P"], g["Q"].copy(), g["users"], g["seen"]
+    I = Q.shape[0]
+    indptr, indices = seen_to_csr(users, seen, P.shape[0])
+    QT, _ = oracle.adaptive_stats(Q)
+    order = oracle.adaptive_order(QT)
+    for case, (f, r) in enumerate(zip(g["inj_factor"], g["inj_r"])):
+        for b, u in enumerate(users):
+            n_unseen = (I - 1) - (indptr[u + 1] - indptr[u])
+            rr = min(int(r), int(n_unseen))  # clamp_(max=num_notseen) neg_samplers.py:94
+            rank = rr - 1 if P[u, f] > 0 else n_unseen - rr  # :96-100
+            want = int(g["inj_picks"][case, b])
+            assert oracle.adaptive_pick_literal(QT, indptr, indices, int(u), int(f), int(rank)) == want
+            assert oracle.adaptive_pick(order, indptr, indices, int(u), int(f), int(rank)) == want
+
+
+def test_uniform_sampler_distribution(golden_dir):
+    """Philox rejection sampler draws exactly the distribution of _sampling_weights (chi-square)."""
+    g = np.load(golden_dir / "sampler.npz")
+    users, seen = g["users"], g["seen"]
+    I = g["Q"].shape[0]
+    indptr, indices = seen_to_csr(users, seen, g["P"].shape[0])
+    n = 40000
+    for b in (0, 1, 2, 5):
+        u = np.full(n, users[b], np.int32)
+        neg = oracle.sample_uniform(indptr, indices, I, u, seed=99, offset=b * n)
+        w = g["weights"][b]
+        counts = np.bincount(neg, minlength=I)
+        assert counts[w == 0].sum() == 0  # never a seen item, never item 0
+        exp = w * n
+        chi2 = ((counts[w > 0] - exp[w > 0]) ** 2 / exp[w > 0]).sum()
+        dof = (w > 0).sum() - 1
+        assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
+
+
+def test_adaptive_sampler_distribution(golden_dir):
+    """Full Philox adaptive sampler: factor ∝ |p_uf|σ_f, r geometric, orientation by sign."""
+    g = np.load(golden_dir / "sampler.npz")
+    P, Q, users, seen = g["P"].copy(), g["Q"].copy(), g["users"], g["seen"]
+    I, d = Q.shape
+    indptr, indices = seen_to_csr(users, seen, P.shape[0])
+    QT, sigma = oracle.adaptive_stats(Q)
+    order = oracle.adaptive_order(QT)
+    n, p = 60000, 0.1
+    u0 = int(users[2])
+    neg, fac, rnk = oracle.sample_adaptive(P, sigma, order, indptr, indices,
+                                           np.full(n, u0, np.int32), p, seed=5)
+    wf = np.abs(P[u0]) * sigma
+    wf = wf / wf.sum()
+    cf = np.bincount(fac, minlength=d)
+    chi2 = ((cf - wf * n) ** 2 / (wf * n)).sum()
+    assert chi2 < (d - 1) + 5 * np.sqrt(2 * (d - 1)), chi2
+    n_unseen = (I - 1) - (indptr[u0 + 1] - indptr[u0])
+    # recover r from the rank and the orientation, compare with Geometric(p) clamped at n_unseen
+    r = np.where(P[u0, fac] > 0, rnk + 1, n_unseen - rnk)
+    assert r.min() >= 1 and r.max() <= n_unseen
+    for k in (1, 2, 3, 5):
+        assert abs((r == k).mean() - p * (1 - p) ** (k - 1)) < 4e-3
+    # every pick is the literal pick
+    for t in range(0, n, 997):
+        assert neg[t] == oracle.adaptive_pick_literal(QT, indptr, indices, u0, int(fac[t]),
+                                                      int(rnk[t]))
+
+
+def test_stream_seq_equals_b1_steps(golden_dir):
+    """orc_train_stream_seq == n reference iterations with batch size 1."""
+    g, reg, _ = load(golden_dir, "math_13_uin_bias")
+    P, Q, b = g["P0"].copy(), g["Q0"].copy(), g["b0"].copy()
+    P2, Q2, b2 = P.copy(), Q.copy(), b.copy()
+    u, i, j = i32(g["users0"]), i32(g["pos0"]), i32(g["neg0"])
+    oracle.train_stream_seq(P, Q, b, u, i, j, oracle.NEG_GIVEN, 0.05, reg)
+    opt = oracle.make_opt(oracle.SGD, 0.05)
+    for t in range(len(u)):
+        oracle.step(P2, Q2, b2, u[t:t + 1], i[t:t + 1], j[t:t + 1], opt, t + 1, None, reg)
+    assert close(P, P2, 1e-6) and close(Q, Q2, 1e-6) and close(b, b2, 1e-6)
+
+
+# ---- metrics ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["wide", "narrow"])
+def test_metrics_match_reference(golden_dir, name):
+    g = np.load(golden_dir / "metrics.npz")
+    lo, ta = g[f"{name}_logits"], g[f"{name}_target"]
+    for k in (5, 10, 20, 50, 100):
+        assert close(metrics_np.ndcg(lo, ta, k), g[f"{name}_ndcg@{k}"], 1e-6)
+        assert close(metrics_np.recall(lo, ta, k), g[f"{name}_recall@{k}"], 1e-6)
+        assert close(metrics_np.precision(lo, ta, k), g[f"{name}_precision@{k}"], 1e-6)
+    want = g[f"{name}_auc_many"]
+    got = metrics_np.roc_auc_many(lo, ta)
+    assert np.array_equal(np.isnan(want), np.isnan(got))
+    assert close(got[~np.isnan(want)], want[~np.isnan(want)], 1e-6)
+    assert close(metrics_np.roc_auc_one(lo), g[f"{name}_auc_one"], 1e-6)
