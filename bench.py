@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py — BPR triples/s on MI355X for the configuration BASELINE.json's metric is quoted on.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): ML-20M-shaped synthetic interactions (136,677 users x 20,108 items,
+~9.6 M training triples after the user-split hold-out), d = 128, plain SGD + L2, ADAPTIVE negative
+sampling p = 1/100 — BASELINE.json configs[2], the d=128 config the metric names.
+
+One step = one refresh period of the reference's training loop (example.py:172-180 +
+neg_samplers.py:122-123): `bpr_adaptive_refresh` (AdaptiveSampler.update_stats) followed by ONE
+fused STREAM launch over the next int(I·ln I / 256)·256 shuffled triples (sample negative → gather
+→ gradient → SGD scatter), all inputs resident in HBM.  Multi-GPU: weak scaling — every rank owns an
+ML-20M-shaped user shard; the item table is replicated and reconciled by an asynchronous
+all-reduce of item deltas every --sync-every steps (revisit_bpr/distributed.py).
+
+Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the fused stream kernel, HBM
+bound, algorithmic bytes 24·d+8 per triple, duration from hipEvents on the launch stream) and
+`cpu_baseline` (the CPU oracle port timed on this host, 1 thread, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "revisit-bpr_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="ml-20m")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--sampler", choices=["adaptive", "uniform"], default="adaptive")
+    ap.add_argument("--adaptive-p", type=float, default=0.01)
+    ap.add_argument("--lr", type=float, default=0.001)
+    ap.add_argument("--batch-size", type=int, default=256,
+                    help="reference batch size; only sets the refresh period I·ln(I)/B batches")
+    ap.add_argument("--sync-every", type=int, default=1, help="item all-reduce period in steps (N>1)")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink users/actions (debug)")
+    ap.add_argument("--max-inflight", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--seed", type=int, default=13)
+    return ap.parse_args()
+
+
+def cpu_baseline(data, d, reg, lr, p, seconds, seed, sampler="adaptive"):
+    """The oracle (CPU port of the same path: adaptive sample → strict B=256 SGD step, sparse apply)
+    timed on one host core over a bounded number of batches."""
+    import oracle
+
+    rng = np.random.default_rng(seed)
+    P = ((rng.random((data.num_users, d)) - 0.5) / d).astype(np.float32)
+    Q = ((rng.random((data.num_items, d)) - 0.5) / d).astype(np.float32)
+    P[0] = 0
+    Q[0] = 0
+    QT, sigma = oracle.adaptive_stats(Q)
+    order = oracle.adaptive_order(QT)
+    perm = rng.permutation(data.nnz)
+    B, done, b0 = 256, 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds and b0 + B <= data.nnz:
+        idx = perm[b0:b0 + B]
+        u, i = np.ascontiguousarray(data.users[idx]), np.ascontiguousarray(data.items[idx])
+        if sampler == "adaptive":
+            neg, _, _ = oracle.sample_adaptive(P, sigma, order, data.indptr, data.indices, u, p,
+                                               seed, offset=b0)
+        else:
+            neg = oracle.sample_uniform(data.indptr, data.indices, data.num_items, u, seed, b0)
+        oracle.step_sgd_sparse(P, Q, None, u, i, neg, lr, reg)
+        done += B
+        b0 += B
+    dt = time.perf_counter() - t0
+    return {
+        "value": done / dt, "unit": "triples/s", "cores": oracle.num_threads(), "kind": "port",
+        "sample": f"{done // B} batches of 256 triples ({done} triples, {dt:.1f} s) of the same "
+                  f"workload: oracle {sampler} sampler + strict SGD step, refresh "
+                  f"excluded; host has {os.cpu_count()} cores",
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libbprcore has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from revisit_bpr import engine as eng
+    from revisit_bpr.datasets import synthetic
+    from revisit_bpr.distributed import ItemSync
+
+    d = args.dim
+    # every rank owns its own ML-20M-shaped user shard (weak scaling); same item space
+    data = synthetic.generate_named(args.workload, eval_users=10_000, seed=args.seed + rank,
+                                    scale=args.scale)
+    U, I = data.num_users, data.num_items
+    g = torch.Generator().manual_seed(args.seed)  # same Q on every rank
+    Q = ((torch.rand(I, d, generator=g) - 0.5) / d)
+    gp = torch.Generator().manual_seed(args.seed + 1000 + rank)
+    P = ((torch.rand(U, d, generator=gp) - 0.5) / d)
+    P[0] = 0
+    Q[0] = 0
+    P, Q = P.to(dev), Q.to(dev)
+    e = eng.Engine(P, Q)
+    reg = (0.0016, 0.0001, 0.00375)  # configs/RQ2/neg-sampling/ada-sampling-ml-20m.yaml.j2:144-147
+    e.set_reg(*reg)
+    e.set_optimizer(eng.OPT_SGD, lr=args.lr)
+    e.bind_seen_csr(torch.from_numpy(data.indptr).to(dev), torch.from_numpy(data.indices).to(dev))
+    sampler = eng.NEG_ADAPTIVE if args.sampler == "adaptive" else eng.NEG_UNIFORM
+
+    # epoch order: a seeded permutation of the triple list, shuffled once on device
+    perm = torch.randperm(data.nnz, device=dev, generator=torch.Generator(dev).manual_seed(args.seed))
+    users = torch.from_numpy(data.users).to(dev)[perm].contiguous()
+    items = torch.from_numpy(data.items).to(dev)[perm].contiguous()
+    every = max(1, int(I * math.log(I) / args.batch_size))  # example.py:302
+    chunk = min(every * args.batch_size, data.nnz)
+    n_chunks = max(1, data.nnz // chunk)
+    sync = ItemSync([Q]) if world > 1 else None
+    scalars = torch.zeros(4, device=dev)
+    seed = args.seed
+
+    def step(k: int):
+        c = k % n_chunks
+        lo = c * chunk
+        if sampler == eng.NEG_ADAPTIVE:
+            e.adaptive_refresh()
+        e.train_stream(users[lo:lo + chunk], items[lo:lo + chunk], sampler=sampler,
+                       adaptive_p=args.adaptive_p, seed=seed,
+                       offset=(rank << 40) + k * chunk, max_inflight=args.max_inflight,
+                       scalars=scalars)
+        if sync is not None and (k + 1) % args.sync_every == 0:
+            sync.finish()
+            sync.start()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    e.timing_enable(True)
+    scalars.zero_()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k)
+    if sync is not None:
+        sync.finish()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    kernel_ms, launches = e.timing_read()
+    e.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    sc = scalars.cpu().numpy()
+
+    if rank == 0:
+        triples = args.steps * chunk * world
+        value = triples / dt
+        bytes_per_triple = 24 * d + 8  # read 3 rows + write 3 rows (fp32) + 2 int32 ids
+        achieved = (bytes_per_triple * chunk) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "BPR triples/sec at d=128 (1/2/4/8 GPU) + nDCG@100 parity vs reference",
+            "value": value,
+            "unit": "triples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}-shaped synthetic user-split ({U - 1} users x {I - 1} "
+                            f"items, {data.nnz} train triples per GPU), d={d}, SGD lr={args.lr} + L2 "
+                            f"reg {reg}, {args.sampler} negative sampling"
+                            + (f" p={args.adaptive_p}" if args.sampler == "adaptive" else "")
+                            + f", STREAM mode, step = refresh + {chunk} triples",
+                "triples_per_step_per_gpu": chunk,
+                "parallelism": f"user-sharded x{world}, item table replicated, async delta "
+                               f"all-reduce every {args.sync_every} step(s)" if world > 1 else "single GPU",
+                "mean_bpr_loss": float(sc[0] / max(sc[3], 1.0)),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_triples<G=32,NV=1,STREAM,%s>" % args.sampler.upper(),
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_triple": bytes_per_triple,
+                "kernel_ms_avg": kernel_ms,
+                "launches": launches,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, d, reg, args.lr, args.adaptive_p,
+                                               args.cpu_seconds, args.seed, args.sampler)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

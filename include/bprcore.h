@@ -43,7 +43,7 @@ typedef enum bpr_status {
 } bpr_status;
 
 /* torch.optim.* kinds used by the reference configs
- * (configs/RQ1/ours.yaml.j2:116-119, configs/RQ2/optimizers/*, configs/RQ3/time-split/ada-sampling-adam.yaml.j2:169-175) */
+ * (configs/RQ1/ours.yaml.j2:116-119, configs/RQ2/optimizers/, configs/RQ3/time-split/ada-sampling-adam.yaml.j2:169-175) */
 typedef enum bpr_opt_kind {
   BPR_OPT_SGD = 0,      /* torch.optim.SGD(lr)                               */
   BPR_OPT_MOMENTUM = 1, /* torch.optim.SGD(lr, momentum, dampening, nesterov) */

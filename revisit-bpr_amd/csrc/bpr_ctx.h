@@ -1,0 +1,69 @@
+// bpr_ctx.h — private state of a bpr_ctx (shared by bprcore.hip and bpr_refresh.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/bprcore.h"
+
+struct bpr_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // bound model state (caller-owned)
+  float* P = nullptr;
+  float* Q = nullptr;
+  float* bias = nullptr;
+  int64_t U = 0, I = 0;
+  int d = 0, G = 0, NV = 0;
+  int pad_user = -1, pad_item = -1;
+  const int64_t* indptr = nullptr;
+  const int32_t* indices = nullptr;
+  float au = 0.f, ai = 0.f, an = 0.f;
+  int opt_kind = BPR_OPT_SGD;
+  bpr_opt_params opt = {0.f, 0.f, 0.f, 0, 0.9f, 0.999f, 1e-8f, 0.99f};
+  float *mP = nullptr, *vP = nullptr, *mQ = nullptr, *vQ = nullptr, *mb = nullptr, *vb = nullptr;
+  // private scratch — STRICT path
+  float *GP = nullptr, *GQ = nullptr, *Gb = nullptr;
+  int32_t *flagP = nullptr, *flagQ = nullptr;
+  int32_t *lastP = nullptr, *lastQ = nullptr;
+  uint32_t* touched = nullptr;
+  uint32_t* touched_cnt = nullptr;
+  int64_t pending = 0;  // upper bound of entries in `touched`
+  int64_t step = 0;     // optimizer steps applied so far
+  int64_t flushed_at = 0;
+  // private scratch — adaptive sampler snapshot
+  int32_t* order = nullptr;  // [d, I]
+  float* sigma = nullptr;    // [d]
+  float* keysT = nullptr;    // [d, I] transposed item table
+  float* keys_sorted = nullptr;
+  int32_t* ids_in = nullptr;
+  int32_t* seg_offsets = nullptr;  // [d+1]
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  bool have_snapshot = false;
+  // scalar slots
+  float* dev_scalars = nullptr;
+  // timing of the dominant kernel
+  bool timing = false;
+  std::vector<hipEvent_t> ev_start, ev_stop;
+  size_t ev_used = 0;
+  double timed_ms = 0.0;
+  int64_t timed_launches = 0;
+};
+
+namespace bpr {
+void set_error(const std::string& msg);
+int refresh_impl(bpr_ctx* c);       // bpr_refresh.hip
+void refresh_free(bpr_ctx* c);      // bpr_refresh.hip
+}  // namespace bpr
+
+#define BPR_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      bpr::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+      return BPR_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)

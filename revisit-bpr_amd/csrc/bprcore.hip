@@ -1,0 +1,640 @@
+// bprcore.hip — C ABI of libbprcore.so (declared in include/bprcore.h) and kernel dispatch.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <type_traits>
+
+#include "bpr_ctx.h"
+#include "bpr_kernels.h"
+
+namespace bpr {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+static int fail(int code, const std::string& msg) {
+  set_error(msg);
+  return code;
+}
+
+// ---- (G, NV) dispatch ----------------------------------------------------------------------
+template <int A, int B>
+struct GNV {
+  static constexpr int G = A;
+  static constexpr int NV = B;
+};
+
+template <typename F>
+static int dispatch_gnv(int G, int NV, F&& f) {
+  switch (G * 8 + NV) {
+    case 2 * 8 + 1: return f(GNV<2, 1>{});
+    case 4 * 8 + 1: return f(GNV<4, 1>{});
+    case 8 * 8 + 1: return f(GNV<8, 1>{});
+    case 16 * 8 + 1: return f(GNV<16, 1>{});
+    case 32 * 8 + 1: return f(GNV<32, 1>{});
+    case 64 * 8 + 1: return f(GNV<64, 1>{});
+    case 64 * 8 + 2: return f(GNV<64, 2>{});
+    case 64 * 8 + 3: return f(GNV<64, 3>{});
+    case 64 * 8 + 4: return f(GNV<64, 4>{});
+    default: return fail(BPR_ERR_UNSUPPORTED, "unsupported embedding dim");
+  }
+}
+
+static int max_blocks() {
+  static int v = [] {
+    const char* e = getenv("BPR_MAX_BLOCKS");
+    int n = e ? atoi(e) : 0;
+    return n > 0 ? n : 256 * 8;  // 256 CUs x 8 resident 256-thread blocks
+  }();
+  return v;
+}
+
+// grid for n groups of G lanes, 256-thread blocks, capped (grid-stride inside the kernels)
+static unsigned grid_for(int64_t n_groups, int G, int64_t cap_groups) {
+  if (cap_groups > 0 && n_groups > cap_groups) n_groups = cap_groups;
+  const int64_t per_block = 256 / G;
+  int64_t blocks = (n_groups + per_block - 1) / per_block;
+  if (blocks > max_blocks()) blocks = max_blocks();
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+static int check_bound(const bpr_ctx* c, const char* who) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, std::string(who) + ": ctx is NULL");
+  if (c->P == nullptr || c->Q == nullptr)
+    return fail(BPR_ERR_INVALID, std::string(who) + ": tables not bound (bpr_bind_tables)");
+  return BPR_OK;
+}
+
+static int ensure_strict_scratch(bpr_ctx* c) {
+  if (c->GP != nullptr) return BPR_OK;
+  const size_t nP = (size_t)c->U * c->d, nQ = (size_t)c->I * c->d;
+  BPR_HIP_CHECK(hipMalloc(&c->GP, sizeof(float) * nP));
+  BPR_HIP_CHECK(hipMalloc(&c->GQ, sizeof(float) * nQ));
+  BPR_HIP_CHECK(hipMalloc(&c->Gb, sizeof(float) * c->I));
+  BPR_HIP_CHECK(hipMalloc(&c->flagP, sizeof(int32_t) * c->U));
+  BPR_HIP_CHECK(hipMalloc(&c->flagQ, sizeof(int32_t) * c->I));
+  BPR_HIP_CHECK(hipMalloc(&c->lastP, sizeof(int32_t) * c->U));
+  BPR_HIP_CHECK(hipMalloc(&c->lastQ, sizeof(int32_t) * c->I));
+  BPR_HIP_CHECK(hipMalloc(&c->touched, sizeof(uint32_t) * (size_t)(c->U + c->I)));
+  BPR_HIP_CHECK(hipMalloc(&c->touched_cnt, sizeof(uint32_t)));
+  BPR_HIP_CHECK(hipMemsetAsync(c->GP, 0, sizeof(float) * nP, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->GQ, 0, sizeof(float) * nQ, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->Gb, 0, sizeof(float) * c->I, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->flagP, 0, sizeof(int32_t) * c->U, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->flagQ, 0, sizeof(int32_t) * c->I, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->lastP, 0, sizeof(int32_t) * c->U, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->lastQ, 0, sizeof(int32_t) * c->I, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->touched_cnt, 0, sizeof(uint32_t), c->stream));
+  c->pending = 0;
+  return BPR_OK;
+}
+
+static void free_strict_scratch(bpr_ctx* c) {
+  hipFree(c->GP); hipFree(c->GQ); hipFree(c->Gb);
+  hipFree(c->flagP); hipFree(c->flagQ); hipFree(c->lastP); hipFree(c->lastQ);
+  hipFree(c->touched); hipFree(c->touched_cnt);
+  c->GP = c->GQ = c->Gb = nullptr;
+  c->flagP = c->flagQ = c->lastP = c->lastQ = nullptr;
+  c->touched = c->touched_cnt = nullptr;
+  c->pending = 0;
+}
+
+static TripleArgs triple_args(const bpr_ctx* c) {
+  TripleArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = c->P; a.Q = c->Q; a.bias = c->bias;
+  a.I = c->I; a.d = c->d;
+  a.pad_user = c->pad_user; a.pad_item = c->pad_item;
+  a.au = c->au; a.ai = c->ai; a.an = c->an; a.lr = c->opt.lr;
+  a.indptr = c->indptr; a.indices = c->indices;
+  a.order = c->order; a.sigma = c->sigma;
+  a.GP = c->GP; a.GQ = c->GQ; a.Gb = c->Gb;
+  a.flagP = c->flagP; a.flagQ = c->flagQ;
+  a.touched = c->touched; a.touched_cnt = c->touched_cnt;
+  return a;
+}
+
+static OptDev opt_dev(const bpr_ctx* c, int64_t t) {
+  OptDev o;
+  memset(&o, 0, sizeof(o));
+  o.kind = c->opt_kind;
+  o.lr = c->opt.lr; o.mu = c->opt.momentum; o.damp = c->opt.dampening;
+  o.nesterov = c->opt.nesterov;
+  o.b1 = c->opt.beta1; o.b2 = c->opt.beta2; o.eps = c->opt.eps; o.alpha = c->opt.alpha;
+  o.t = t;
+  auto safe_log = [](double x) { return x > 0.0 ? log(x) : -1.0e30; };
+  o.log_b1 = safe_log((double)o.b1);
+  o.log_b2 = safe_log((double)o.b2);
+  o.log_mu = safe_log((double)o.mu);
+  o.log_alpha = safe_log((double)o.alpha);
+  // Adam replay: terms decay like (b1/sqrt(b2))^s; stop once below 1e-8 of the first
+  o.kmax = 0;
+  if (o.kind == OPT_ADAM && o.b1 > 0.f) {
+    const double ratio = (double)o.b1 / sqrt((double)o.b2);
+    o.kmax = ratio < 1.0 ? (int)ceil(log(1e-8) / log(ratio)) : 1 << 20;
+  }
+  return o;
+}
+
+static ApplyArgs apply_args(const bpr_ctx* c, int64_t t) {
+  ApplyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = c->P; a.Q = c->Q; a.bias = c->bias;
+  a.GP = c->GP; a.GQ = c->GQ; a.Gb = c->Gb;
+  a.mP = c->mP; a.vP = c->vP; a.mQ = c->mQ; a.vQ = c->vQ; a.mb = c->mb; a.vb = c->vb;
+  a.lastP = c->lastP; a.lastQ = c->lastQ;
+  a.flagP = c->flagP; a.flagQ = c->flagQ;
+  a.touched = c->touched; a.touched_cnt = c->touched_cnt;
+  a.U = c->U; a.I = c->I; a.d = c->d;
+  a.pad_user = c->pad_user; a.pad_item = c->pad_item;
+  a.o = opt_dev(c, t);
+  return a;
+}
+
+static int check_opt_state(const bpr_ctx* c, const char* who) {
+  const bool need_m = c->opt_kind == BPR_OPT_MOMENTUM || c->opt_kind == BPR_OPT_ADAM;
+  const bool need_v = c->opt_kind == BPR_OPT_ADAM || c->opt_kind == BPR_OPT_RMSPROP;
+  if ((need_m && (!c->mP || !c->mQ || (c->bias && !c->mb))) ||
+      (need_v && (!c->vP || !c->vQ || (c->bias && !c->vb))))
+    return fail(BPR_ERR_INVALID,
+                std::string(who) + ": optimizer state not bound (bpr_bind_opt_state)");
+  return BPR_OK;
+}
+
+struct Timer {
+  bpr_ctx* c;
+  size_t slot = 0;
+  bool on = false;
+  Timer(bpr_ctx* ctx, bool enabled) : c(ctx) {
+    if (!enabled || !c->timing) return;
+    if (c->ev_used == c->ev_start.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      c->ev_start.push_back(a);
+      c->ev_stop.push_back(b);
+    }
+    slot = c->ev_used++;
+    on = true;
+    hipEventRecord(c->ev_start[slot], c->stream);
+  }
+  ~Timer() {
+    if (on) hipEventRecord(c->ev_stop[slot], c->stream);
+  }
+};
+
+static int drain_timing(bpr_ctx* c) {
+  if (c->ev_used == 0) return BPR_OK;
+  BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (size_t k = 0; k < c->ev_used; ++k) {
+    float ms = 0.f;
+    BPR_HIP_CHECK(hipEventElapsedTime(&ms, c->ev_start[k], c->ev_stop[k]));
+    c->timed_ms += (double)ms;
+    c->timed_launches += 1;
+  }
+  c->ev_used = 0;
+  return BPR_OK;
+}
+
+// ---- launches ---------------------------------------------------------------------------------
+template <int MODE>
+static int launch_triples(bpr_ctx* c, TripleArgs a, int sampler, int64_t cap_groups,
+                          bool timed) {
+  if (a.n <= 0) return BPR_OK;
+  return dispatch_gnv(c->G, c->NV, [&](auto tag) -> int {
+    using T = decltype(tag);
+    constexpr int G = T::G, NV = T::NV;
+    const unsigned grid = grid_for(a.n, G, cap_groups);
+    // a cap below one 256-thread block shrinks the block (whole waves), so max_inflight = 1 at
+    // G = 64 really is one wave walking the stream sequentially
+    unsigned block = 256;
+    if (cap_groups > 0 && cap_groups * G < 256) block = (unsigned)(((cap_groups * G + 63) / 64) * 64);
+    Timer tm(c, timed);
+    (void)tm;
+    if constexpr (MODE == MODE_STREAM) {
+      if (sampler == NEG_GIVEN)
+        hipLaunchKernelGGL((k_triples<G, NV, MODE_STREAM, NEG_GIVEN>), dim3(grid), dim3(block), 0,
+                           c->stream, a);
+      else if (sampler == NEG_UNIFORM)
+        hipLaunchKernelGGL((k_triples<G, NV, MODE_STREAM, NEG_UNIFORM>), dim3(grid), dim3(block), 0,
+                           c->stream, a);
+      else
+        hipLaunchKernelGGL((k_triples<G, NV, MODE_STREAM, NEG_ADAPTIVE>), dim3(grid), dim3(block),
+                           0, c->stream, a);
+    } else {
+      hipLaunchKernelGGL((k_triples<G, NV, MODE, NEG_GIVEN>), dim3(grid), dim3(block), 0,
+                         c->stream, a);
+    }
+    BPR_HIP_CHECK(hipGetLastError());
+    return BPR_OK;
+  });
+}
+
+}  // namespace bpr
+
+using namespace bpr;
+
+extern "C" {
+
+int bpr_version(void) { return BPRCORE_VERSION; }
+const char* bpr_last_error(void) { return g_last_error.c_str(); }
+
+int bpr_ctx_create(bpr_ctx** out, int device_id, void* hip_stream) {
+  if (out == nullptr) return fail(BPR_ERR_INVALID, "bpr_ctx_create: out is NULL");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(BPR_ERR_HIP, "bpr_ctx_create: no HIP device visible (libbprcore has no CPU path)");
+  if (device_id < 0 || device_id >= ndev)
+    return fail(BPR_ERR_INVALID, "bpr_ctx_create: bad device id");
+  BPR_HIP_CHECK(hipSetDevice(device_id));
+  bpr_ctx* c = new (std::nothrow) bpr_ctx();
+  if (c == nullptr) return fail(BPR_ERR_NOMEM, "bpr_ctx_create: out of host memory");
+  c->device = device_id;
+  c->stream = (hipStream_t)hip_stream;
+  if (hipMalloc(&c->dev_scalars, sizeof(float) * BPR_SCALARS) != hipSuccess) {
+    delete c;
+    return fail(BPR_ERR_HIP, "bpr_ctx_create: hipMalloc failed");
+  }
+  *out = c;
+  return BPR_OK;
+}
+
+int bpr_ctx_destroy(bpr_ctx* c) {
+  if (c == nullptr) return BPR_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  free_strict_scratch(c);
+  refresh_free(c);
+  hipFree(c->dev_scalars);
+  for (auto e : c->ev_start) hipEventDestroy(e);
+  for (auto e : c->ev_stop) hipEventDestroy(e);
+  delete c;
+  return BPR_OK;
+}
+
+int bpr_set_stream(bpr_ctx* c, void* hip_stream) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_stream: ctx is NULL");
+  c->stream = (hipStream_t)hip_stream;
+  return BPR_OK;
+}
+
+int bpr_bind_tables(bpr_ctx* c, float* P, int64_t U, float* Q, int64_t I, int32_t d,
+                    float* item_bias, int32_t pad_user, int32_t pad_item) {
+  if (c == nullptr || P == nullptr || Q == nullptr)
+    return fail(BPR_ERR_INVALID, "bpr_bind_tables: NULL argument");
+  if (U < 1 || I < 2 || U >= ((int64_t)1 << 30) || I >= ((int64_t)1 << 30))
+    return fail(BPR_ERR_INVALID, "bpr_bind_tables: table sizes out of range");
+  if (d < 8 || d > 1024 || (d % 4) != 0)
+    return fail(BPR_ERR_UNSUPPORTED,
+                "bpr_bind_tables: embedding dim must be a multiple of 4 in [8, 1024]");
+  if (((uintptr_t)P | (uintptr_t)Q) & 15u)
+    return fail(BPR_ERR_INVALID, "bpr_bind_tables: tables must be 16-byte aligned");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (c->U != U || c->I != I || c->d != d) {
+    BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    free_strict_scratch(c);
+    refresh_free(c);
+  }
+  c->P = P; c->Q = Q; c->bias = item_bias;
+  c->U = U; c->I = I; c->d = d;
+  c->pad_user = pad_user; c->pad_item = pad_item;
+  const int slices = d / 4;
+  int G = 2;
+  while (G < slices && G < 64) G <<= 1;
+  c->G = G;
+  c->NV = (slices + G - 1) / G;
+  return BPR_OK;
+}
+
+int bpr_bind_seen_csr(bpr_ctx* c, const int64_t* indptr, const int32_t* indices) {
+  if (c == nullptr || indptr == nullptr)
+    return fail(BPR_ERR_INVALID, "bpr_bind_seen_csr: NULL argument");
+  c->indptr = indptr;
+  c->indices = indices;
+  return BPR_OK;
+}
+
+int bpr_set_reg(bpr_ctx* c, float alpha_user, float alpha_item, float alpha_neg) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_reg: ctx is NULL");
+  c->au = alpha_user; c->ai = alpha_item; c->an = alpha_neg;
+  return BPR_OK;
+}
+
+int bpr_set_optimizer(bpr_ctx* c, int32_t kind, const bpr_opt_params* params) {
+  if (c == nullptr || params == nullptr)
+    return fail(BPR_ERR_INVALID, "bpr_set_optimizer: NULL argument");
+  if (kind < BPR_OPT_SGD || kind > BPR_OPT_RMSPROP)
+    return fail(BPR_ERR_INVALID, "bpr_set_optimizer: unknown optimizer kind");
+  if (kind == BPR_OPT_MOMENTUM && !(params->momentum >= 0.f && params->momentum < 1.f))
+    return fail(BPR_ERR_INVALID, "bpr_set_optimizer: momentum must be in [0, 1)");
+  c->opt_kind = kind;
+  c->opt = *params;
+  return BPR_OK;
+}
+
+int bpr_bind_opt_state(bpr_ctx* c, float* m_P, float* v_P, float* m_Q, float* v_Q, float* m_bias,
+                       float* v_bias) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_bind_opt_state: ctx is NULL");
+  c->mP = m_P; c->vP = v_P; c->mQ = m_Q; c->vQ = v_Q; c->mb = m_bias; c->vb = v_bias;
+  return BPR_OK;
+}
+
+// ---- sampling -----------------------------------------------------------------------------------
+static int launch_sample(bpr_ctx* c, int what, SampleArgs a) {
+  if (a.n <= 0) return BPR_OK;
+  return dispatch_gnv(c->G, c->NV, [&](auto tag) -> int {
+    using T = decltype(tag);
+    constexpr int G = T::G, NV = T::NV;
+    const unsigned grid = grid_for(a.n, G, 0);
+    if (what == SAMPLE_UNIFORM)
+      hipLaunchKernelGGL((k_sample<G, NV, SAMPLE_UNIFORM>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (what == SAMPLE_ADAPTIVE)
+      hipLaunchKernelGGL((k_sample<G, NV, SAMPLE_ADAPTIVE>), dim3(grid), dim3(256), 0, c->stream,
+                         a);
+    else
+      hipLaunchKernelGGL((k_sample<G, NV, SAMPLE_PICK>), dim3(grid), dim3(256), 0, c->stream, a);
+    BPR_HIP_CHECK(hipGetLastError());
+    return BPR_OK;
+  });
+}
+
+static SampleArgs sample_args(const bpr_ctx* c) {
+  SampleArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = c->P; a.I = c->I; a.d = c->d;
+  a.indptr = c->indptr; a.indices = c->indices;
+  a.order = c->order; a.sigma = c->sigma;
+  return a;
+}
+
+static float inv_log1mp(float p) { return (float)(1.0 / log1p(-(double)p)); }
+
+int bpr_sample_uniform(bpr_ctx* c, const int32_t* users, int64_t B, uint64_t seed, uint64_t offset,
+                       int32_t* neg_out) {
+  if (int rc = check_bound(c, "bpr_sample_uniform")) return rc;
+  if (c->indptr == nullptr) return fail(BPR_ERR_INVALID, "bpr_sample_uniform: seen CSR not bound");
+  if (users == nullptr || neg_out == nullptr || B < 0)
+    return fail(BPR_ERR_INVALID, "bpr_sample_uniform: bad argument");
+  SampleArgs a = sample_args(c);
+  a.users = users; a.n = B; a.seed = seed; a.offset = offset; a.neg = neg_out;
+  return launch_sample(c, SAMPLE_UNIFORM, a);
+}
+
+int bpr_adaptive_refresh(bpr_ctx* c) {
+  if (int rc = check_bound(c, "bpr_adaptive_refresh")) return rc;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  return refresh_impl(c);
+}
+
+int bpr_sample_adaptive(bpr_ctx* c, const int32_t* users, int64_t B, float p, uint64_t seed,
+                        uint64_t offset, int32_t* neg_out, int32_t* factor_out,
+                        int32_t* rank_out) {
+  if (int rc = check_bound(c, "bpr_sample_adaptive")) return rc;
+  if (c->indptr == nullptr) return fail(BPR_ERR_INVALID, "bpr_sample_adaptive: seen CSR not bound");
+  if (!c->have_snapshot)
+    return fail(BPR_ERR_INVALID, "bpr_sample_adaptive: call bpr_adaptive_refresh first");
+  if (!(p > 0.f && p < 1.f)) return fail(BPR_ERR_INVALID, "bpr_sample_adaptive: p not in (0,1)");
+  if (users == nullptr || neg_out == nullptr || B < 0)
+    return fail(BPR_ERR_INVALID, "bpr_sample_adaptive: bad argument");
+  SampleArgs a = sample_args(c);
+  a.users = users; a.n = B; a.seed = seed; a.offset = offset;
+  a.neg = neg_out; a.factor_out = factor_out; a.rank_out = rank_out;
+  a.inv_log1mp = inv_log1mp(p);
+  return launch_sample(c, SAMPLE_ADAPTIVE, a);
+}
+
+int bpr_adaptive_pick(bpr_ctx* c, const int32_t* users, const int32_t* factor, const int32_t* rank,
+                      int64_t B, int32_t* neg_out) {
+  if (int rc = check_bound(c, "bpr_adaptive_pick")) return rc;
+  if (c->indptr == nullptr || !c->have_snapshot)
+    return fail(BPR_ERR_INVALID, "bpr_adaptive_pick: seen CSR / snapshot missing");
+  if (!users || !factor || !rank || !neg_out || B < 0)
+    return fail(BPR_ERR_INVALID, "bpr_adaptive_pick: bad argument");
+  SampleArgs a = sample_args(c);
+  a.users = users; a.factor_in = factor; a.rank_in = rank; a.n = B; a.neg = neg_out;
+  return launch_sample(c, SAMPLE_PICK, a);
+}
+
+int bpr_adaptive_get_snapshot(bpr_ctx* c, int32_t* order_out, float* sigma_out) {
+  if (int rc = check_bound(c, "bpr_adaptive_get_snapshot")) return rc;
+  if (!c->have_snapshot) return fail(BPR_ERR_INVALID, "bpr_adaptive_get_snapshot: no snapshot");
+  if (order_out)
+    BPR_HIP_CHECK(hipMemcpyAsync(order_out, c->order, sizeof(int32_t) * (size_t)c->d * c->I,
+                                 hipMemcpyDeviceToDevice, c->stream));
+  if (sigma_out)
+    BPR_HIP_CHECK(hipMemcpyAsync(sigma_out, c->sigma, sizeof(float) * c->d,
+                                 hipMemcpyDeviceToDevice, c->stream));
+  return BPR_OK;
+}
+
+// ---- hot path -----------------------------------------------------------------------------------
+static int check_triples(const bpr_ctx* c, const char* who, const int32_t* users,
+                         const int32_t* pos, int64_t B) {
+  if (int rc = check_bound(c, who)) return rc;
+  if (users == nullptr || pos == nullptr || B < 0)
+    return fail(BPR_ERR_INVALID, std::string(who) + ": bad argument");
+  return BPR_OK;
+}
+
+int bpr_forward(bpr_ctx* c, const int32_t* users, const int32_t* pos, const int32_t* neg,
+                int64_t B, float* out_logits_pos, float* out_logits_neg, float* out_scalars) {
+  if (int rc = check_triples(c, "bpr_forward", users, pos, B)) return rc;
+  if (neg == nullptr) return fail(BPR_ERR_INVALID, "bpr_forward: neg is NULL");
+  TripleArgs a = triple_args(c);
+  a.users = users; a.pos = pos; a.neg = const_cast<int32_t*>(neg); a.n = B;
+  a.lpos = out_logits_pos; a.lneg = out_logits_neg; a.scalars = out_scalars;
+  return launch_triples<MODE_FORWARD>(c, a, NEG_GIVEN, 0, false);
+}
+
+int bpr_forward_grad(bpr_ctx* c, const int32_t* users, const int32_t* pos, const int32_t* neg,
+                     int64_t B, float* out_logits_pos, float* out_logits_neg, float* out_scalars) {
+  if (int rc = check_triples(c, "bpr_forward_grad", users, pos, B)) return rc;
+  if (neg == nullptr) return fail(BPR_ERR_INVALID, "bpr_forward_grad: neg is NULL");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = ensure_strict_scratch(c)) return rc;
+  TripleArgs a = triple_args(c);
+  a.users = users; a.pos = pos; a.neg = const_cast<int32_t*>(neg); a.n = B;
+  a.lpos = out_logits_pos; a.lneg = out_logits_neg; a.scalars = out_scalars;
+  c->pending += 3 * B;
+  if (c->pending > c->U + c->I) c->pending = c->U + c->I;
+  return launch_triples<MODE_GRAD>(c, a, NEG_GIVEN, 0, true);
+}
+
+int bpr_apply(bpr_ctx* c) {
+  if (int rc = check_bound(c, "bpr_apply")) return rc;
+  if (int rc = check_opt_state(c, "bpr_apply")) return rc;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = ensure_strict_scratch(c)) return rc;
+  c->step += 1;
+  if (c->pending > 0) {
+    ApplyArgs a = apply_args(c, c->step);
+    int rc = dispatch_gnv(c->G, c->NV, [&](auto tag) -> int {
+      using T = decltype(tag);
+      const unsigned grid = (unsigned)((c->pending * T::G + 255) / 256);
+      hipLaunchKernelGGL((k_apply<T::G, T::NV>), dim3(grid), dim3(256), 0, c->stream, a);
+      BPR_HIP_CHECK(hipGetLastError());
+      return BPR_OK;
+    });
+    if (rc) return rc;
+    BPR_HIP_CHECK(hipMemsetAsync(c->touched_cnt, 0, sizeof(uint32_t), c->stream));
+    c->pending = 0;
+  }
+  return BPR_OK;
+}
+
+int bpr_discard_grad(bpr_ctx* c) {
+  if (int rc = check_bound(c, "bpr_discard_grad")) return rc;
+  if (c->GP == nullptr || c->pending == 0) return BPR_OK;
+  ApplyArgs a = apply_args(c, c->step);
+  int rc = dispatch_gnv(c->G, c->NV, [&](auto tag) -> int {
+    using T = decltype(tag);
+    const unsigned grid = (unsigned)((c->pending * T::G + 255) / 256);
+    hipLaunchKernelGGL((k_discard<T::G, T::NV>), dim3(grid), dim3(256), 0, c->stream, a);
+    BPR_HIP_CHECK(hipGetLastError());
+    return BPR_OK;
+  });
+  if (rc) return rc;
+  BPR_HIP_CHECK(hipMemsetAsync(c->touched_cnt, 0, sizeof(uint32_t), c->stream));
+  c->pending = 0;
+  return BPR_OK;
+}
+
+int bpr_get_grad(bpr_ctx* c, float* gP, float* gQ, float* gbias) {
+  if (int rc = check_bound(c, "bpr_get_grad")) return rc;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = ensure_strict_scratch(c)) return rc;
+  if (gP)
+    BPR_HIP_CHECK(hipMemcpyAsync(gP, c->GP, sizeof(float) * (size_t)c->U * c->d,
+                                 hipMemcpyDeviceToDevice, c->stream));
+  if (gQ)
+    BPR_HIP_CHECK(hipMemcpyAsync(gQ, c->GQ, sizeof(float) * (size_t)c->I * c->d,
+                                 hipMemcpyDeviceToDevice, c->stream));
+  if (gbias)
+    BPR_HIP_CHECK(hipMemcpyAsync(gbias, c->Gb, sizeof(float) * (size_t)c->I,
+                                 hipMemcpyDeviceToDevice, c->stream));
+  return BPR_OK;
+}
+
+static int check_sampler(const bpr_ctx* c, const char* who, int32_t sampler, float adaptive_p,
+                         const int32_t* neg) {
+  if (sampler == BPR_NEG_GIVEN) {
+    if (neg == nullptr) return fail(BPR_ERR_INVALID, std::string(who) + ": neg is NULL");
+    return BPR_OK;
+  }
+  if (sampler != BPR_NEG_UNIFORM && sampler != BPR_NEG_ADAPTIVE)
+    return fail(BPR_ERR_INVALID, std::string(who) + ": unknown sampler");
+  if (c->indptr == nullptr) return fail(BPR_ERR_INVALID, std::string(who) + ": seen CSR not bound");
+  if (sampler == BPR_NEG_ADAPTIVE) {
+    if (!c->have_snapshot)
+      return fail(BPR_ERR_INVALID, std::string(who) + ": call bpr_adaptive_refresh first");
+    if (!(adaptive_p > 0.f && adaptive_p < 1.f))
+      return fail(BPR_ERR_INVALID, std::string(who) + ": adaptive_p not in (0,1)");
+  }
+  return BPR_OK;
+}
+
+int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t n,
+                     int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
+                     int64_t max_inflight, float* out_scalars) {
+  if (int rc = check_triples(c, "bpr_train_stream", users, pos, n)) return rc;
+  if (int rc = check_sampler(c, "bpr_train_stream", sampler, adaptive_p, neg)) return rc;
+  if (c->opt_kind != BPR_OPT_SGD)
+    return fail(BPR_ERR_UNSUPPORTED,
+                "bpr_train_stream: STREAM mode implements plain SGD only; use STRICT "
+                "(bpr_forward_grad + bpr_apply) for momentum / Adam / RMSprop");
+  if (c->pending != 0)
+    return fail(BPR_ERR_INVALID, "bpr_train_stream: unapplied STRICT gradients pending");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  TripleArgs a = triple_args(c);
+  a.users = users; a.pos = pos; a.neg = neg; a.n = n;
+  a.seed = seed; a.offset = offset;
+  a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
+  a.scalars = out_scalars;
+  return launch_triples<MODE_STREAM>(c, a, sampler, max_inflight, true);
+}
+
+int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t B,
+             int32_t mode, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
+             float* out_logits_pos, float* out_logits_neg, float* out_scalars) {
+  if (int rc = check_triples(c, "bpr_step", users, pos, B)) return rc;
+  if (int rc = check_sampler(c, "bpr_step", sampler, adaptive_p, neg)) return rc;
+  if (mode == BPR_MODE_STREAM) {
+    if (out_logits_pos || out_logits_neg)
+      return fail(BPR_ERR_UNSUPPORTED, "bpr_step: STREAM mode does not return logits");
+    return bpr_train_stream(c, users, pos, neg, B, sampler, adaptive_p, seed, offset, 0,
+                            out_scalars);
+  }
+  if (mode != BPR_MODE_STRICT) return fail(BPR_ERR_INVALID, "bpr_step: unknown mode");
+  if (sampler != BPR_NEG_GIVEN) {
+    if (neg == nullptr)
+      return fail(BPR_ERR_INVALID, "bpr_step: STRICT mode needs a neg buffer to sample into");
+    int rc = sampler == BPR_NEG_UNIFORM
+                 ? bpr_sample_uniform(c, users, B, seed, offset, neg)
+                 : bpr_sample_adaptive(c, users, B, adaptive_p, seed, offset, neg, nullptr,
+                                       nullptr);
+    if (rc) return rc;
+  }
+  if (int rc = bpr_forward_grad(c, users, pos, neg, B, out_logits_pos, out_logits_neg,
+                                out_scalars))
+    return rc;
+  return bpr_apply(c);
+}
+
+int bpr_flush_lazy(bpr_ctx* c) {
+  if (int rc = check_bound(c, "bpr_flush_lazy")) return rc;
+  if (c->opt_kind == BPR_OPT_SGD || c->GP == nullptr || c->step == 0) return BPR_OK;
+  if (int rc = check_opt_state(c, "bpr_flush_lazy")) return rc;
+  if (c->pending != 0)
+    return fail(BPR_ERR_INVALID, "bpr_flush_lazy: unapplied gradients pending");
+  ApplyArgs a = apply_args(c, c->step);
+  return dispatch_gnv(c->G, c->NV, [&](auto tag) -> int {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_flush_lazy<T::G, T::NV>), dim3(grid_for(c->U, T::G, 0)), dim3(256), 0,
+                       c->stream, a, 0);
+    hipLaunchKernelGGL((k_flush_lazy<T::G, T::NV>), dim3(grid_for(c->I, T::G, 0)), dim3(256), 0,
+                       c->stream, a, 1);
+    BPR_HIP_CHECK(hipGetLastError());
+    return BPR_OK;
+  });
+}
+
+int bpr_get_step_host(bpr_ctx* c, int64_t* step_host) {
+  if (c == nullptr || step_host == nullptr)
+    return fail(BPR_ERR_INVALID, "bpr_get_step_host: NULL argument");
+  *step_host = c->step;
+  return BPR_OK;
+}
+
+int bpr_set_step(bpr_ctx* c, int64_t step) {
+  if (c == nullptr || step < 0) return fail(BPR_ERR_INVALID, "bpr_set_step: bad argument");
+  // rows are assumed flushed at `step` (a checkpoint is written after bpr_flush_lazy)
+  c->step = step;
+  if (c->lastP != nullptr) {
+    BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::vector<int32_t> h((size_t)(c->U > c->I ? c->U : c->I), (int32_t)step);
+    BPR_HIP_CHECK(hipMemcpy(c->lastP, h.data(), sizeof(int32_t) * c->U, hipMemcpyHostToDevice));
+    BPR_HIP_CHECK(hipMemcpy(c->lastQ, h.data(), sizeof(int32_t) * c->I, hipMemcpyHostToDevice));
+  }
+  return BPR_OK;
+}
+
+int bpr_timing_enable(bpr_ctx* c, int32_t on) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_timing_enable: ctx is NULL");
+  if (int rc = drain_timing(c)) return rc;
+  c->timing = on != 0;
+  c->timed_ms = 0.0;
+  c->timed_launches = 0;
+  return BPR_OK;
+}
+
+int bpr_timing_read_host(bpr_ctx* c, double* avg_ms_host, int64_t* launches_host) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_timing_read_host: ctx is NULL");
+  if (int rc = drain_timing(c)) return rc;
+  if (avg_ms_host) *avg_ms_host = c->timed_launches ? c->timed_ms / (double)c->timed_launches : 0.0;
+  if (launches_host) *launches_host = c->timed_launches;
+  return BPR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+"""Torch-facing handle on the HIP BPR engine (libbprcore.so through ``revisit_bpr.native``).
+
+torch is used for device memory and streams only: every tensor handed in stays owned by the
+caller, the engine receives ``data_ptr()``s and mutates the embedding tables in place.  All
+methods are asynchronous on the current torch stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from revisit_bpr import native
+from revisit_bpr.native import (MODE_STREAM, MODE_STRICT, NEG_ADAPTIVE, NEG_GIVEN, NEG_UNIFORM,
+                                OPT_ADAM, OPT_MOMENTUM, OPT_RMSPROP, OPT_SGD)
+
+__all__ = ["Engine", "resolve_reg_alphas", "MODE_STREAM", "MODE_STRICT", "NEG_ADAPTIVE",
+           "NEG_GIVEN", "NEG_UNIFORM", "OPT_ADAM", "OPT_MOMENTUM", "OPT_RMSPROP", "OPT_SGD"]
+
+
+def resolve_reg_alphas(reg_alphas: Optional[dict]) -> tuple[float, float, float]:
+    """(user, item, neg) after the rules of the reference's Model.regularization
+    (revisit_bpr/models/bpr/model.py:74-86): `all` overrides; missing user/item → 0; missing neg →
+    item."""
+    reg = reg_alphas or {}
+    all_reg, user, item, neg = reg.get("all"), reg.get("user"), reg.get("item"), reg.get("neg")
+    if all(r is None for r in (all_reg, user, item, neg)):
+        return 0.0, 0.0, 0.0
+    if all_reg is not None:
+        user = item = neg = all_reg
+    user = user or 0
+    item = item or 0
+    neg = neg or item
+    return float(user), float(item), float(neg)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Engine:
+    """One bpr_ctx bound to a pair of embedding tables resident in HBM."""
+
+    def __init__(self, P: torch.Tensor, Q: torch.Tensor, item_bias: Optional[torch.Tensor] = None,
+                 pad_user: Optional[int] = 0, pad_item: Optional[int] = 0) -> None:
+        self._lib = native.load()
+        if not (P.is_cuda and Q.is_cuda):
+            raise RuntimeError("Engine needs the embedding tables on a ROCm device; there is no "
+                               "CPU path in libbprcore")
+        for name, t in (("P", P), ("Q", Q), ("item_bias", item_bias)):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+                raise ValueError(f"{name} must be a contiguous float32 tensor")
+        if P.shape[1] != Q.shape[1]:
+            raise ValueError("user and item tables must share the embedding dim")
+        self.device = P.device
+        self.P, self.Q, self.item_bias = P, Q, item_bias
+        self.U, self.d = P.shape
+        self.I = Q.shape[0]
+        self._ctx = ctypes.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        native.check(self._lib.bpr_ctx_create(ctypes.byref(self._ctx), idx, self._stream()))
+        native.check(self._lib.bpr_bind_tables(
+            self._ctx, P.data_ptr(), self.U, Q.data_ptr(), self.I, self.d, _ptr(item_bias),
+            -1 if pad_user is None else int(pad_user), -1 if pad_item is None else int(pad_item)))
+        self._keep: dict[str, object] = {}
+        self._scalars = torch.zeros(native.SCALARS, dtype=torch.float32, device=self.device)
+        self.opt_kind = OPT_SGD
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _sync_stream(self) -> None:
+        native.check(self._lib.bpr_set_stream(self._ctx, self._stream()))
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.bpr_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ids(self, t: torch.Tensor, name: str) -> torch.Tensor:
+        if not t.is_cuda:
+            raise ValueError(f"{name} must live on the GPU")
+        t = t.reshape(-1)
+        if t.dtype != torch.int32:
+            t = t.to(torch.int32)
+        return t.contiguous()
+
+    # ---- configuration ----------------------------------------------------------------------
+    def bind_seen_csr(self, indptr: torch.Tensor, indices: torch.Tensor) -> None:
+        """indptr [U+1] int64, indices [nnz] int32 (sorted per row, no 0, no duplicates)."""
+        if indptr.dtype != torch.int64 or indices.dtype != torch.int32:
+            raise ValueError("indptr must be int64 and indices int32")
+        if indptr.numel() != self.U + 1:
+            raise ValueError("indptr must have U+1 entries")
+        indptr, indices = indptr.contiguous(), indices.contiguous()
+        self._keep["csr"] = (indptr, indices)
+        native.check(self._lib.bpr_bind_seen_csr(self._ctx, indptr.data_ptr(), indices.data_ptr()))
+
+    def set_reg(self, user: float, item: float, neg: float) -> None:
+        native.check(self._lib.bpr_set_reg(self._ctx, user, item, neg))
+
+    def set_optimizer(self, kind: int, lr: float, momentum: float = 0.0, dampening: float = 0.0,
+                      nesterov: bool = False, betas=(0.9, 0.999), eps: float = 1e-8,
+                      alpha: float = 0.99) -> None:
+        prm = native.OptParams(lr, momentum, dampening, int(nesterov), betas[0], betas[1], eps,
+                               alpha)
+        native.check(self._lib.bpr_set_optimizer(self._ctx, kind, ctypes.byref(prm)))
+        self.opt_kind = kind
+
+    def bind_opt_state(self, mP=None, vP=None, mQ=None, vQ=None, mb=None, vb=None) -> None:
+        self._keep["opt_state"] = (mP, vP, mQ, vQ, mb, vb)
+        native.check(self._lib.bpr_bind_opt_state(self._ctx, _ptr(mP), _ptr(vP), _ptr(mQ), _ptr(vQ),
+                                                  _ptr(mb), _ptr(vb)))
+
+    def alloc_opt_state(self) -> dict:
+        """Zero state tensors of the shapes the current optimizer kind needs, bound to the ctx."""
+        z = torch.zeros_like
+        need_m = self.opt_kind in (OPT_MOMENTUM, OPT_ADAM)
+        need_v = self.opt_kind in (OPT_ADAM, OPT_RMSPROP)
+        st = {
+            "mP": z(self.P) if need_m else None, "vP": z(self.P) if need_v else None,
+            "mQ": z(self.Q) if need_m else None, "vQ": z(self.Q) if need_v else None,
+            "mb": z(self.item_bias) if need_m and self.item_bias is not None else None,
+            "vb": z(self.item_bias) if need_v and self.item_bias is not None else None,
+        }
+        self.bind_opt_state(**st)
+        return st
+
+    # ---- negative sampling ------------------------------------------------------------------
+    def sample_uniform(self, users: torch.Tensor, seed: int, offset: int = 0) -> torch.Tensor:
+        self._sync_stream()
+        users = self._ids(users, "users")
+        out = torch.empty_like(users)
+        native.check(self._lib.bpr_sample_uniform(self._ctx, users.data_ptr(), users.numel(), seed,
+                                                  offset, out.data_ptr()))
+        return out
+
+    def adaptive_refresh(self) -> None:
+        self._sync_stream()
+        native.check(self._lib.bpr_adaptive_refresh(self._ctx))
+
+    def sample_adaptive(self, users: torch.Tensor, p: float, seed: int, offset: int = 0,
+                        return_draws: bool = False):
+        self._sync_stream()
+        users = self._ids(users, "users")
+        neg = torch.empty_like(users)
+        fac = torch.empty_like(users) if return_draws else None
+        rnk = torch.empty_like(users) if return_draws else None
+        native.check(self._lib.bpr_sample_adaptive(self._ctx, users.data_ptr(), users.numel(), p,
+                                                   seed, offset, neg.data_ptr(), _ptr(fac),
+                                                   _ptr(rnk)))
+        return (neg, fac, rnk) if return_draws else neg
+
+    def adaptive_pick(self, users, factor, rank) -> torch.Tensor:
+        self._sync_stream()
+        users, factor, rank = (self._ids(users, "users"), self._ids(factor, "factor"),
+                               self._ids(rank, "rank"))
+        neg = torch.empty_like(users)
+        native.check(self._lib.bpr_adaptive_pick(self._ctx, users.data_ptr(), factor.data_ptr(),
+                                                 rank.data_ptr(), users.numel(), neg.data_ptr()))
+        return neg
+
+    def adaptive_snapshot(self) -> tuple[torch.Tensor, torch.Tensor]:
+        self._sync_stream()
+        order = torch.empty((self.d, self.I), dtype=torch.int32, device=self.device)
+        sigma = torch.empty(self.d, dtype=torch.float32, device=self.device)
+        native.check(self._lib.bpr_adaptive_get_snapshot(self._ctx, order.data_ptr(),
+                                                         sigma.data_ptr()))
+        return order, sigma
+
+    # ---- hot path ---------------------------------------------------------------------------
+    def _outs(self, B: int, want_logits: bool, scalars: Optional[torch.Tensor]):
+        lp = torch.empty(B, dtype=torch.float32, device=self.device) if want_logits else None
+        ln = torch.empty(B, dtype=torch.float32, device=self.device) if want_logits else None
+        if scalars is None:
+            scalars = torch.zeros(native.SCALARS, dtype=torch.float32, device=self.device)
+        return lp, ln, scalars
+
+    def forward(self, users, pos, neg, scalars=None):
+        self._sync_stream()
+        users, pos, neg = self._ids(users, "users"), self._ids(pos, "pos"), self._ids(neg, "neg")
+        lp, ln, sc = self._outs(users.numel(), True, scalars)
+        native.check(self._lib.bpr_forward(self._ctx, users.data_ptr(), pos.data_ptr(),
+                                           neg.data_ptr(), users.numel(), lp.data_ptr(),
+                                           ln.data_ptr(), sc.data_ptr()))
+        return lp, ln, sc
+
+    def forward_grad(self, users, pos, neg, scalars=None):
+        self._sync_stream()
+        users, pos, neg = self._ids(users, "users"), self._ids(pos, "pos"), self._ids(neg, "neg")
+        lp, ln, sc = self._outs(users.numel(), True, scalars)
+        native.check(self._lib.bpr_forward_grad(self._ctx, users.data_ptr(), pos.data_ptr(),
+                                                neg.data_ptr(), users.numel(), lp.data_ptr(),
+                                                ln.data_ptr(), sc.data_ptr()))
+        return lp, ln, sc
+
+    def apply(self) -> None:
+        self._sync_stream()
+        native.check(self._lib.bpr_apply(self._ctx))
+
+    def discard_grad(self) -> None:
+        self._sync_stream()
+        native.check(self._lib.bpr_discard_grad(self._ctx))
+
+    def get_grad(self):
+        self._sync_stream()
+        gP, gQ = torch.empty_like(self.P), torch.empty_like(self.Q)
+        gb = torch.empty(self.I, dtype=torch.float32, device=self.device)
+        native.check(self._lib.bpr_get_grad(self._ctx, gP.data_ptr(), gQ.data_ptr(),
+                                            gb.data_ptr()))
+        return gP, gQ, gb
+
+    def step(self, users, pos, neg=None, mode: int = MODE_STRICT, sampler: int = NEG_GIVEN,
+             adaptive_p: float = 0.01, seed: int = 0, offset: int = 0, scalars=None,
+             want_logits: bool = True):
+        """One reference iteration (sample → forward → backward → optimizer step)."""
+        self._sync_stream()
+        users, pos = self._ids(users, "users"), self._ids(pos, "pos")
+        if neg is None:
+            neg = torch.empty_like(users)
+        else:
+            neg = self._ids(neg, "neg")
+        lp, ln, sc = self._outs(users.numel(), want_logits and mode == MODE_STRICT, scalars)
+        native.check(self._lib.bpr_step(self._ctx, users.data_ptr(), pos.data_ptr(),
+                                        neg.data_ptr(), users.numel(), mode, sampler, adaptive_p,
+                                        seed, offset, _ptr(lp), _ptr(ln), sc.data_ptr()))
+        return lp, ln, sc, neg
+
+    def train_stream(self, users, pos, sampler: int = NEG_UNIFORM, neg: Optional[torch.Tensor] = None,
+                     adaptive_p: float = 0.01, seed: int = 0, offset: int = 0,
+                     max_inflight: int = 0, scalars: Optional[torch.Tensor] = None) -> None:
+        """STREAM mode over users/pos (int32, on device) in one launch; `scalars` (if given) is
+        added to."""
+        self._sync_stream()
+        if users.dtype != torch.int32 or pos.dtype != torch.int32:
+            raise ValueError("train_stream takes int32 id tensors (no hidden copies on the hot path)")
+        if sampler == NEG_GIVEN and neg is None:
+            raise ValueError("sampler NEG_GIVEN needs `neg`")
+        native.check(self._lib.bpr_train_stream(self._ctx, users.data_ptr(), pos.data_ptr(),
+                                                _ptr(neg), users.numel(), sampler, adaptive_p, seed,
+                                                offset, max_inflight, _ptr(scalars)))
+
+    def flush_lazy(self) -> None:
+        self._sync_stream()
+        native.check(self._lib.bpr_flush_lazy(self._ctx))
+
+    @property
+    def step_count(self) -> int:
+        v = ctypes.c_int64()
+        native.check(self._lib.bpr_get_step_host(self._ctx, ctypes.byref(v)))
+        return v.value
+
+    def set_step(self, step: int) -> None:
+        native.check(self._lib.bpr_set_step(self._ctx, step))
+
+    # ---- measurement ------------------------------------------------------------------------
+    def timing_enable(self, on: bool = True) -> None:
+        native.check(self._lib.bpr_timing_enable(self._ctx, int(on)))
+
+    def timing_read(self) -> tuple[float, int]:
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        native.check(self._lib.bpr_timing_read_host(self._ctx, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value

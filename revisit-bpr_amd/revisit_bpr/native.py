@@ -1,0 +1,104 @@
+"""ctypes binding of libbprcore.so (include/bprcore.h) — the only door into the HIP engine.
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible, every entry
+point raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C revisit-bpr_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent.parent / "libbprcore.so"
+
+OK = 0
+OPT_SGD, OPT_MOMENTUM, OPT_ADAM, OPT_RMSPROP = 0, 1, 2, 3
+MODE_STRICT, MODE_STREAM = 0, 1
+NEG_GIVEN, NEG_UNIFORM, NEG_ADAPTIVE = 0, 1, 2
+SCALARS = 4
+
+
+class OptParams(ctypes.Structure):
+    """struct bpr_opt_params"""
+
+    _fields_ = [
+        ("lr", c_float),
+        ("momentum", c_float),
+        ("dampening", c_float),
+        ("nesterov", c_int32),
+        ("beta1", c_float),
+        ("beta2", c_float),
+        ("eps", c_float),
+        ("alpha", c_float),
+    ]
+
+
+class BprError(RuntimeError):
+    def __init__(self, code: int, msg: str) -> None:
+        super().__init__(f"libbprcore error {code}: {msg}")
+        self.code = code
+
+
+# name -> (restype, argtypes); mirrors include/bprcore.h one to one
+SIGNATURES = {
+    "bpr_version": (c_int, []),
+    "bpr_last_error": (c_char_p, []),
+    "bpr_ctx_create": (c_int, [POINTER(c_void_p), c_int, c_void_p]),
+    "bpr_ctx_destroy": (c_int, [c_void_p]),
+    "bpr_set_stream": (c_int, [c_void_p, c_void_p]),
+    "bpr_bind_tables": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
+                                c_int32, c_int32]),
+    "bpr_bind_seen_csr": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "bpr_set_reg": (c_int, [c_void_p, c_float, c_float, c_float]),
+    "bpr_set_optimizer": (c_int, [c_void_p, c_int32, POINTER(OptParams)]),
+    "bpr_bind_opt_state": (c_int, [c_void_p] + [c_void_p] * 6),
+    "bpr_sample_uniform": (c_int, [c_void_p, c_void_p, c_int64, c_uint64, c_uint64, c_void_p]),
+    "bpr_adaptive_refresh": (c_int, [c_void_p]),
+    "bpr_sample_adaptive": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_uint64, c_uint64,
+                                    c_void_p, c_void_p, c_void_p]),
+    "bpr_adaptive_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "bpr_adaptive_get_snapshot": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "bpr_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                            c_void_p]),
+    "bpr_forward_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                 c_void_p, c_void_p]),
+    "bpr_apply": (c_int, [c_void_p]),
+    "bpr_discard_grad": (c_int, [c_void_p]),
+    "bpr_get_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bpr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float,
+                         c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "bpr_train_stream": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
+                                 c_uint64, c_uint64, c_int64, c_void_p]),
+    "bpr_flush_lazy": (c_int, [c_void_p]),
+    "bpr_get_step_host": (c_int, [c_void_p, POINTER(c_int64)]),
+    "bpr_set_step": (c_int, [c_void_p, c_int64]),
+    "bpr_timing_enable": (c_int, [c_void_p, c_int32]),
+    "bpr_timing_read_host": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libbprcore.so and declare every prototype.  Raises if the library is missing."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run __graft_entry__.build() (or `make -C revisit-bpr_amd/csrc`). "
+                "There is no CPU fallback."
+            )
+        lib = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise BprError(rc, (load().bpr_last_error() or b"").decode("utf-8", "replace"))
