@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="ml-20m")
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--sampler", choices=["adaptive", "uniform"], default="adaptive")
+    ap.add_argument("--sampler", choices=["adaptive", "uniform", "given"], default="adaptive")
     ap.add_argument("--adaptive-p", type=float, default=0.01)
     ap.add_argument("--lr", type=float, default=0.001)
     ap.add_argument("--batch-size", type=int, default=256,
@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--sync-every", type=int, default=1, help="item all-reduce period in steps (N>1)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink users/actions (debug)")
     ap.add_argument("--max-inflight", type=int, default=0)
+    ap.add_argument("--run-len", type=int, default=8)
+    ap.add_argument("--ungrouped", action="store_true", help="all-atomic user rows (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=13)
@@ -134,26 +136,32 @@ def main():
     e.set_reg(*reg)
     e.set_optimizer(eng.OPT_SGD, lr=args.lr)
     e.bind_seen_csr(torch.from_numpy(data.indptr).to(dev), torch.from_numpy(data.indices).to(dev))
-    sampler = eng.NEG_ADAPTIVE if args.sampler == "adaptive" else eng.NEG_UNIFORM
+    sampler = {"adaptive": eng.NEG_ADAPTIVE, "uniform": eng.NEG_UNIFORM, "given": eng.NEG_GIVEN}[args.sampler]
 
-    # epoch order: a seeded permutation of the triple list, shuffled once on device
-    perm = torch.randperm(data.nnz, device=dev, generator=torch.Generator(dev).manual_seed(args.seed))
-    users = torch.from_numpy(data.users).to(dev)[perm].contiguous()
-    items = torch.from_numpy(data.items).to(dev)[perm].contiguous()
+    # epoch order: bpr_plan_epoch = seeded pseudo-random partition of the triple list into chunks of
+    # one refresh period, each grouped by user (the STREAM kernel keeps the user row in registers)
     every = max(1, int(I * math.log(I) / args.batch_size))  # example.py:302
     chunk = min(every * args.batch_size, data.nnz)
     n_chunks = max(1, data.nnz // chunk)
+    src_users = torch.from_numpy(data.users).to(dev)
+    src_items = torch.from_numpy(data.items).to(dev)
+    users, items = torch.empty_like(src_users), torch.empty_like(src_items)
+    e.set_stream_opts(not args.ungrouped, args.run_len)
     sync = ItemSync([Q]) if world > 1 else None
     scalars = torch.zeros(4, device=dev)
     seed = args.seed
+    given_neg = (torch.randint(1, I, (chunk,), device=dev, dtype=torch.int32)
+                 if sampler == eng.NEG_GIVEN else None)  # measurement aid only
 
     def step(k: int):
         c = k % n_chunks
         lo = c * chunk
+        if c == 0:  # new epoch: re-plan (inside the timed region — it is part of the job)
+            e.plan_epoch(src_users, src_items, chunk, seed + k // n_chunks, out=(users, items))
         if sampler == eng.NEG_ADAPTIVE:
             e.adaptive_refresh()
         e.train_stream(users[lo:lo + chunk], items[lo:lo + chunk], sampler=sampler,
-                       adaptive_p=args.adaptive_p, seed=seed,
+                       neg=given_neg, adaptive_p=args.adaptive_p, seed=seed,
                        offset=(rank << 40) + k * chunk, max_inflight=args.max_inflight,
                        scalars=scalars)
         if sync is not None and (k + 1) % args.sync_every == 0:
@@ -166,13 +174,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
+    step(0)  # plans the first epoch
+    for k in range(1, args.warmup + 1):
         step(k)
     barrier()
     e.timing_enable(True)
     scalars.zero_()
     t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
+    for k in range(args.warmup + 1, args.warmup + 1 + args.steps):
         step(k)
     if sync is not None:
         sync.finish()
@@ -218,7 +227,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_triples<G=32,NV=1,STREAM,%s>" % args.sampler.upper(),
+                "kernel": "k_stream<G=%d,E=%d,%s>" % (32 if d <= 128 else 64, max(1, -(-d // (32 if d <= 128 else 64))), args.sampler.upper()),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -18,6 +18,7 @@
  *     ctx was created with (pass torch's current stream) — except bpr_ctx_create/destroy and the
  *     `*_host` getters, which synchronise that stream.
  *   - A ctx is single-threaded and tied to one HIP device + stream.
+ *   - Embedding dim d in [1, 1024]; tables row-major fp32, 4-byte aligned.
  *   - Row 0 of both tables is the pad row (reference: nn.Embedding(padding_idx=0)); item ids
  *     handed to the library are in [0, I), user ids in [0, U).  Ids are int32.
  */
@@ -38,7 +39,7 @@ typedef enum bpr_status {
   BPR_OK = 0,
   BPR_ERR_INVALID = -1,     /* bad argument / state (message says which) */
   BPR_ERR_HIP = -2,         /* a HIP runtime call failed */
-  BPR_ERR_UNSUPPORTED = -3, /* valid request the engine does not implement (e.g. d not multiple of 4) */
+  BPR_ERR_UNSUPPORTED = -3, /* valid request the engine does not implement (e.g. d > 1024) */
   BPR_ERR_NOMEM = -4
 } bpr_status;
 
@@ -170,6 +171,21 @@ int bpr_step(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* ne
 int bpr_train_stream(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
                      int64_t n, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
                      int64_t max_inflight, float* out_scalars);
+
+/* STREAM options.  grouped_by_user = 1 promises that inside every chunk handed to
+ * bpr_train_stream the triples of a user are contiguous (the output of bpr_plan_epoch): a user
+ * whose triples all fall in one run of `run_len` consecutive triples is then owned by one
+ * wavefront group for the whole launch and its row is written back with a plain store; with 0
+ * (default) every user-row update is an atomic add.  run_len (default 8) = consecutive triples one
+ * group walks with the user row held in registers. */
+int bpr_set_stream_opts(bpr_ctx* ctx, int32_t grouped_by_user, int32_t run_len);
+
+/* Epoch order for STREAM mode — replaces DataLoader(shuffle=True, generator=manual_seed(seed))
+ * (example.py:307-321; experiments/bpr/exp.py:109-118): a seeded pseudo-random partition of the n
+ * training triples into ceil(n/chunk) chunks of `chunk` triples (the last may be shorter); inside a
+ * chunk triples are grouped by user.  users_out/pos_out [n] must not alias the inputs. */
+int bpr_plan_epoch(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_in, int64_t n,
+                   int64_t chunk, uint64_t seed, int32_t* users_out, int32_t* pos_out);
 
 /* Dense-optimizer equivalence: torch's dense Adam / momentum move EVERY row on every
  * step.  The strict path replays the missed zero-gradient steps lazily when a row is next

@@ -16,7 +16,9 @@ struct bpr_ctx {
   float* Q = nullptr;
   float* bias = nullptr;
   int64_t U = 0, I = 0;
-  int d = 0, G = 0, NV = 0;
+  int d = 0, G = 0, E = 0;
+  bool grouped = false;  // STREAM: chunks are grouped by user (bpr_plan_epoch output)
+  int run_len = 8;       // STREAM: consecutive triples walked by one group
   int pad_user = -1, pad_item = -1;
   const int64_t* indptr = nullptr;
   const int32_t* indices = nullptr;
@@ -37,12 +39,18 @@ struct bpr_ctx {
   int32_t* order = nullptr;  // [d, I]
   float* sigma = nullptr;    // [d]
   float* keysT = nullptr;    // [d, I] transposed item table
-  float* keys_sorted = nullptr;
+  float* keys_sorted = nullptr;  // 2 x [d, I] uint64 composite sort keys (in | out)
   int32_t* ids_in = nullptr;
   int32_t* seg_offsets = nullptr;  // [d+1]
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   bool have_snapshot = false;
+  // private scratch — epoch planner
+  uint64_t* plan_keys = nullptr;
+  uint64_t* plan_keys_sorted = nullptr;
+  void* plan_tmp = nullptr;
+  size_t plan_tmp_bytes = 0;
+  int64_t plan_cap = 0;
   // scalar slots
   float* dev_scalars = nullptr;
   // timing of the dominant kernel
@@ -57,6 +65,8 @@ namespace bpr {
 void set_error(const std::string& msg);
 int refresh_impl(bpr_ctx* c);       // bpr_refresh.hip
 void refresh_free(bpr_ctx* c);      // bpr_refresh.hip
+int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n,
+                    int64_t chunk, uint64_t seed, int32_t* users_out, int32_t* pos_out);
 }  // namespace bpr
 
 #define BPR_HIP_CHECK(expr)                                                              \

@@ -1,10 +1,12 @@
 // bpr_device.h — device-side building blocks of libbprcore (gfx950 / CDNA4, wave64).
 //
-// Work decomposition: a *group* of G lanes (G = 2..64, a power of two dividing the 64-lane wave)
-// owns one BPR triple.  Lane gl of the group holds 16-byte slices [c*4G + 4gl, +4) of each of the
-// three embedding rows (NV slices per row), so every row access is a run of consecutive 16-B
-// lanes: one fully coalesced 64*16 B = 1 KiB wave transaction covers 64/G rows' slices.
-// d=128 → G=32, NV=1 (two triples per wave); d=256 → G=64; d=1024 → G=64, NV=4.
+// Work decomposition: a *group* of G lanes (G = 32 for d <= 128, else 64) owns one BPR triple.
+// Lane gl of the group holds elements {e*G + gl : e < E} of each embedding row, so every row access
+// — load OR fp32 atomic — is a run of G consecutive dwords per instruction: 128 B (one cache line)
+// per group at G = 32, 256 B at G = 64.  That layout is dictated by the atomics: the chip retires
+// device-scope fp32 atomics at a fixed rate of ~9-10 G cache-line requests/s regardless of how many
+// lanes hit the line (measured, tools/ubench/gs_bench.hip: float4-per-lane rows → 4 partial-line
+// requests per row slice, 188 M triples/s; dword-per-lane rows → full lines, 740 M triples/s).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -81,8 +83,11 @@ __device__ __forceinline__ float group_scan_incl(float v, int gl) {
 template <int G>
 __device__ __forceinline__ uint64_t group_ballot(bool pred, int lane) {
   const uint64_t full = __ballot(pred);
-  if constexpr (G == 64) return full;
-  return (full >> (lane & ~(G - 1))) & ((1ull << G) - 1ull);
+  if constexpr (G == 64) {
+    return full;
+  } else {
+    return (full >> (lane & ~(G - 1))) & ((1ull << G) - 1ull);
+  }
 }
 // value held by lane `src` of the caller's group
 template <int G, typename T>
@@ -104,6 +109,21 @@ __device__ __forceinline__ bool csr_contains(const int32_t* __restrict__ indices
   return false;
 }
 
+// "has user u seen item c?" — two interchangeable answers
+struct SeenCsr {  // binary search in the user's sorted CSR slice (≈ log2(n_u) dependent loads)
+  const int32_t* __restrict__ indices;
+  int64_t lo, hi;
+  __device__ __forceinline__ bool operator()(int32_t c) const {
+    return csr_contains(indices, lo, hi, c);
+  }
+};
+struct SeenBitmap {  // one LDS read: the group's I-bit bitmap of the current user (k_stream)
+  const uint32_t* bm;
+  __device__ __forceinline__ bool operator()(int32_t c) const {
+    return ((bm[c >> 5] >> (c & 31)) & 1u) != 0u;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Uniform negative: UniformSampler.sample (reference revisit_bpr/modules/neg_samplers.py:31-37),
 // i.e. uniform over items ∉ seen(u) ∪ {0}.  Candidate k of triple t is
@@ -111,13 +131,10 @@ __device__ __forceinline__ bool csr_contains(const int32_t* __restrict__ indices
 // the result is the first accepted candidate.  A group tests G candidates per round.
 // All lanes of the wave must call this together (wave-uniform loop).
 // ---------------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ int32_t sample_uniform(const int64_t* __restrict__ indptr,
-                                                  const int32_t* __restrict__ indices, int64_t I,
-                                                  int32_t user, uint64_t seed, uint64_t t,
-                                                  int lane) {
+template <int G, typename Seen>
+__device__ __forceinline__ int32_t sample_uniform(const Seen& seen, int64_t I, uint64_t seed,
+                                                  uint64_t t, int lane) {
   const int gl = lane & (G - 1);
-  const int64_t lo = indptr[user], hi = indptr[user + 1];
   int32_t result = 0;
   bool done = false;
   constexpr int ROUNDS = UNIFORM_MAX_CAND / G;
@@ -125,7 +142,7 @@ __device__ __forceinline__ int32_t sample_uniform(const int64_t* __restrict__ in
     const uint32_t k = (uint32_t)(round * G + gl);
     const uint32_t r = draw(seed, t, k >> 2, PURPOSE_UNIFORM, (int)(k & 3u));
     const int32_t c = 1 + (int32_t)__umulhi(r, (uint32_t)(I - 1));
-    const bool ok = !csr_contains(indices, lo, hi, c);
+    const bool ok = !seen(c);
     const uint64_t m = group_ballot<G>(ok, lane);
     const int first = m ? (__ffsll((unsigned long long)m) - 1) : 0;
     const int32_t cand = group_bcast<G>(c, first, lane);
@@ -142,7 +159,7 @@ __device__ __forceinline__ int32_t sample_uniform(const int64_t* __restrict__ in
 // Adaptive negative: AdaptiveSampler.sample (neg_samplers.py:74-124).
 //   order [d, I]  per-factor descending item order of the last snapshot (bpr_adaptive_refresh)
 //   sigma [d]     per-factor unbiased std of the snapshot
-// p[] are the caller's register copies of the LIVE user row (slice layout of this file).
+// p[] are the caller's register copies of the LIVE user row (element layout of this file).
 // ---------------------------------------------------------------------------------------------
 struct AdaptiveDraw {
   int32_t factor;
@@ -150,35 +167,44 @@ struct AdaptiveDraw {
   int32_t item;
 };
 
-// rank-th (0-based, from the top) item of order[f] that is not in seen(u) ∪ {0}; walks from the
-// nearer end: `from_top` selects the direction, `skip` = unseen items to pass first.
-template <int G>
+// item number `skip` (0-based) among the items of order_f that are not in seen(u) ∪ {0}, counting
+// from the top (from_top) or from the bottom of the order.  WALK_UNROLL chunks of G order entries
+// are fetched per trip so the (coalesced, independent) loads overlap.
+constexpr int WALK_UNROLL = 4;
+
+template <int G, typename Seen>
 __device__ __forceinline__ int32_t adaptive_walk(const int32_t* __restrict__ order_f, int64_t I,
-                                                 const int32_t* __restrict__ indices, int64_t lo,
-                                                 int64_t hi, bool from_top, int32_t skip,
+                                                 const Seen& seen, bool from_top, int32_t skip,
                                                  int lane) {
   const int gl = lane & (G - 1);
   int32_t result = 0;
   bool done = false;
-  for (int64_t base = 0; base < I; base += G) {
-    const int64_t k = base + gl;
-    const bool valid = k < I;
-    const int64_t tpos = from_top ? k : (I - 1 - k);
-    const int32_t item = valid ? order_f[tpos] : 0;
-    const bool unseen = valid && item != 0 && !csr_contains(indices, lo, hi, item);
-    const uint64_t m = group_ballot<G>(unseen, lane);
-    const int cnt = __popcll((unsigned long long)m);
-    const int below = __popcll((unsigned long long)(m & ((1ull << gl) - 1ull)));
-    const bool mine = !done && unseen && (below == skip);
-    const uint64_t hit = group_ballot<G>(mine, lane);
-    const int src = hit ? (__ffsll((unsigned long long)hit) - 1) : 0;
-    const int32_t got = group_bcast<G>(item, src, lane);
-    if (!done) {
-      if (hit) {
-        result = got;
-        done = true;
-      } else {
-        skip -= cnt;
+  for (int64_t base = 0; base < I; base += (int64_t)G * WALK_UNROLL) {
+    int32_t items[WALK_UNROLL];
+#pragma unroll
+    for (int c = 0; c < WALK_UNROLL; ++c) {
+      const int64_t k = base + (int64_t)c * G + gl;
+      const int64_t tpos = from_top ? k : (I - 1 - k);
+      items[c] = (k < I) ? order_f[tpos] : 0;  // 0 = pad item = never a candidate
+    }
+#pragma unroll
+    for (int c = 0; c < WALK_UNROLL; ++c) {
+      const int32_t item = items[c];
+      const bool unseen = item != 0 && !seen(item);
+      const uint64_t m = group_ballot<G>(unseen, lane);
+      const int cnt = __popcll((unsigned long long)m);
+      const int below = __popcll((unsigned long long)(m & ((1ull << gl) - 1ull)));
+      const bool mine = !done && unseen && (below == skip);
+      const uint64_t hit = group_ballot<G>(mine, lane);
+      const int src = hit ? (__ffsll((unsigned long long)hit) - 1) : 0;
+      const int32_t got = group_bcast<G>(item, src, lane);
+      if (!done) {
+        if (hit) {
+          result = got;
+          done = true;
+        } else {
+          skip -= cnt;
+        }
       }
     }
     if (__all(done)) break;
@@ -186,48 +212,35 @@ __device__ __forceinline__ int32_t adaptive_walk(const int32_t* __restrict__ ord
   return result;
 }
 
-template <int G, int NV>
+template <int G, int E, typename Seen>
 __device__ __forceinline__ AdaptiveDraw sample_adaptive(
-    const float4 (&p)[NV], int d, const float* __restrict__ sigma,
-    const int32_t* __restrict__ order, int64_t I, const int64_t* __restrict__ indptr,
-    const int32_t* __restrict__ indices, int32_t user, float inv_log1mp, uint64_t seed, uint64_t t,
-    int lane) {
+    const float (&p)[E], int d, const float* __restrict__ sigma,
+    const int32_t* __restrict__ order, int64_t I, const Seen& seen, int64_t n_seen,
+    float inv_log1mp, uint64_t seed, uint64_t t, int lane) {
   const int gl = lane & (G - 1);
   const u32x4 rnd = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), 0u, PURPOSE_ADAPTIVE,
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
-  // ---- factor ~ Categorical(|p_uf|·σ_f)  (neg_samplers.py:84-88), inverse CDF in element order
-  float w[NV][4];
-  float incl[NV];  // inclusive scan (over lanes) of this lane's slice sum, per chunk
-  float carry[NV]; // total weight of all earlier chunks
+  // ---- factor ~ Categorical(|p_uf|·σ_f)  (neg_samplers.py:84-88): inverse CDF in factor order
+  // f = e*G + gl, i.e. chunk e after chunk e-1, lanes in order inside a chunk
+  float w[E], incl[E], carry[E];
   float total = 0.f;
 #pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    const int f0 = c * 4 * G + 4 * gl;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f0 < d) s = *reinterpret_cast<const float4*>(sigma + f0);
-    w[c][0] = fabsf(p[c].x) * s.x;
-    w[c][1] = fabsf(p[c].y) * s.y;
-    w[c][2] = fabsf(p[c].z) * s.z;
-    w[c][3] = fabsf(p[c].w) * s.w;
-    const float local = (w[c][0] + w[c][1]) + (w[c][2] + w[c][3]);
-    incl[c] = group_scan_incl<G>(local, gl);
-    carry[c] = total;
-    total += group_bcast<G>(incl[c], G - 1, lane);
+  for (int e = 0; e < E; ++e) {
+    const int f = e * G + gl;
+    w[e] = (f < d) ? fabsf(p[e]) * sigma[f] : 0.f;
+    incl[e] = group_scan_incl<G>(w[e], gl);
+    carry[e] = total;
+    total += group_bcast<G>(incl[e], G - 1, lane);
   }
   const float uf = (float)(rnd.x >> 8) * (1.0f / 16777216.0f);
   const float thr = uf * total;
   int fsel = 0x7fffffff, flast = -1;
 #pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    float cum = carry[c] + (incl[c] - ((w[c][0] + w[c][1]) + (w[c][2] + w[c][3])));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int f = c * 4 * G + 4 * gl + e;
-      cum += w[c][e];
-      if (w[c][e] > 0.f) {
-        flast = max(flast, f);
-        if (cum > thr) fsel = min(fsel, f);
-      }
+  for (int e = 0; e < E; ++e) {
+    const int f = e * G + gl;
+    if (w[e] > 0.f) {
+      flast = max(flast, f);
+      if (carry[e] + incl[e] > thr) fsel = min(fsel, f);
     }
   }
   fsel = group_min<G>(fsel);
@@ -236,17 +249,11 @@ __device__ __forceinline__ AdaptiveDraw sample_adaptive(
   // ---- the user's factor value decides the orientation (:96-100)
   float pv = 0.f;
 #pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    const int f0 = c * 4 * G + 4 * gl;
-    if (fsel == f0 + 0) pv = p[c].x;
-    if (fsel == f0 + 1) pv = p[c].y;
-    if (fsel == f0 + 2) pv = p[c].z;
-    if (fsel == f0 + 3) pv = p[c].w;
-  }
+  for (int e = 0; e < E; ++e)
+    if (fsel == e * G + gl) pv = p[e];
   pv = group_sum<G>(pv);
   // ---- r ~ Geometric(p) on {1,2,…}, clamped to #unseen (:90-94)
-  const int64_t lo = indptr[user], hi = indptr[user + 1];
-  const int64_t n_unseen = (I - 1) - (hi - lo);
+  const int64_t n_unseen = (I - 1) - n_seen;
   const float ug = (float)((rnd.y >> 8) + 1u) * (1.0f / 16777216.0f);
   const float rr = ceilf(logf(ug) * inv_log1mp);
   int64_t r = rr < 1.0f ? 1 : (rr > 2.0e9f ? 2000000000ll : (int64_t)rr);
@@ -255,49 +262,57 @@ __device__ __forceinline__ AdaptiveDraw sample_adaptive(
   AdaptiveDraw out;
   out.factor = fsel;
   out.rank = (int32_t)(from_top ? r - 1 : n_unseen - r);
-  out.item = (n_unseen > 0)
-                 ? adaptive_walk<G>(order + (int64_t)fsel * I, I, indices, lo, hi, from_top,
-                                    (int32_t)(r - 1), lane)
-                 : 0;
+  out.item = (n_unseen > 0) ? adaptive_walk<G>(order + (int64_t)fsel * I, I, seen, from_top,
+                                               (int32_t)(r - 1), lane)
+                            : 0;
   return out;
 }
 
 // ---------------------------------------------------------------------------------------------
-// row slices
+// rows: lane gl holds elements e*G + gl
 // ---------------------------------------------------------------------------------------------
-template <int G, int NV>
-__device__ __forceinline__ void load_row(float4 (&r)[NV], const float* __restrict__ row, int d,
+template <int G, int E>
+__device__ __forceinline__ void load_row(float (&r)[E], const float* __restrict__ row, int d,
                                          int gl) {
 #pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    const int f0 = c * 4 * G + 4 * gl;
-    r[c] = (f0 < d) ? *reinterpret_cast<const float4*>(row + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = 0; e < E; ++e) {
+    const int f = e * G + gl;
+    r[e] = (f < d) ? row[f] : 0.f;
   }
 }
 
-__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
-  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+template <int G, int E>
+__device__ __forceinline__ void store_row(float* __restrict__ row, const float (&r)[E], int d,
+                                          int gl) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int f = e * G + gl;
+    if (f < d) row[f] = r[e];
+  }
 }
 
-// fire-and-forget fp32 atomic add at device scope (global_atomic_add_f32, executed at L2 /
-// memory side; no lost updates across XCDs).
+// fire-and-forget fp32 atomic add at device scope (global_atomic_add_f32; resolved below the
+// per-XCD L2s, so updates from different XCDs to one row are never lost)
 __device__ __forceinline__ void atomic_add_f32(float* addr, float v) {
   __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int G, int NV>
-__device__ __forceinline__ void atomic_add_row(float* __restrict__ row, const float4 (&v)[NV],
-                                               int d, int gl) {
+template <int G, int E>
+__device__ __forceinline__ void atomic_add_row(float* __restrict__ row, const float (&v)[E], int d,
+                                               int gl) {
 #pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    const int f0 = c * 4 * G + 4 * gl;
-    if (f0 < d) {
-      atomic_add_f32(row + f0 + 0, v[c].x);
-      atomic_add_f32(row + f0 + 1, v[c].y);
-      atomic_add_f32(row + f0 + 2, v[c].z);
-      atomic_add_f32(row + f0 + 3, v[c].w);
-    }
+  for (int e = 0; e < E; ++e) {
+    const int f = e * G + gl;
+    if (f < d) atomic_add_f32(row + f, v[e]);
   }
+}
+
+template <int E>
+__device__ __forceinline__ float dot(const float (&a)[E], const float (&b)[E]) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) s = fmaf(a[e], b[e], s);
+  return s;
 }
 
 // −logσ(x) = softplus(−x)

@@ -1,12 +1,17 @@
 // bpr_kernels.h — the kernels of libbprcore (gfx950).  See DESIGN.md for the roofline of each.
 //
-//   k_triples<G,NV,MODE,SAMPLER>   the hot path: [sample j] → gather p_u,q_i,q_j → x, σ(−x) →
-//                                  MODE_FORWARD: logits + loss scalars only
-//                                  MODE_GRAD   : + accumulate per-row gradients (STRICT phase A)
-//                                  MODE_STREAM : + apply SGD in place with fp32 atomics
-//   k_apply<G,NV>                  STRICT phase B: one optimizer step per touched row
-//   k_discard<G,NV>, k_flush_lazy<G,NV>, samplers-only kernels.
+//   k_stream<G,E,SAMPLER>    THE hot path (STREAM mode): a group walks a run of consecutive triples of
+//                            a user-grouped chunk with the user row in registers:
+//                            [sample j] → gather q_i, q_j → x, σ(−x) → SGD; item rows updated with
+//                            full-line fp32 atomics, the user row written back once per run.
+//   k_triples<G,E,MODE>      STRICT mode, one triple per group:
+//                            MODE_FORWARD: logits + loss scalars only
+//                            MODE_GRAD   : + accumulate per-row gradients (phase A)
+//   k_apply<G,E>             STRICT phase B: one optimizer step per touched row
+//   k_discard<G,E>, k_flush_lazy<G,E>, k_sample<G,E,WHAT> (samplers behind the Python API).
 #pragma once
+#include <type_traits>
+
 #include "bpr_device.h"
 
 namespace bpr {
@@ -15,256 +20,6 @@ enum { MODE_FORWARD = 0, MODE_GRAD = 1, MODE_STREAM = 2 };
 enum { NEG_GIVEN = 0, NEG_UNIFORM = 1, NEG_ADAPTIVE = 2 };
 enum { OPT_SGD = 0, OPT_MOMENTUM = 1, OPT_ADAM = 2, OPT_RMSPROP = 3 };
 
-struct TripleArgs {
-  float* P;
-  float* Q;
-  float* bias;
-  int64_t I;
-  int d;
-  int pad_user, pad_item;
-  float au, ai, an, lr;
-  // sampling
-  const int64_t* indptr;
-  const int32_t* indices;
-  const int32_t* order;
-  const float* sigma;
-  float inv_log1mp;
-  uint64_t seed, offset;
-  // triple stream
-  const int32_t* users;
-  const int32_t* pos;
-  int32_t* neg;
-  int64_t n;
-  // outputs
-  float* lpos;
-  float* lneg;
-  float* scalars;
-  // STRICT accumulators
-  float* GP;
-  float* GQ;
-  float* Gb;
-  int32_t* flagP;
-  int32_t* flagQ;
-  uint32_t* touched;
-  uint32_t* touched_cnt;
-};
-
-__device__ __forceinline__ void mark_touched(int32_t* flag, uint32_t row, uint32_t table,
-                                             uint32_t* touched, uint32_t* cnt) {
-  if (atomicExch(&flag[row], 1) == 0) {
-    const uint32_t slot = atomicAdd(cnt, 1u);
-    touched[slot] = row * 2u + table;
-  }
-}
-
-template <int G, int NV, int MODE, int SAMPLER>
-__global__ __launch_bounds__(256) void k_triples(const TripleArgs a) {
-  constexpr int GPW = 64 / G;  // groups (triples) per wave
-  const int lane = threadIdx.x & 63;
-  const int gl = lane & (G - 1);
-  const int gw = lane / G;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int d = a.d;
-  const bool stats = a.scalars != nullptr;
-  float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
-
-  for (int64_t base = wave * GPW; base < a.n; base += n_waves * GPW) {
-    const int64_t t = base + gw;
-    const bool act = t < a.n;
-    const int64_t tt = act ? t : a.n - 1;
-    const int32_t u = a.users[tt];
-    const int32_t i = a.pos[tt];
-    float* __restrict__ prow = a.P + (int64_t)u * d;
-    float* __restrict__ irow = a.Q + (int64_t)i * d;
-    float4 p[NV], qi[NV], qj[NV];
-    load_row<G, NV>(p, prow, d, gl);
-    load_row<G, NV>(qi, irow, d, gl);
-
-    int32_t j;
-    if constexpr (SAMPLER == NEG_GIVEN) {
-      j = a.neg[tt];
-    } else if constexpr (SAMPLER == NEG_UNIFORM) {
-      j = sample_uniform<G>(a.indptr, a.indices, a.I, u, a.seed, a.offset + (uint64_t)tt, lane);
-    } else {
-      j = sample_adaptive<G, NV>(p, d, a.sigma, a.order, a.I, a.indptr, a.indices, u,
-                                 a.inv_log1mp, a.seed, a.offset + (uint64_t)tt, lane).item;
-    }
-    if constexpr (SAMPLER != NEG_GIVEN) {
-      if (a.neg != nullptr && act && gl == 0) a.neg[t] = j;
-    }
-    float* __restrict__ jrow = a.Q + (int64_t)j * d;
-    load_row<G, NV>(qj, jrow, d, gl);
-
-    // ---- MF.forward (model.py:131-145) and BPR logits (model.py:48-64)
-    float dpi = 0.f, dpj = 0.f;
-#pragma unroll
-    for (int c = 0; c < NV; ++c) {
-      dpi += dot4(p[c], qi[c]);
-      dpj += dot4(p[c], qj[c]);
-    }
-    dpi = group_sum<G>(dpi);
-    dpj = group_sum<G>(dpj);
-    float xp = dpi, xn = dpj;
-    if (a.bias != nullptr) {
-      xp += a.bias[i];
-      xn += a.bias[j];
-    }
-    const float x = xp - xn;
-    if (act && gl == 0) {
-      if (a.lpos != nullptr) a.lpos[t] = xp;
-      if (a.lneg != nullptr) a.lneg[t] = xn;
-    }
-    if (stats) {
-      // Loss (loss.py:20) and Model.regularization (model.py:87-93)
-      float np2 = 0.f, ni2 = 0.f, nj2 = 0.f;
-#pragma unroll
-      for (int c = 0; c < NV; ++c) {
-        np2 += dot4(p[c], p[c]);
-        ni2 += dot4(qi[c], qi[c]);
-        nj2 += dot4(qj[c], qj[c]);
-      }
-      np2 = group_sum<G>(np2);
-      ni2 = group_sum<G>(ni2);
-      nj2 = group_sum<G>(nj2);
-      if (act && gl == 0) {
-        s_loss += neg_logsigmoid(x);
-        s_reg += 0.5f * (a.ai * ni2 + a.an * nj2 + a.au * np2);
-        s_abs += fabsf(x);
-        s_cnt += 1.f;
-      }
-    }
-    if constexpr (MODE == MODE_FORWARD) continue;
-
-    // ---- pairwise gradient, w = σ(−x)
-    const float w = 1.0f / (1.0f + expf(x));
-    // gradient sign convention: MODE_GRAD accumulates +g, MODE_STREAM adds −lr·g
-    const float sc = (MODE == MODE_STREAM) ? -a.lr : 1.0f;
-    float4 gp[NV], gi[NV], gj[NV];
-#pragma unroll
-    for (int c = 0; c < NV; ++c) {
-      gp[c].x = sc * (-w * (qi[c].x - qj[c].x) + a.au * p[c].x);
-      gp[c].y = sc * (-w * (qi[c].y - qj[c].y) + a.au * p[c].y);
-      gp[c].z = sc * (-w * (qi[c].z - qj[c].z) + a.au * p[c].z);
-      gp[c].w = sc * (-w * (qi[c].w - qj[c].w) + a.au * p[c].w);
-      gi[c].x = sc * (-w * p[c].x + a.ai * qi[c].x);
-      gi[c].y = sc * (-w * p[c].y + a.ai * qi[c].y);
-      gi[c].z = sc * (-w * p[c].z + a.ai * qi[c].z);
-      gi[c].w = sc * (-w * p[c].w + a.ai * qi[c].w);
-      gj[c].x = sc * (w * p[c].x + a.an * qj[c].x);
-      gj[c].y = sc * (w * p[c].y + a.an * qj[c].y);
-      gj[c].z = sc * (w * p[c].z + a.an * qj[c].z);
-      gj[c].w = sc * (w * p[c].w + a.an * qj[c].w);
-    }
-    if (!act) continue;
-    if constexpr (MODE == MODE_STREAM) {
-      if (u != a.pad_user) atomic_add_row<G, NV>(prow, gp, d, gl);
-      if (i != a.pad_item) atomic_add_row<G, NV>(irow, gi, d, gl);
-      if (j != a.pad_item) atomic_add_row<G, NV>(jrow, gj, d, gl);
-      if (a.bias != nullptr && gl == 0) {
-        atomic_add_f32(a.bias + i, a.lr * w);
-        atomic_add_f32(a.bias + j, -a.lr * w);
-      }
-    } else {
-      if (u != a.pad_user) atomic_add_row<G, NV>(a.GP + (int64_t)u * d, gp, d, gl);
-      if (i != a.pad_item) atomic_add_row<G, NV>(a.GQ + (int64_t)i * d, gi, d, gl);
-      if (j != a.pad_item) atomic_add_row<G, NV>(a.GQ + (int64_t)j * d, gj, d, gl);
-      if (gl == 0) {
-        if (a.bias != nullptr) {
-          atomic_add_f32(a.Gb + i, -w);
-          atomic_add_f32(a.Gb + j, w);
-        }
-        if (u != a.pad_user) mark_touched(a.flagP, (uint32_t)u, 0u, a.touched, a.touched_cnt);
-        mark_touched(a.flagQ, (uint32_t)i, 1u, a.touched, a.touched_cnt);
-        mark_touched(a.flagQ, (uint32_t)j, 1u, a.touched, a.touched_cnt);
-      }
-    }
-  }
-
-  if (stats) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      s_loss += __shfl_xor(s_loss, off, 64);
-      s_reg += __shfl_xor(s_reg, off, 64);
-      s_abs += __shfl_xor(s_abs, off, 64);
-      s_cnt += __shfl_xor(s_cnt, off, 64);
-    }
-    if (lane == 0 && s_cnt > 0.f) {
-      atomic_add_f32(a.scalars + 0, s_loss);
-      atomic_add_f32(a.scalars + 1, s_reg);
-      atomic_add_f32(a.scalars + 2, s_abs);
-      atomic_add_f32(a.scalars + 3, s_cnt);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// sampler-only kernels (UniformSampler.sample / AdaptiveSampler.sample behind the Python API)
-// ---------------------------------------------------------------------------------------------
-struct SampleArgs {
-  const float* P;
-  int64_t I;
-  int d;
-  const int64_t* indptr;
-  const int32_t* indices;
-  const int32_t* order;
-  const float* sigma;
-  float inv_log1mp;
-  uint64_t seed, offset;
-  const int32_t* users;
-  const int32_t* factor_in;
-  const int32_t* rank_in;
-  int64_t n;
-  int32_t* neg;
-  int32_t* factor_out;
-  int32_t* rank_out;
-};
-
-enum { SAMPLE_UNIFORM = 0, SAMPLE_ADAPTIVE = 1, SAMPLE_PICK = 2 };
-
-template <int G, int NV, int WHAT>
-__global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
-  constexpr int GPW = 64 / G;
-  const int lane = threadIdx.x & 63;
-  const int gl = lane & (G - 1);
-  const int gw = lane / G;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t base = wave * GPW; base < a.n; base += n_waves * GPW) {
-    const int64_t t = base + gw;
-    const bool act = t < a.n;
-    const int64_t tt = act ? t : a.n - 1;
-    const int32_t u = a.users[tt];
-    if constexpr (WHAT == SAMPLE_UNIFORM) {
-      const int32_t j =
-          sample_uniform<G>(a.indptr, a.indices, a.I, u, a.seed, a.offset + (uint64_t)tt, lane);
-      if (act && gl == 0) a.neg[t] = j;
-    } else if constexpr (WHAT == SAMPLE_ADAPTIVE) {
-      float4 p[NV];
-      load_row<G, NV>(p, a.P + (int64_t)u * a.d, a.d, gl);
-      const AdaptiveDraw r =
-          sample_adaptive<G, NV>(p, a.d, a.sigma, a.order, a.I, a.indptr, a.indices, u,
-                                 a.inv_log1mp, a.seed, a.offset + (uint64_t)tt, lane);
-      if (act && gl == 0) {
-        a.neg[t] = r.item;
-        if (a.factor_out != nullptr) a.factor_out[t] = r.factor;
-        if (a.rank_out != nullptr) a.rank_out[t] = r.rank;
-      }
-    } else {
-      const int32_t f = a.factor_in[tt];
-      const int32_t rk = a.rank_in[tt];
-      const int64_t lo = a.indptr[u], hi = a.indptr[u + 1];
-      const int32_t j =
-          adaptive_walk<G>(a.order + (int64_t)f * a.I, a.I, a.indices, lo, hi, true, rk, lane);
-      if (act && gl == 0) a.neg[t] = j;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// STRICT phase B: torch.optim step on the touched rows, with lazy replay of the zero-gradient
-// steps a dense torch optimizer would have applied to the row since it was last touched (H2).
-// ---------------------------------------------------------------------------------------------
 struct OptDev {
   int kind;
   float lr, mu, damp;
@@ -349,19 +104,476 @@ __device__ __forceinline__ void opt_update(float& w, float g, float& m, float& v
   }
 }
 
-#define BPR_FOR4(EXPR_X, EXPR_Y, EXPR_Z, EXPR_W) \
-  { EXPR_X; EXPR_Y; EXPR_Z; EXPR_W; }
 
-template <int G, int NV>
+// Bring the register copy of a row to "now" (all steps before o.t applied): a dense torch
+// optimizer has been moving the row since it was last touched, and the forward pass must see
+// those moves (the state tensors themselves are only rewritten by k_apply / k_flush_lazy).
+template <int G, int E>
+__device__ __forceinline__ void catch_up_row(float (&r)[E], const float* __restrict__ M,
+                                             const float* __restrict__ V, int64_t row, int d,
+                                             int gl, int64_t s0, int64_t k, const OptDev& o) {
+  if (k <= 0) return;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int f = e * G + gl;
+    if (f >= d) continue;
+    float m = M != nullptr ? M[row * d + f] : 0.f;
+    float v = V != nullptr ? V[row * d + f] : 0.f;
+    opt_replay(r[e], m, v, s0, k, o);
+  }
+}
+
+struct TripleArgs {
+  float* P;
+  float* Q;
+  float* bias;
+  int64_t I;
+  int d;
+  int pad_user, pad_item;
+  float au, ai, an, lr;
+  // sampling
+  const int64_t* indptr;
+  const int32_t* indices;
+  const int32_t* order;
+  const float* sigma;
+  float inv_log1mp;
+  uint64_t seed, offset;
+  // triple stream
+  const int32_t* users;
+  const int32_t* pos;
+  int32_t* neg;
+  int64_t n;
+  int run_len;  // STREAM: consecutive triples walked by one group
+  int grouped;  // STREAM: 1 = triples of a user are contiguous in this chunk (exclusive rows)
+  int bm_words; // STREAM: 32-bit words of one group's seen-bitmap in LDS (0 = use the CSR)
+  int dbg;      // measurement only (BPR_DEBUG env): 1 = drop item-row updates, 2 = plain stores
+  // outputs
+  float* lpos;
+  float* lneg;
+  float* scalars;   // caller's 4 floats (non-NULL = statistics wanted)
+  float* partials;  // [gridDim.x, 4] per-block partial sums (ctx scratch)
+  // STRICT accumulators
+  float* GP;
+  float* GQ;
+  float* Gb;
+  int32_t* flagP;
+  int32_t* flagQ;
+  uint32_t* touched;
+  uint32_t* touched_cnt;
+  // stateful optimizers (STRICT): state + last-touched step, to read rows "as of now"
+  const float *mP, *vP, *mQ, *vQ, *mb, *vb;
+  const int32_t* lastP;
+  const int32_t* lastQ;
+  OptDev o;  // o.t = number of the step this forward belongs to
+};
+
+__device__ __forceinline__ void mark_touched(int32_t* flag, uint32_t row, uint32_t table,
+                                             uint32_t* touched, uint32_t* cnt) {
+  if (atomicExch(&flag[row], 1) == 0) {
+    const uint32_t slot = atomicAdd(cnt, 1u);
+    touched[slot] = row * 2u + table;
+  }
+}
+
+// Loss statistics: wave shuffle → LDS → ONE plain store of the block's partial sums.  (Adding them
+// to the caller's 4 floats with atomics from every wave serialises ~10^4 same-line atomics per
+// launch — measured 0.3 ms — so the final sum is a separate one-block kernel, k_sum_partials.)
+__device__ __forceinline__ void reduce_scalars(float* partials, float s_loss, float s_reg,
+                                               float s_abs, float s_cnt, int lane) {
+  __shared__ float red[4][4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s_loss += __shfl_xor(s_loss, off, 64);
+    s_reg += __shfl_xor(s_reg, off, 64);
+    s_abs += __shfl_xor(s_abs, off, 64);
+    s_cnt += __shfl_xor(s_cnt, off, 64);
+  }
+  const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) {
+    red[wv][0] = s_loss;
+    red[wv][1] = s_reg;
+    red[wv][2] = s_abs;
+    red[wv][3] = s_cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.f;
+    for (int k = 0; k < nw; ++k) v += red[k][threadIdx.x];
+    partials[(int64_t)blockIdx.x * 4 + threadIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ partials,
+                                                      int n_blocks, float* __restrict__ out) {
+  __shared__ double red[256][4];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < n_blocks; b += 256)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += (double)partials[(int64_t)b * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = acc[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out[threadIdx.x] += (float)red[0][threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+// STREAM: the throughput kernel.
+//
+// The chunk [0, n) is cut into runs of `run_len` consecutive triples; group g walks run g, g+NG, …
+// While consecutive triples share the user, the user row lives in registers (read once, written
+// once).  When the chunk is grouped by user (bpr_plan_epoch) a user whose triples all fall inside
+// one run is owned exclusively by that group for the whole launch → plain store, no atomics and no
+// cross-XCD coherence question; a user whose triples straddle a run boundary gets the group's
+// accumulated delta added atomically instead.  Item rows are shared by everybody → one full-line
+// fp32 atomic add per 128 B of row.
+// ---------------------------------------------------------------------------------------------
+extern __shared__ uint32_t bpr_smem[];
+
+template <int G, int E, int SAMPLER, bool BM>
+__global__ __launch_bounds__(256) void k_stream(const TripleArgs a) {
+  constexpr int GPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const int gw = lane / G;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int d = a.d;
+  const int L = a.run_len;
+  const int64_t n_runs = (a.n + L - 1) / L;
+  const bool stats = a.scalars != nullptr;
+  float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
+  // per-group seen-items bitmap of the current user in LDS (I bits): one ds_read answers "seen?"
+  const int W = a.bm_words;
+  uint32_t* bm = bpr_smem + (size_t)(threadIdx.x / G) * W;
+  if constexpr (BM) {
+    for (int k = gl; k < W; k += G) bm[k] = 0u;
+  }
+  int64_t cur_lo = 0, cur_hi = 0;  // CSR slice of the current user
+
+  for (int64_t rbase = wave * GPW; rbase < n_runs; rbase += n_waves * GPW) {
+    const int64_t run = rbase + gw;
+    const bool run_act = run < n_runs;
+    const int64_t t0 = run_act ? run * L : 0;
+    const int64_t t1 = run_act ? min(t0 + L, a.n) : 0;
+    int32_t cur_u = -1;
+    bool cur_starts_inside = false;
+    float p[E], dp[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) p[e] = dp[e] = 0.f;
+
+    for (int step = 0; step < L; ++step) {
+      const int64_t t = t0 + step;
+      const bool act = run_act && t < t1;
+      const int64_t tt = act ? t : (a.n - 1);
+      const int32_t u = a.users[tt];
+      const int32_t i = a.pos[tt];
+      if (act && u != cur_u) {
+        // ---- user change: write the previous user's row back, fetch the new one
+        if (cur_u >= 0 && cur_u != a.pad_user) {
+          float* row = a.P + (int64_t)cur_u * d;
+          if (a.grouped && cur_starts_inside) {  // run of cur_u ended here, inside my range
+#pragma unroll
+            for (int e = 0; e < E; ++e) p[e] += dp[e];
+            store_row<G, E>(row, p, d, gl);
+          } else {
+            atomic_add_row<G, E>(row, dp, d, gl);
+          }
+        }
+        load_row<G, E>(p, a.P + (int64_t)u * d, d, gl);
+#pragma unroll
+        for (int e = 0; e < E; ++e) dp[e] = 0.f;
+        if constexpr (SAMPLER != NEG_GIVEN) {
+          if constexpr (BM) {  // wipe the previous user's bits (whichever way is shorter)
+            if (cur_hi - cur_lo < (int64_t)W) {
+              for (int64_t k = cur_lo + gl; k < cur_hi; k += G) bm[a.indices[k] >> 5] = 0u;
+            } else {
+              for (int k = gl; k < W; k += G) bm[k] = 0u;
+            }
+          }
+          cur_lo = a.indptr[u];
+          cur_hi = a.indptr[u + 1];
+          if constexpr (BM) {
+            for (int64_t k = cur_lo + gl; k < cur_hi; k += G) {
+              const int32_t it = a.indices[k];
+              atomicOr(&bm[it >> 5], 1u << (it & 31));
+            }
+          }
+        }
+        cur_u = u;
+        cur_starts_inside = (step > 0) || (t == 0) || (a.users[t - 1] != u);
+      }
+      // live user row = p + dp (dp = this group's not-yet-written updates)
+      float pl[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) pl[e] = p[e] + dp[e];
+
+      float* __restrict__ irow = a.Q + (int64_t)i * d;
+      float qi[E], qj[E];
+      load_row<G, E>(qi, irow, d, gl);
+      int32_t j;
+      if constexpr (SAMPLER == NEG_GIVEN) {
+        j = a.neg[tt];
+      } else {
+        using Seen = typename std::conditional<BM, SeenBitmap, SeenCsr>::type;
+        Seen seen;
+        if constexpr (BM) {
+          seen = SeenBitmap{bm};
+        } else {
+          seen = SeenCsr{a.indices, cur_lo, cur_hi};
+        }
+        if constexpr (SAMPLER == NEG_UNIFORM) {
+          j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane);
+        } else {
+          j = sample_adaptive<G, E>(pl, d, a.sigma, a.order, a.I, seen, cur_hi - cur_lo,
+                                    a.inv_log1mp, a.seed, a.offset + (uint64_t)tt, lane).item;
+        }
+      }
+      if constexpr (SAMPLER != NEG_GIVEN) {
+        if (a.neg != nullptr && act && gl == 0) a.neg[t] = j;
+      }
+      float* __restrict__ jrow = a.Q + (int64_t)j * d;
+      load_row<G, E>(qj, jrow, d, gl);
+
+      float xp = group_sum<G>(dot<E>(pl, qi));
+      float xn = group_sum<G>(dot<E>(pl, qj));
+      if (a.bias != nullptr) {
+        xp += a.bias[i];
+        xn += a.bias[j];
+      }
+      const float x = xp - xn;
+      if (stats) {
+        const float np2 = group_sum<G>(dot<E>(pl, pl));
+        const float ni2 = group_sum<G>(dot<E>(qi, qi));
+        const float nj2 = group_sum<G>(dot<E>(qj, qj));
+        if (act && gl == 0) {
+          s_loss += neg_logsigmoid(x);
+          s_reg += 0.5f * (a.ai * ni2 + a.an * nj2 + a.au * np2);
+          s_abs += fabsf(x);
+          s_cnt += 1.f;
+        }
+      }
+      // ---- SGD on the three rows (SURVEY §3.3 gradients), w = σ(−x)
+      const float w = 1.0f / (1.0f + expf(x));
+      const float lr = a.lr;
+      float gi[E], gj[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        gi[e] = -lr * (-w * pl[e] + a.ai * qi[e]);
+        gj[e] = -lr * (w * pl[e] + a.an * qj[e]);
+      }
+      if (act) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) dp[e] += -lr * (-w * (qi[e] - qj[e]) + a.au * pl[e]);
+        if (a.dbg == 0) {
+          if (i != a.pad_item) atomic_add_row<G, E>(irow, gi, d, gl);
+          if (j != a.pad_item) atomic_add_row<G, E>(jrow, gj, d, gl);
+        } else if (a.dbg == 2) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            gi[e] += qi[e];
+            gj[e] += qj[e];
+          }
+          store_row<G, E>(irow, gi, d, gl);
+          store_row<G, E>(jrow, gj, d, gl);
+        }
+        if (a.bias != nullptr && gl == 0) {
+          atomic_add_f32(a.bias + i, lr * w);
+          atomic_add_f32(a.bias + j, -lr * w);
+        }
+      }
+    }
+    // ---- end of run: flush the last user
+    if (run_act && cur_u >= 0 && cur_u != a.pad_user) {
+      float* row = a.P + (int64_t)cur_u * d;
+      const bool ends_inside = (t1 == a.n) || (a.users[t1] != cur_u);
+      if (a.grouped && cur_starts_inside && ends_inside) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[e] += dp[e];
+        store_row<G, E>(row, p, d, gl);
+      } else {
+        atomic_add_row<G, E>(row, dp, d, gl);
+      }
+    }
+  }
+  if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// STRICT phase A / forward-only: one triple per group, negatives given.
+// ---------------------------------------------------------------------------------------------
+template <int G, int E, int MODE>
+__global__ __launch_bounds__(256) void k_triples(const TripleArgs a) {
+  constexpr int GPW = 64 / G;  // groups (triples) per wave
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const int gw = lane / G;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int d = a.d;
+  const bool stats = a.scalars != nullptr;
+  float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
+
+  for (int64_t base = wave * GPW; base < a.n; base += n_waves * GPW) {
+    const int64_t t = base + gw;
+    const bool act = t < a.n;
+    const int64_t tt = act ? t : a.n - 1;
+    const int32_t u = a.users[tt];
+    const int32_t i = a.pos[tt];
+    const int32_t j = a.neg[tt];
+    float p[E], qi[E], qj[E];
+    load_row<G, E>(p, a.P + (int64_t)u * d, d, gl);
+    load_row<G, E>(qi, a.Q + (int64_t)i * d, d, gl);
+    load_row<G, E>(qj, a.Q + (int64_t)j * d, d, gl);
+    float bias_i = 0.f, bias_j = 0.f;
+    if (a.bias != nullptr) {
+      bias_i = a.bias[i];
+      bias_j = a.bias[j];
+    }
+    if (a.o.kind != OPT_SGD && a.lastP != nullptr) {
+      const int64_t su = a.lastP[u], si = a.lastQ[i], sj = a.lastQ[j];
+      const int64_t now = a.o.t - 1;
+      catch_up_row<G, E>(p, a.mP, a.vP, u, d, gl, su, now - su, a.o);
+      catch_up_row<G, E>(qi, a.mQ, a.vQ, i, d, gl, si, now - si, a.o);
+      catch_up_row<G, E>(qj, a.mQ, a.vQ, j, d, gl, sj, now - sj, a.o);
+      if (a.bias != nullptr) {
+        float m = a.mb ? a.mb[i] : 0.f, v = a.vb ? a.vb[i] : 0.f;
+        opt_replay(bias_i, m, v, si, now - si, a.o);
+        m = a.mb ? a.mb[j] : 0.f;
+        v = a.vb ? a.vb[j] : 0.f;
+        opt_replay(bias_j, m, v, sj, now - sj, a.o);
+      }
+    }
+    // ---- MF.forward (model.py:131-145) and BPR logits (model.py:48-64)
+    const float xp = group_sum<G>(dot<E>(p, qi)) + bias_i;
+    const float xn = group_sum<G>(dot<E>(p, qj)) + bias_j;
+    const float x = xp - xn;
+    if (act && gl == 0) {
+      if (a.lpos != nullptr) a.lpos[t] = xp;
+      if (a.lneg != nullptr) a.lneg[t] = xn;
+    }
+    if (stats) {
+      // Loss (loss.py:20) and Model.regularization (model.py:87-93)
+      const float np2 = group_sum<G>(dot<E>(p, p));
+      const float ni2 = group_sum<G>(dot<E>(qi, qi));
+      const float nj2 = group_sum<G>(dot<E>(qj, qj));
+      if (act && gl == 0) {
+        s_loss += neg_logsigmoid(x);
+        s_reg += 0.5f * (a.ai * ni2 + a.an * nj2 + a.au * np2);
+        s_abs += fabsf(x);
+        s_cnt += 1.f;
+      }
+    }
+    if constexpr (MODE == MODE_GRAD) {
+      // ---- pairwise gradient, w = σ(−x), accumulated per row
+      const float w = 1.0f / (1.0f + expf(x));
+      float gp[E], gi[E], gj[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        gp[e] = -w * (qi[e] - qj[e]) + a.au * p[e];
+        gi[e] = -w * p[e] + a.ai * qi[e];
+        gj[e] = w * p[e] + a.an * qj[e];
+      }
+      if (act) {
+        if (u != a.pad_user) atomic_add_row<G, E>(a.GP + (int64_t)u * d, gp, d, gl);
+        if (i != a.pad_item) atomic_add_row<G, E>(a.GQ + (int64_t)i * d, gi, d, gl);
+        if (j != a.pad_item) atomic_add_row<G, E>(a.GQ + (int64_t)j * d, gj, d, gl);
+        if (gl == 0) {
+          if (a.bias != nullptr) {
+            atomic_add_f32(a.Gb + i, -w);
+            atomic_add_f32(a.Gb + j, w);
+          }
+          if (u != a.pad_user) mark_touched(a.flagP, (uint32_t)u, 0u, a.touched, a.touched_cnt);
+          mark_touched(a.flagQ, (uint32_t)i, 1u, a.touched, a.touched_cnt);
+          mark_touched(a.flagQ, (uint32_t)j, 1u, a.touched, a.touched_cnt);
+        }
+      }
+    }
+  }
+  if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampler-only kernels (UniformSampler.sample / AdaptiveSampler.sample behind the Python API)
+// ---------------------------------------------------------------------------------------------
+struct SampleArgs {
+  const float* P;
+  int64_t I;
+  int d;
+  const int64_t* indptr;
+  const int32_t* indices;
+  const int32_t* order;
+  const float* sigma;
+  float inv_log1mp;
+  uint64_t seed, offset;
+  const int32_t* users;
+  const int32_t* factor_in;
+  const int32_t* rank_in;
+  int64_t n;
+  int32_t* neg;
+  int32_t* factor_out;
+  int32_t* rank_out;
+};
+
+enum { SAMPLE_UNIFORM = 0, SAMPLE_ADAPTIVE = 1, SAMPLE_PICK = 2 };
+
+template <int G, int E, int WHAT>
+__global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
+  constexpr int GPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const int gw = lane / G;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t base = wave * GPW; base < a.n; base += n_waves * GPW) {
+    const int64_t t = base + gw;
+    const bool act = t < a.n;
+    const int64_t tt = act ? t : a.n - 1;
+    const int32_t u = a.users[tt];
+    const int64_t lo = a.indptr[u], hi = a.indptr[u + 1];
+    const SeenCsr seen{a.indices, lo, hi};
+    if constexpr (WHAT == SAMPLE_UNIFORM) {
+      const int32_t j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane);
+      if (act && gl == 0) a.neg[t] = j;
+    } else if constexpr (WHAT == SAMPLE_ADAPTIVE) {
+      float p[E];
+      load_row<G, E>(p, a.P + (int64_t)u * a.d, a.d, gl);
+      const AdaptiveDraw r =
+          sample_adaptive<G, E>(p, a.d, a.sigma, a.order, a.I, seen, hi - lo, a.inv_log1mp,
+                                a.seed, a.offset + (uint64_t)tt, lane);
+      if (act && gl == 0) {
+        a.neg[t] = r.item;
+        if (a.factor_out != nullptr) a.factor_out[t] = r.factor;
+        if (a.rank_out != nullptr) a.rank_out[t] = r.rank;
+      }
+    } else {
+      const int32_t f = a.factor_in[tt];
+      const int32_t rk = a.rank_in[tt];
+      const int32_t j = adaptive_walk<G>(a.order + (int64_t)f * a.I, a.I, seen, true, rk, lane);
+      if (act && gl == 0) a.neg[t] = j;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// STRICT phase B: torch.optim step on the touched rows, with lazy replay of the zero-gradient
+// steps a dense torch optimizer would have applied to the row since it was last touched (H2).
+// ---------------------------------------------------------------------------------------------
+template <int G, int E>
 __global__ __launch_bounds__(256) void k_apply(const ApplyArgs a) {
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const uint32_t cnt = *a.touched_cnt;
   if (grp >= (int64_t)cnt) return;
-  const uint32_t e = a.touched[grp];
-  const bool is_item = (e & 1u) != 0u;
-  const int64_t row = (int64_t)(e >> 1);
+  const uint32_t en = a.touched[grp];
+  const bool is_item = (en & 1u) != 0u;
+  const int64_t row = (int64_t)(en >> 1);
   const int d = a.d;
   float* W = (is_item ? a.Q : a.P) + row * d;
   float* Gr = (is_item ? a.GQ : a.GP) + row * d;
@@ -381,24 +593,19 @@ __global__ __launch_bounds__(256) void k_apply(const ApplyArgs a) {
   }
   if (row != pad) {
 #pragma unroll
-    for (int c = 0; c < NV; ++c) {
-      const int f0 = c * 4 * G + 4 * gl;
-      if (f0 >= d) continue;
-      float4 w4 = *reinterpret_cast<float4*>(W + f0);
-      const float4 g4 = *reinterpret_cast<float4*>(Gr + f0);
-      float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = m4;
-      if (M != nullptr) m4 = *reinterpret_cast<float4*>(M + row * d + f0);
-      if (V != nullptr) v4 = *reinterpret_cast<float4*>(V + row * d + f0);
-      BPR_FOR4(opt_replay(w4.x, m4.x, v4.x, s0, k, o), opt_replay(w4.y, m4.y, v4.y, s0, k, o),
-               opt_replay(w4.z, m4.z, v4.z, s0, k, o), opt_replay(w4.w, m4.w, v4.w, s0, k, o));
-      BPR_FOR4(opt_update(w4.x, g4.x, m4.x, v4.x, o, adam_step, adam_bc2_sqrt),
-               opt_update(w4.y, g4.y, m4.y, v4.y, o, adam_step, adam_bc2_sqrt),
-               opt_update(w4.z, g4.z, m4.z, v4.z, o, adam_step, adam_bc2_sqrt),
-               opt_update(w4.w, g4.w, m4.w, v4.w, o, adam_step, adam_bc2_sqrt));
-      *reinterpret_cast<float4*>(W + f0) = w4;
-      *reinterpret_cast<float4*>(Gr + f0) = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (M != nullptr) *reinterpret_cast<float4*>(M + row * d + f0) = m4;
-      if (V != nullptr) *reinterpret_cast<float4*>(V + row * d + f0) = v4;
+    for (int e = 0; e < E; ++e) {
+      const int f = e * G + gl;
+      if (f >= d) continue;
+      float w = W[f];
+      const float g = Gr[f];
+      float m = M != nullptr ? M[row * d + f] : 0.f;
+      float v = V != nullptr ? V[row * d + f] : 0.f;
+      opt_replay(w, m, v, s0, k, o);
+      opt_update(w, g, m, v, o, adam_step, adam_bc2_sqrt);
+      W[f] = w;
+      Gr[f] = 0.f;
+      if (M != nullptr) M[row * d + f] = m;
+      if (V != nullptr) V[row * d + f] = v;
     }
   }
   if (gl == 0) {
@@ -418,20 +625,20 @@ __global__ __launch_bounds__(256) void k_apply(const ApplyArgs a) {
 }
 
 // drop accumulated gradients of the touched rows
-template <int G, int NV>
+template <int G, int E>
 __global__ __launch_bounds__(256) void k_discard(const ApplyArgs a) {
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   if (grp >= (int64_t)*a.touched_cnt) return;
-  const uint32_t e = a.touched[grp];
-  const bool is_item = (e & 1u) != 0u;
-  const int64_t row = (int64_t)(e >> 1);
+  const uint32_t en = a.touched[grp];
+  const bool is_item = (en & 1u) != 0u;
+  const int64_t row = (int64_t)(en >> 1);
   float* Gr = (is_item ? a.GQ : a.GP) + row * a.d;
 #pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    const int f0 = c * 4 * G + 4 * gl;
-    if (f0 < a.d) *reinterpret_cast<float4*>(Gr + f0) = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = 0; e < E; ++e) {
+    const int f = e * G + gl;
+    if (f < a.d) Gr[f] = 0.f;
   }
   if (gl == 0) {
     if (is_item && a.Gb != nullptr) a.Gb[row] = 0.f;
@@ -440,7 +647,7 @@ __global__ __launch_bounds__(256) void k_discard(const ApplyArgs a) {
 }
 
 // bring every row of one table to step o.t (dense sweep; before eval / checkpoint / all-reduce)
-template <int G, int NV>
+template <int G, int E>
 __global__ __launch_bounds__(256) void k_flush_lazy(const ApplyArgs a, const int is_item) {
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
@@ -458,18 +665,16 @@ __global__ __launch_bounds__(256) void k_flush_lazy(const ApplyArgs a, const int
     const int64_t k = o.t - s0;
     if (k <= 0) continue;
 #pragma unroll
-    for (int c = 0; c < NV; ++c) {
-      const int f0 = c * 4 * G + 4 * gl;
-      if (f0 >= d) continue;
-      float4 w4 = *reinterpret_cast<float4*>(Wt + row * d + f0);
-      float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = m4;
-      if (M != nullptr) m4 = *reinterpret_cast<float4*>(M + row * d + f0);
-      if (V != nullptr) v4 = *reinterpret_cast<float4*>(V + row * d + f0);
-      BPR_FOR4(opt_replay(w4.x, m4.x, v4.x, s0, k, o), opt_replay(w4.y, m4.y, v4.y, s0, k, o),
-               opt_replay(w4.z, m4.z, v4.z, s0, k, o), opt_replay(w4.w, m4.w, v4.w, s0, k, o));
-      *reinterpret_cast<float4*>(Wt + row * d + f0) = w4;
-      if (M != nullptr) *reinterpret_cast<float4*>(M + row * d + f0) = m4;
-      if (V != nullptr) *reinterpret_cast<float4*>(V + row * d + f0) = v4;
+    for (int e = 0; e < E; ++e) {
+      const int f = e * G + gl;
+      if (f >= d) continue;
+      float w = Wt[row * d + f];
+      float m = M != nullptr ? M[row * d + f] : 0.f;
+      float v = V != nullptr ? V[row * d + f] : 0.f;
+      opt_replay(w, m, v, s0, k, o);
+      Wt[row * d + f] = w;
+      if (M != nullptr) M[row * d + f] = m;
+      if (V != nullptr) V[row * d + f] = v;
     }
     if (gl == 0) {
       if (is_item && a.bias != nullptr) {

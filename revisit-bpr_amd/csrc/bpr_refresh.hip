@@ -4,8 +4,13 @@
 // The reference snapshots Qᵀ [d, I] and, at every sample, argsorts one masked row of it.  The only
 // thing those argsorts ever use of the snapshot is each factor's ORDER of the items, so the
 // snapshot kept here is order[f][:] = argsort_desc(Q[:, f]) (stable, ties by item id) plus
-// sigma_f = unbiased std of Q[1:, f].  Sort = rocPRIM segmented radix sort, d segments of I keys.
+// sigma_f = unbiased std of Q[1:, f].  Sort = ONE device-wide rocPRIM radix sort over composite
+// 64-bit keys (factor << 32 | descending-orderable float bits), restricted to the 32 + log2(d)
+// significant bits — measured 2.1x faster than DeviceSegmentedRadixSort / DeviceSegmentedSort for
+// d = 128 segments of 20 k keys (tools/ubench/sort_bench.hip: 0.23 ms vs 0.49 ms).
 #include <hipcub/hipcub.hpp>
+
+#include <algorithm>
 
 #include "bpr_ctx.h"
 
@@ -62,6 +67,17 @@ __global__ __launch_bounds__(256) void k_sigma(const float* __restrict__ T, int6
   if (threadIdx.x == 0) sigma[blockIdx.x] = (float)sqrt(red[0] / (double)(I - 2));
 }
 
+// composite sort key: (factor << 32) | ~orderable(value)  → ascending sort = per-factor descending
+__global__ void k_compose_keys(const float* __restrict__ T, uint64_t* __restrict__ keys, int64_t n,
+                               int64_t I) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t b = __float_as_uint(T[k]);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    keys[k] = ((uint64_t)(k / I) << 32) | (uint64_t)(~b);
+  }
+}
+
 __global__ void k_iota(int32_t* ids, int32_t* offs, int64_t I, int d) {
   const int64_t n = (int64_t)d * I;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
@@ -71,7 +87,106 @@ __global__ void k_iota(int32_t* ids, int32_t* offs, int64_t I, int d) {
     for (int f = threadIdx.x; f <= d; f += blockDim.x) offs[f] = (int32_t)((int64_t)f * I);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Epoch planner: DataLoader(shuffle=True) of the reference (example.py:307-321, exp.py:109-118)
+// re-stated for the STREAM kernel.  A keyed Feistel network gives a pseudo-random permutation
+// pi of [0, n) that every thread can evaluate on its own; triple t goes to chunk pi(t) / chunk,
+// and one radix sort by (chunk, user) makes every chunk contiguous and grouped by user.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ uint64_t feistel_perm(uint64_t x, uint64_t n, int half_bits,
+                                                 uint64_t seed) {
+  const uint32_t mask = (half_bits >= 32) ? 0xFFFFFFFFu : ((1u << half_bits) - 1u);
+  do {  // cycle-walk: the network permutes [0, 4^half_bits) ⊇ [0, n)
+    uint32_t l = (uint32_t)(x >> half_bits) & mask, r = (uint32_t)x & mask;
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+      const uint32_t k = (uint32_t)(seed >> (16 * (round & 1))) + 0x9E3779B9u * (uint32_t)(round + 1) +
+                         (uint32_t)(seed >> 32);
+      const uint32_t f = mix32(r ^ k) & mask;
+      const uint32_t nl = r;
+      r = l ^ f;
+      l = nl;
+    }
+    x = ((uint64_t)l << half_bits) | r;
+  } while (x >= n);
+  return x;
+}
+
+__global__ void k_plan_keys(const int32_t* __restrict__ users, int64_t n, int64_t chunk,
+                            int half_bits, int ubits, uint64_t seed, uint64_t* __restrict__ keys) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t c = feistel_perm((uint64_t)t, (uint64_t)n, half_bits, seed) / (uint64_t)chunk;
+    keys[t] = (c << ubits) | (uint64_t)(uint32_t)users[t];
+  }
+}
+
+__global__ void k_plan_users(const uint64_t* __restrict__ keys, int64_t n, int ubits,
+                             int32_t* __restrict__ users_out) {
+  const uint64_t mask = (1ull << ubits) - 1ull;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+       t += (int64_t)gridDim.x * blockDim.x)
+    users_out[t] = (int32_t)(keys[t] & mask);
+}
+
+static int bits_for(uint64_t v) {  // bits needed to represent values 0..v
+  int b = 1;
+  while ((v >> b) != 0) ++b;
+  return b;
+}
+
+int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n,
+                    int64_t chunk, uint64_t seed, int32_t* users_out, int32_t* pos_out) {
+  if (n == 0) return BPR_OK;
+  if (n >= ((int64_t)1 << 31)) {
+    set_error("bpr_plan_epoch: n must be < 2^31");
+    return BPR_ERR_UNSUPPORTED;
+  }
+  const int ubits = bits_for((uint64_t)(c->U - 1));
+  const int64_t n_chunks = (n + chunk - 1) / chunk;
+  const int cbits = bits_for((uint64_t)(n_chunks - 1));
+  int half_bits = (bits_for((uint64_t)(n - 1)) + 1) / 2;
+  if (half_bits < 1) half_bits = 1;
+  if (c->plan_cap < n) {
+    hipFree(c->plan_keys); hipFree(c->plan_keys_sorted); hipFree(c->plan_tmp);
+    c->plan_keys = c->plan_keys_sorted = nullptr;
+    c->plan_tmp = nullptr;
+    c->plan_cap = 0;
+    BPR_HIP_CHECK(hipMalloc(&c->plan_keys, sizeof(uint64_t) * n));
+    BPR_HIP_CHECK(hipMalloc(&c->plan_keys_sorted, sizeof(uint64_t) * n));
+    size_t bytes = 0;
+    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->plan_keys,
+                                                     c->plan_keys_sorted, pos_in, pos_out, (int)n,
+                                                     0, 64, c->stream));
+    BPR_HIP_CHECK(hipMalloc(&c->plan_tmp, bytes > 0 ? bytes : 16));
+    c->plan_tmp_bytes = bytes;
+    c->plan_cap = n;
+  }
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_plan_keys, dim3(grid), dim3(256), 0, c->stream, users_in, n, chunk,
+                     half_bits, ubits, seed, c->plan_keys);
+  size_t bytes = c->plan_tmp_bytes;
+  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->plan_tmp, bytes, c->plan_keys,
+                                                   c->plan_keys_sorted, pos_in, pos_out, (int)n, 0,
+                                                   ubits + cbits, c->stream));
+  hipLaunchKernelGGL(k_plan_users, dim3(grid), dim3(256), 0, c->stream, c->plan_keys_sorted, n,
+                     ubits, users_out);
+  BPR_HIP_CHECK(hipGetLastError());
+  return BPR_OK;
+}
+
 void refresh_free(bpr_ctx* c) {
+  hipFree(c->plan_keys);
+  hipFree(c->plan_keys_sorted);
+  hipFree(c->plan_tmp);
+  c->plan_keys = c->plan_keys_sorted = nullptr;
+  c->plan_tmp = nullptr;
+  c->plan_cap = 0;
   hipFree(c->order);
   hipFree(c->sigma);
   hipFree(c->keysT);
@@ -104,25 +219,28 @@ int refresh_impl(bpr_ctx* c) {
     BPR_HIP_CHECK(hipMalloc(&c->order, sizeof(int32_t) * n));
     BPR_HIP_CHECK(hipMalloc(&c->sigma, sizeof(float) * d));
     BPR_HIP_CHECK(hipMalloc(&c->keysT, sizeof(float) * n));
-    BPR_HIP_CHECK(hipMalloc(&c->keys_sorted, sizeof(float) * n));
+    BPR_HIP_CHECK(hipMalloc(&c->keys_sorted, sizeof(uint64_t) * 2 * n));  // composite keys in|out
     BPR_HIP_CHECK(hipMalloc(&c->ids_in, sizeof(int32_t) * n));
     BPR_HIP_CHECK(hipMalloc(&c->seg_offsets, sizeof(int32_t) * (d + 1)));
     hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, c->stream, c->ids_in, c->seg_offsets, I,
                        d);
     size_t bytes = 0;
-    BPR_HIP_CHECK(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(
-        nullptr, bytes, c->keysT, c->keys_sorted, c->ids_in, c->order, (int)n, d, c->seg_offsets,
-        c->seg_offsets + 1, 0, 32, c->stream));
+    uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
+    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k64, k64 + n, c->ids_in,
+                                                     c->order, (int)n, 0, 64, c->stream));
     BPR_HIP_CHECK(hipMalloc(&c->sort_tmp, bytes > 0 ? bytes : 16));
     c->sort_tmp_bytes = bytes;
   }
   dim3 tgrid((unsigned)((I + 31) / 32), (unsigned)((d + 31) / 32));
   hipLaunchKernelGGL(k_transpose, tgrid, dim3(256), 0, c->stream, c->Q, c->keysT, I, d);
   hipLaunchKernelGGL(k_sigma, dim3(d), dim3(256), 0, c->stream, c->keysT, I, c->sigma);
+  uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
+  hipLaunchKernelGGL(k_compose_keys, dim3(2048), dim3(256), 0, c->stream, c->keysT, k64, n, I);
+  int key_bits = 32;
+  while ((1 << (key_bits - 32)) < d) ++key_bits;
   size_t bytes = c->sort_tmp_bytes;
-  BPR_HIP_CHECK(hipcub::DeviceSegmentedRadixSort::SortPairsDescending(
-      c->sort_tmp, bytes, c->keysT, c->keys_sorted, c->ids_in, c->order, (int)n, d,
-      c->seg_offsets, c->seg_offsets + 1, 0, 32, c->stream));
+  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp, bytes, k64, k64 + n, c->ids_in,
+                                                   c->order, (int)n, 0, key_bits, c->stream));
   BPR_HIP_CHECK(hipGetLastError());
   c->have_snapshot = true;
   return BPR_OK;

@@ -19,25 +19,22 @@ static int fail(int code, const std::string& msg) {
   return code;
 }
 
-// ---- (G, NV) dispatch ----------------------------------------------------------------------
+// ---- (G, E) dispatch: G lanes per triple, E elements per lane (bpr_device.h) --------------------
 template <int A, int B>
-struct GNV {
+struct GE {
   static constexpr int G = A;
-  static constexpr int NV = B;
+  static constexpr int E = B;
 };
 
 template <typename F>
-static int dispatch_gnv(int G, int NV, F&& f) {
-  switch (G * 8 + NV) {
-    case 2 * 8 + 1: return f(GNV<2, 1>{});
-    case 4 * 8 + 1: return f(GNV<4, 1>{});
-    case 8 * 8 + 1: return f(GNV<8, 1>{});
-    case 16 * 8 + 1: return f(GNV<16, 1>{});
-    case 32 * 8 + 1: return f(GNV<32, 1>{});
-    case 64 * 8 + 1: return f(GNV<64, 1>{});
-    case 64 * 8 + 2: return f(GNV<64, 2>{});
-    case 64 * 8 + 3: return f(GNV<64, 3>{});
-    case 64 * 8 + 4: return f(GNV<64, 4>{});
+static int dispatch_ge(int G, int E, F&& f) {
+  switch (G * 32 + E) {
+    case 32 * 32 + 1: return f(GE<32, 1>{});
+    case 32 * 32 + 2: return f(GE<32, 2>{});
+    case 32 * 32 + 4: return f(GE<32, 4>{});
+    case 64 * 32 + 4: return f(GE<64, 4>{});
+    case 64 * 32 + 8: return f(GE<64, 8>{});
+    case 64 * 32 + 16: return f(GE<64, 16>{});
     default: return fail(BPR_ERR_UNSUPPORTED, "unsupported embedding dim");
   }
 }
@@ -102,6 +99,8 @@ static void free_strict_scratch(bpr_ctx* c) {
   c->pending = 0;
 }
 
+static OptDev opt_dev(const bpr_ctx* c, int64_t t);
+
 static TripleArgs triple_args(const bpr_ctx* c) {
   TripleArgs a;
   memset(&a, 0, sizeof(a));
@@ -114,6 +113,10 @@ static TripleArgs triple_args(const bpr_ctx* c) {
   a.GP = c->GP; a.GQ = c->GQ; a.Gb = c->Gb;
   a.flagP = c->flagP; a.flagQ = c->flagQ;
   a.touched = c->touched; a.touched_cnt = c->touched_cnt;
+  a.partials = c->dev_scalars;
+  a.mP = c->mP; a.vP = c->vP; a.mQ = c->mQ; a.vQ = c->vQ; a.mb = c->mb; a.vb = c->vb;
+  a.lastP = c->lastP; a.lastQ = c->lastQ;
+  a.o = opt_dev(c, c->step + 1);
   return a;
 }
 
@@ -200,33 +203,64 @@ static int drain_timing(bpr_ctx* c) {
 
 // ---- launches ---------------------------------------------------------------------------------
 template <int MODE>
-static int launch_triples(bpr_ctx* c, TripleArgs a, int sampler, int64_t cap_groups,
-                          bool timed) {
+static int launch_triples(bpr_ctx* c, TripleArgs a, bool timed) {
   if (a.n <= 0) return BPR_OK;
-  return dispatch_gnv(c->G, c->NV, [&](auto tag) -> int {
+  return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
-    constexpr int G = T::G, NV = T::NV;
-    const unsigned grid = grid_for(a.n, G, cap_groups);
-    // a cap below one 256-thread block shrinks the block (whole waves), so max_inflight = 1 at
-    // G = 64 really is one wave walking the stream sequentially
-    unsigned block = 256;
-    if (cap_groups > 0 && cap_groups * G < 256) block = (unsigned)(((cap_groups * G + 63) / 64) * 64);
+    constexpr int G = T::G, E = T::E;
+    const unsigned grid = grid_for(a.n, G, 0);
     Timer tm(c, timed);
     (void)tm;
-    if constexpr (MODE == MODE_STREAM) {
+    hipLaunchKernelGGL((k_triples<G, E, MODE>), dim3(grid), dim3(256), 0, c->stream, a);
+    if (a.scalars != nullptr)
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, a.partials, (int)grid,
+                         a.scalars);
+    BPR_HIP_CHECK(hipGetLastError());
+    return BPR_OK;
+  });
+}
+
+// STREAM: one group per run of a.run_len triples; max_inflight caps the number of groups (= triples
+// in flight).  A cap below one 256-thread block shrinks the block (whole waves), so
+// max_inflight = 1 at G = 64 really is ONE wave walking the stream sequentially.
+static int launch_stream(bpr_ctx* c, TripleArgs a, int sampler, int64_t cap_groups) {
+  if (a.n <= 0) return BPR_OK;
+  return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
+    using T = decltype(tag);
+    constexpr int G = T::G, E = T::E;
+    const int64_t n_runs = (a.n + a.run_len - 1) / a.run_len;
+    const unsigned grid = grid_for(n_runs, G, cap_groups);
+    unsigned block = 256;
+    if (cap_groups > 0 && cap_groups * G < 256) block = (unsigned)(((cap_groups * G + 63) / 64) * 64);
+    // LDS seen-bitmap: I bits per group, if the block's groups fit in 64 KiB (keeps >= 2 blocks/CU)
+    const int words = (int)((c->I + 31) / 32);
+    const size_t lds = (size_t)(block / G) * (size_t)words * sizeof(uint32_t);
+    static const bool no_bm = getenv("BPR_NO_BITMAP") != nullptr;
+    const bool bm = sampler != NEG_GIVEN && lds <= 64 * 1024 && !no_bm;
+    a.bm_words = bm ? words : 0;
+    const size_t shmem = bm ? lds : 0;
+    {
+      Timer tm(c, true);
+      (void)tm;
       if (sampler == NEG_GIVEN)
-        hipLaunchKernelGGL((k_triples<G, NV, MODE_STREAM, NEG_GIVEN>), dim3(grid), dim3(block), 0,
+        hipLaunchKernelGGL((k_stream<G, E, NEG_GIVEN, false>), dim3(grid), dim3(block), 0,
+                           c->stream, a);
+      else if (sampler == NEG_UNIFORM && bm)
+        hipLaunchKernelGGL((k_stream<G, E, NEG_UNIFORM, true>), dim3(grid), dim3(block), shmem,
                            c->stream, a);
       else if (sampler == NEG_UNIFORM)
-        hipLaunchKernelGGL((k_triples<G, NV, MODE_STREAM, NEG_UNIFORM>), dim3(grid), dim3(block), 0,
+        hipLaunchKernelGGL((k_stream<G, E, NEG_UNIFORM, false>), dim3(grid), dim3(block), 0,
+                           c->stream, a);
+      else if (bm)
+        hipLaunchKernelGGL((k_stream<G, E, NEG_ADAPTIVE, true>), dim3(grid), dim3(block), shmem,
                            c->stream, a);
       else
-        hipLaunchKernelGGL((k_triples<G, NV, MODE_STREAM, NEG_ADAPTIVE>), dim3(grid), dim3(block),
-                           0, c->stream, a);
-    } else {
-      hipLaunchKernelGGL((k_triples<G, NV, MODE, NEG_GIVEN>), dim3(grid), dim3(block), 0,
-                         c->stream, a);
+        hipLaunchKernelGGL((k_stream<G, E, NEG_ADAPTIVE, false>), dim3(grid), dim3(block), 0,
+                           c->stream, a);
     }
+    if (a.scalars != nullptr)
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, a.partials, (int)grid,
+                         a.scalars);
     BPR_HIP_CHECK(hipGetLastError());
     return BPR_OK;
   });
@@ -253,7 +287,7 @@ int bpr_ctx_create(bpr_ctx** out, int device_id, void* hip_stream) {
   if (c == nullptr) return fail(BPR_ERR_NOMEM, "bpr_ctx_create: out of host memory");
   c->device = device_id;
   c->stream = (hipStream_t)hip_stream;
-  if (hipMalloc(&c->dev_scalars, sizeof(float) * BPR_SCALARS) != hipSuccess) {
+  if (hipMalloc(&c->dev_scalars, sizeof(float) * 4 * (size_t)(max_blocks() + 1)) != hipSuccess) {
     delete c;
     return fail(BPR_ERR_HIP, "bpr_ctx_create: hipMalloc failed");
   }
@@ -286,11 +320,10 @@ int bpr_bind_tables(bpr_ctx* c, float* P, int64_t U, float* Q, int64_t I, int32_
     return fail(BPR_ERR_INVALID, "bpr_bind_tables: NULL argument");
   if (U < 1 || I < 2 || U >= ((int64_t)1 << 30) || I >= ((int64_t)1 << 30))
     return fail(BPR_ERR_INVALID, "bpr_bind_tables: table sizes out of range");
-  if (d < 8 || d > 1024 || (d % 4) != 0)
-    return fail(BPR_ERR_UNSUPPORTED,
-                "bpr_bind_tables: embedding dim must be a multiple of 4 in [8, 1024]");
-  if (((uintptr_t)P | (uintptr_t)Q) & 15u)
-    return fail(BPR_ERR_INVALID, "bpr_bind_tables: tables must be 16-byte aligned");
+  if (d < 1 || d > 1024)
+    return fail(BPR_ERR_UNSUPPORTED, "bpr_bind_tables: embedding dim must be in [1, 1024]");
+  if (((uintptr_t)P | (uintptr_t)Q) & 3u)
+    return fail(BPR_ERR_INVALID, "bpr_bind_tables: tables must be 4-byte aligned");
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->U != U || c->I != I || c->d != d) {
     BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -300,11 +333,10 @@ int bpr_bind_tables(bpr_ctx* c, float* P, int64_t U, float* Q, int64_t I, int32_
   c->P = P; c->Q = Q; c->bias = item_bias;
   c->U = U; c->I = I; c->d = d;
   c->pad_user = pad_user; c->pad_item = pad_item;
-  const int slices = d / 4;
-  int G = 2;
-  while (G < slices && G < 64) G <<= 1;
-  c->G = G;
-  c->NV = (slices + G - 1) / G;
+  c->G = d <= 128 ? 32 : 64;
+  const int per_lane = (d + c->G - 1) / c->G;
+  c->E = c->G == 32 ? (per_lane <= 1 ? 1 : per_lane <= 2 ? 2 : 4)
+                    : (per_lane <= 4 ? 4 : per_lane <= 8 ? 8 : 16);
   return BPR_OK;
 }
 
@@ -344,17 +376,17 @@ int bpr_bind_opt_state(bpr_ctx* c, float* m_P, float* v_P, float* m_Q, float* v_
 // ---- sampling -----------------------------------------------------------------------------------
 static int launch_sample(bpr_ctx* c, int what, SampleArgs a) {
   if (a.n <= 0) return BPR_OK;
-  return dispatch_gnv(c->G, c->NV, [&](auto tag) -> int {
+  return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
-    constexpr int G = T::G, NV = T::NV;
+    constexpr int G = T::G, E = T::E;
     const unsigned grid = grid_for(a.n, G, 0);
     if (what == SAMPLE_UNIFORM)
-      hipLaunchKernelGGL((k_sample<G, NV, SAMPLE_UNIFORM>), dim3(grid), dim3(256), 0, c->stream, a);
+      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_UNIFORM>), dim3(grid), dim3(256), 0, c->stream, a);
     else if (what == SAMPLE_ADAPTIVE)
-      hipLaunchKernelGGL((k_sample<G, NV, SAMPLE_ADAPTIVE>), dim3(grid), dim3(256), 0, c->stream,
+      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_ADAPTIVE>), dim3(grid), dim3(256), 0, c->stream,
                          a);
     else
-      hipLaunchKernelGGL((k_sample<G, NV, SAMPLE_PICK>), dim3(grid), dim3(256), 0, c->stream, a);
+      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_PICK>), dim3(grid), dim3(256), 0, c->stream, a);
     BPR_HIP_CHECK(hipGetLastError());
     return BPR_OK;
   });
@@ -433,7 +465,7 @@ int bpr_adaptive_get_snapshot(bpr_ctx* c, int32_t* order_out, float* sigma_out) 
 static int check_triples(const bpr_ctx* c, const char* who, const int32_t* users,
                          const int32_t* pos, int64_t B) {
   if (int rc = check_bound(c, who)) return rc;
-  if (users == nullptr || pos == nullptr || B < 0)
+  if (B < 0 || (B > 0 && (users == nullptr || pos == nullptr)))
     return fail(BPR_ERR_INVALID, std::string(who) + ": bad argument");
   return BPR_OK;
 }
@@ -441,17 +473,17 @@ static int check_triples(const bpr_ctx* c, const char* who, const int32_t* users
 int bpr_forward(bpr_ctx* c, const int32_t* users, const int32_t* pos, const int32_t* neg,
                 int64_t B, float* out_logits_pos, float* out_logits_neg, float* out_scalars) {
   if (int rc = check_triples(c, "bpr_forward", users, pos, B)) return rc;
-  if (neg == nullptr) return fail(BPR_ERR_INVALID, "bpr_forward: neg is NULL");
+  if (neg == nullptr && B > 0) return fail(BPR_ERR_INVALID, "bpr_forward: neg is NULL");
   TripleArgs a = triple_args(c);
   a.users = users; a.pos = pos; a.neg = const_cast<int32_t*>(neg); a.n = B;
   a.lpos = out_logits_pos; a.lneg = out_logits_neg; a.scalars = out_scalars;
-  return launch_triples<MODE_FORWARD>(c, a, NEG_GIVEN, 0, false);
+  return launch_triples<MODE_FORWARD>(c, a, false);
 }
 
 int bpr_forward_grad(bpr_ctx* c, const int32_t* users, const int32_t* pos, const int32_t* neg,
                      int64_t B, float* out_logits_pos, float* out_logits_neg, float* out_scalars) {
   if (int rc = check_triples(c, "bpr_forward_grad", users, pos, B)) return rc;
-  if (neg == nullptr) return fail(BPR_ERR_INVALID, "bpr_forward_grad: neg is NULL");
+  if (neg == nullptr && B > 0) return fail(BPR_ERR_INVALID, "bpr_forward_grad: neg is NULL");
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (int rc = ensure_strict_scratch(c)) return rc;
   TripleArgs a = triple_args(c);
@@ -459,7 +491,7 @@ int bpr_forward_grad(bpr_ctx* c, const int32_t* users, const int32_t* pos, const
   a.lpos = out_logits_pos; a.lneg = out_logits_neg; a.scalars = out_scalars;
   c->pending += 3 * B;
   if (c->pending > c->U + c->I) c->pending = c->U + c->I;
-  return launch_triples<MODE_GRAD>(c, a, NEG_GIVEN, 0, true);
+  return launch_triples<MODE_GRAD>(c, a, true);
 }
 
 int bpr_apply(bpr_ctx* c) {
@@ -470,10 +502,10 @@ int bpr_apply(bpr_ctx* c) {
   c->step += 1;
   if (c->pending > 0) {
     ApplyArgs a = apply_args(c, c->step);
-    int rc = dispatch_gnv(c->G, c->NV, [&](auto tag) -> int {
+    int rc = dispatch_ge(c->G, c->E, [&](auto tag) -> int {
       using T = decltype(tag);
       const unsigned grid = (unsigned)((c->pending * T::G + 255) / 256);
-      hipLaunchKernelGGL((k_apply<T::G, T::NV>), dim3(grid), dim3(256), 0, c->stream, a);
+      hipLaunchKernelGGL((k_apply<T::G, T::E>), dim3(grid), dim3(256), 0, c->stream, a);
       BPR_HIP_CHECK(hipGetLastError());
       return BPR_OK;
     });
@@ -488,10 +520,10 @@ int bpr_discard_grad(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_discard_grad")) return rc;
   if (c->GP == nullptr || c->pending == 0) return BPR_OK;
   ApplyArgs a = apply_args(c, c->step);
-  int rc = dispatch_gnv(c->G, c->NV, [&](auto tag) -> int {
+  int rc = dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
     const unsigned grid = (unsigned)((c->pending * T::G + 255) / 256);
-    hipLaunchKernelGGL((k_discard<T::G, T::NV>), dim3(grid), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL((k_discard<T::G, T::E>), dim3(grid), dim3(256), 0, c->stream, a);
     BPR_HIP_CHECK(hipGetLastError());
     return BPR_OK;
   });
@@ -518,9 +550,9 @@ int bpr_get_grad(bpr_ctx* c, float* gP, float* gQ, float* gbias) {
 }
 
 static int check_sampler(const bpr_ctx* c, const char* who, int32_t sampler, float adaptive_p,
-                         const int32_t* neg) {
+                         const int32_t* neg, int64_t B) {
   if (sampler == BPR_NEG_GIVEN) {
-    if (neg == nullptr) return fail(BPR_ERR_INVALID, std::string(who) + ": neg is NULL");
+    if (neg == nullptr && B > 0) return fail(BPR_ERR_INVALID, std::string(who) + ": neg is NULL");
     return BPR_OK;
   }
   if (sampler != BPR_NEG_UNIFORM && sampler != BPR_NEG_ADAPTIVE)
@@ -539,7 +571,7 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
                      int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
                      int64_t max_inflight, float* out_scalars) {
   if (int rc = check_triples(c, "bpr_train_stream", users, pos, n)) return rc;
-  if (int rc = check_sampler(c, "bpr_train_stream", sampler, adaptive_p, neg)) return rc;
+  if (int rc = check_sampler(c, "bpr_train_stream", sampler, adaptive_p, neg, n)) return rc;
   if (c->opt_kind != BPR_OPT_SGD)
     return fail(BPR_ERR_UNSUPPORTED,
                 "bpr_train_stream: STREAM mode implements plain SGD only; use STRICT "
@@ -552,14 +584,20 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
   a.seed = seed; a.offset = offset;
   a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
   a.scalars = out_scalars;
-  return launch_triples<MODE_STREAM>(c, a, sampler, max_inflight, true);
+  a.run_len = c->run_len;
+  a.grouped = c->grouped;
+  {
+    static const int dbg = getenv("BPR_DEBUG") ? atoi(getenv("BPR_DEBUG")) : 0;
+    a.dbg = dbg;
+  }
+  return launch_stream(c, a, sampler, max_inflight);
 }
 
 int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t B,
              int32_t mode, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
              float* out_logits_pos, float* out_logits_neg, float* out_scalars) {
   if (int rc = check_triples(c, "bpr_step", users, pos, B)) return rc;
-  if (int rc = check_sampler(c, "bpr_step", sampler, adaptive_p, neg)) return rc;
+  if (int rc = check_sampler(c, "bpr_step", sampler, adaptive_p, neg, B)) return rc;
   if (mode == BPR_MODE_STREAM) {
     if (out_logits_pos || out_logits_neg)
       return fail(BPR_ERR_UNSUPPORTED, "bpr_step: STREAM mode does not return logits");
@@ -568,7 +606,7 @@ int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg,
   }
   if (mode != BPR_MODE_STRICT) return fail(BPR_ERR_INVALID, "bpr_step: unknown mode");
   if (sampler != BPR_NEG_GIVEN) {
-    if (neg == nullptr)
+    if (neg == nullptr && B > 0)
       return fail(BPR_ERR_INVALID, "bpr_step: STRICT mode needs a neg buffer to sample into");
     int rc = sampler == BPR_NEG_UNIFORM
                  ? bpr_sample_uniform(c, users, B, seed, offset, neg)
@@ -582,6 +620,24 @@ int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg,
   return bpr_apply(c);
 }
 
+int bpr_set_stream_opts(bpr_ctx* c, int32_t grouped_by_user, int32_t run_len) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: ctx is NULL");
+  if (run_len < 1 || run_len > 4096)
+    return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: run_len must be in [1, 4096]");
+  c->grouped = grouped_by_user != 0;
+  c->run_len = run_len;
+  return BPR_OK;
+}
+
+int bpr_plan_epoch(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n,
+                   int64_t chunk, uint64_t seed, int32_t* users_out, int32_t* pos_out) {
+  if (int rc = check_bound(c, "bpr_plan_epoch")) return rc;
+  if (n < 0 || chunk < 1 || (n > 0 && (!users_in || !pos_in || !users_out || !pos_out)))
+    return fail(BPR_ERR_INVALID, "bpr_plan_epoch: bad argument");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  return plan_epoch_impl(c, users_in, pos_in, n, chunk, seed, users_out, pos_out);
+}
+
 int bpr_flush_lazy(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_flush_lazy")) return rc;
   if (c->opt_kind == BPR_OPT_SGD || c->GP == nullptr || c->step == 0) return BPR_OK;
@@ -589,11 +645,11 @@ int bpr_flush_lazy(bpr_ctx* c) {
   if (c->pending != 0)
     return fail(BPR_ERR_INVALID, "bpr_flush_lazy: unapplied gradients pending");
   ApplyArgs a = apply_args(c, c->step);
-  return dispatch_gnv(c->G, c->NV, [&](auto tag) -> int {
+  return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
-    hipLaunchKernelGGL((k_flush_lazy<T::G, T::NV>), dim3(grid_for(c->U, T::G, 0)), dim3(256), 0,
+    hipLaunchKernelGGL((k_flush_lazy<T::G, T::E>), dim3(grid_for(c->U, T::G, 0)), dim3(256), 0,
                        c->stream, a, 0);
-    hipLaunchKernelGGL((k_flush_lazy<T::G, T::NV>), dim3(grid_for(c->I, T::G, 0)), dim3(256), 0,
+    hipLaunchKernelGGL((k_flush_lazy<T::G, T::E>), dim3(grid_for(c->I, T::G, 0)), dim3(256), 0,
                        c->stream, a, 1);
     BPR_HIP_CHECK(hipGetLastError());
     return BPR_OK;

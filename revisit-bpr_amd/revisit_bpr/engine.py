@@ -248,6 +248,21 @@ class Engine:
                                                 _ptr(neg), users.numel(), sampler, adaptive_p, seed,
                                                 offset, max_inflight, _ptr(scalars)))
 
+    def set_stream_opts(self, grouped_by_user: bool, run_len: int = 8) -> None:
+        native.check(self._lib.bpr_set_stream_opts(self._ctx, int(grouped_by_user), run_len))
+
+    def plan_epoch(self, users: torch.Tensor, pos: torch.Tensor, chunk: int, seed: int,
+                   out: Optional[tuple[torch.Tensor, torch.Tensor]] = None):
+        """Shuffle the training triples into chunks of `chunk`, each grouped by user (on device)."""
+        self._sync_stream()
+        if users.dtype != torch.int32 or pos.dtype != torch.int32:
+            raise ValueError("plan_epoch takes int32 id tensors")
+        uo, po = out if out is not None else (torch.empty_like(users), torch.empty_like(pos))
+        native.check(self._lib.bpr_plan_epoch(self._ctx, users.data_ptr(), pos.data_ptr(),
+                                              users.numel(), chunk, seed, uo.data_ptr(),
+                                              po.data_ptr()))
+        return uo, po
+
     def flush_lazy(self) -> None:
         self._sync_stream()
         native.check(self._lib.bpr_flush_lazy(self._ctx))

@@ -70,6 +70,9 @@ SIGNATURES = {
                          c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "bpr_train_stream": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
                                  c_uint64, c_uint64, c_int64, c_void_p]),
+    "bpr_set_stream_opts": (c_int, [c_void_p, c_int32, c_int32]),
+    "bpr_plan_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_void_p,
+                               c_void_p]),
     "bpr_flush_lazy": (c_int, [c_void_p]),
     "bpr_get_step_host": (c_int, [c_void_p, POINTER(c_int64)]),
     "bpr_set_step": (c_int, [c_void_p, c_int64]),
@@ -90,6 +93,10 @@ def load() -> ctypes.CDLL:
                 "Run __graft_entry__.build() (or `make -C revisit-bpr_amd/csrc`). "
                 "There is no CPU fallback."
             )
+        # torch ships its own HIP runtime; load it FIRST so libbprcore's libamdhip64 dependency
+        # resolves to the same runtime instance (two runtimes in one process cannot share a GPU)
+        import torch  # noqa: F401
+
         lib = ctypes.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export it

@@ -161,7 +161,7 @@ def test_lazy_replay_without_intermediate_flush(golden_dir, opt_name):
 # ------------------------------------------------------------------------------------------------
 # against the oracle at the dims the kernels are specialised for
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d", [8, 12, 32, 64, 128, 200, 256, 512, 1024])
+@pytest.mark.parametrize("d", [1, 8, 12, 32, 50, 64, 128, 200, 256, 300, 512, 1000, 1024])
 def test_strict_step_vs_oracle_dims(d):
     U, I, B = 300, 200, 256
     P, Q, _, _, users, pos, neg = rand_problem(U, I, d, 10, seed=d, B=B)
@@ -205,7 +205,7 @@ def test_empty_batch_and_errors():
     with pytest.raises(native.BprError):  # STREAM is SGD only
         e.train_stream(dev(users), dev(pos), sampler=0, neg=dev(neg))
     with pytest.raises(native.BprError):  # unsupported dim
-        Engine(torch.zeros(4, 6, device="cuda"), torch.zeros(4, 6, device="cuda"))
+        Engine(torch.zeros(4, 2000, device="cuda"), torch.zeros(4, 2000, device="cuda"))
     with pytest.raises(RuntimeError):  # no CPU path
         Engine(torch.zeros(4, 8), torch.zeros(4, 8))
 
@@ -378,3 +378,95 @@ def test_stream_full_chip_learns_and_never_picks_seen():
     assert losses[-1] < losses[0] - 0.05, losses
     assert torch.isfinite(e.P).all() and torch.isfinite(e.Q).all()
     assert not e.P[0].any() and not e.Q[0].any()
+
+
+# ------------------------------------------------------------------------------------------------
+# epoch planner + user-grouped STREAM
+# ------------------------------------------------------------------------------------------------
+def test_plan_epoch_is_a_grouped_random_partition():
+    from revisit_bpr.datasets import synthetic
+
+    data = synthetic.generate(3000, 800, 70000, median_per_user=15, seed=5)
+    P = np.zeros((data.num_users, 8), np.float32)
+    Q = np.zeros((data.num_items, 8), np.float32)
+    e = make_engine(P, Q)
+    users, pos = dev(data.users), dev(data.items)
+    n, chunk = data.nnz, 9000
+    u1, p1 = (t.cpu().numpy() for t in e.plan_epoch(users, pos, chunk, seed=1))
+    u2, p2 = (t.cpu().numpy() for t in e.plan_epoch(users, pos, chunk, seed=2))
+    key = data.users.astype(np.int64) * data.num_items + data.items
+    for uu, pp in ((u1, p1), (u2, p2)):
+        assert np.array_equal(np.sort(uu.astype(np.int64) * data.num_items + pp), np.sort(key))
+        for c0 in range(0, n, chunk):  # grouped (sorted) by user inside every chunk
+            assert np.all(np.diff(uu[c0:c0 + chunk]) >= 0)
+    assert not np.array_equal(u1, u2)
+    # chunk membership is (pseudo-)random: a user's triples spread over the chunks, and the first
+    # chunk of two seeds shares about 1/n_chunks of its triples
+    k1 = set((u1[:chunk].astype(np.int64) * data.num_items + p1[:chunk]).tolist())
+    k2 = set((u2[:chunk].astype(np.int64) * data.num_items + p2[:chunk]).tolist())
+    frac = len(k1 & k2) / chunk
+    assert 0.5 * chunk / n < frac < 2.0 * chunk / n, frac
+    # source position of chunk 0 is not clustered at the front of the (user-sorted) input
+    first_user_share = (u1[:chunk] < data.num_users // 2).mean()
+    assert 0.4 < first_user_share < 0.6, first_user_share
+
+
+@pytest.mark.parametrize("d,run_len", [(200, 4), (256, 8), (256, 3), (512, 1), (1024, 5)])
+def test_stream_grouped_sequential_equals_b1_sgd(d, run_len):
+    """(G = 64 dims only: one group per wave, so max_inflight=1 is truly sequential.)
+    Planned (user-grouped) chunk walked by ONE group == sequential SGD in planned order,
+    including users whose run straddles run boundaries (atomic delta path) and users fully inside
+    a run (register-resident row, plain store)."""
+    from revisit_bpr.datasets import synthetic
+
+    data = synthetic.generate(150, 90, 1500, median_per_user=8, seed=d + run_len)
+    rng = np.random.default_rng(d)
+    P = ((rng.random((data.num_users, d)) - 0.5) * 0.5).astype(np.float32)
+    Q = ((rng.random((data.num_items, d)) - 0.5) * 0.5).astype(np.float32)
+    P[0] = 0
+    Q[0] = 0
+    reg = (0.01, 0.02, 0.03)
+    e = make_engine(P, Q, None, reg)
+    e.bind_seen_csr(dev(data.indptr), dev(data.indices))
+    e.set_optimizer(kind=0, lr=0.05)
+    e.set_stream_opts(True, run_len)
+    pu, pp = e.plan_epoch(dev(data.users), dev(data.items), chunk=data.nnz, seed=3)
+    negs = torch.zeros_like(pu)
+    sc = torch.zeros(4, device="cuda")
+    e.train_stream(pu, pp, sampler=1, neg=negs, seed=11, max_inflight=1, scalars=sc)
+    Po, Qo = P.copy(), Q.copy()
+    neg_o = np.zeros(data.nnz, np.int32)
+    sco = oracle.train_stream_seq(Po, Qo, None, pu.cpu().numpy(), pp.cpu().numpy(), neg_o, 1, 0.05,
+                                  reg, indptr=data.indptr, indices=data.indices, seed=11)
+    assert np.array_equal(negs.cpu().numpy(), neg_o)
+    assert close(e.P.cpu().numpy(), Po, 1e-5), maxerr(e.P.cpu().numpy(), Po)
+    assert close(e.Q.cpu().numpy(), Qo, 1e-5), maxerr(e.Q.cpu().numpy(), Qo)
+    assert close(sc.cpu().numpy()[:3], sco[:3], 1e-4)
+
+
+def test_stream_grouped_matches_atomic_mode_at_full_concurrency():
+    """Same planned chunk, full chip: register-resident user rows (grouped) and all-atomic user
+    rows give the same tables up to second order in lr (both are asynchronous SGD)."""
+    from revisit_bpr.datasets import synthetic
+
+    data = synthetic.generate(4000, 1500, 120000, median_per_user=20, seed=9)
+    d = 128
+    rng = np.random.default_rng(0)
+    P0 = ((rng.random((data.num_users, d)) - 0.5) / d * 8).astype(np.float32)
+    Q0 = ((rng.random((data.num_items, d)) - 0.5) / d * 8).astype(np.float32)
+    P0[0] = 0
+    Q0[0] = 0
+    res = []
+    for grouped in (True, False):
+        e = make_engine(P0, Q0, None, (0.001, 0.001, 0.001))
+        e.bind_seen_csr(dev(data.indptr), dev(data.indices))
+        e.set_optimizer(kind=0, lr=0.01)
+        e.set_stream_opts(grouped, 8)
+        pu, pp = e.plan_epoch(dev(data.users), dev(data.items), chunk=data.nnz, seed=4)
+        e.train_stream(pu, pp, sampler=1, seed=2)
+        res.append((e.P.cpu().numpy(), e.Q.cpu().numpy()))
+    (Pg, Qg), (Pa, Qa) = res
+    step = np.abs(Pg - P0).max()
+    assert step > 1e-4
+    assert np.abs(Pg - Pa).max() < 0.05 * step, (np.abs(Pg - Pa).max(), step)
+    assert np.abs(Qg - Qa).max() < 0.05 * np.abs(Qg - Q0).max()
