@@ -10,6 +10,8 @@
 // d = 128 segments of 20 k keys (tools/ubench/sort_bench.hip: 0.23 ms vs 0.49 ms).
 #include <hipcub/hipcub.hpp>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "bpr_ctx.h"
@@ -65,6 +67,76 @@ __global__ __launch_bounds__(256) void k_sigma(const float* __restrict__ T, int6
     __syncthreads();
   }
   if (threadIdx.x == 0) sigma[blockIdx.x] = (float)sqrt(red[0] / (double)(I - 2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path (I <= 36,864 items): ONE 1024-thread workgroup per factor sorts the whole column in
+// registers + LDS (hipcub::BlockRadixSort — LSD radix, stable, so ties keep ascending item id) and
+// computes sigma_f on the way: d independent workgroups, no inter-block traffic, no memsets.
+// The column sits in 1024 x ITEMS registers; the ~100 KiB of LDS is the radix exchange buffer.
+// ---------------------------------------------------------------------------------------------
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_sort_factor(const float* __restrict__ T, int64_t I,
+                                                      int32_t* __restrict__ order,
+                                                      float* __restrict__ sigma) {
+  using Sort = hipcub::BlockRadixSort<float, 1024, ITEMS, uint16_t>;
+  __shared__ union {
+    typename Sort::TempStorage sort;
+    double red[2][16];
+  } sm;
+  const int f = blockIdx.x;
+  const float* row = T + (int64_t)f * I;
+  const int t = threadIdx.x;
+  float keys[ITEMS];
+  uint16_t vals[ITEMS];
+  double s1 = 0.0, s2 = 0.0;
+  const float first = row[1];  // shift: removes the mean's magnitude from the sums
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int64_t i = (int64_t)t * ITEMS + k;  // blocked arrangement: sort stability = item order
+    const bool valid = i < I;
+    const float v = valid ? row[i] : -__builtin_huge_valf();
+    keys[k] = v;
+    vals[k] = (uint16_t)i;
+    if (valid && i >= 1) {
+      const double c = (double)v - (double)first;
+      s1 += c;
+      s2 += c * c;
+    }
+  }
+  // sigma_f = unbiased std over rows 1..I-1 (neg_samplers.py:132)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  if ((t & 63) == 0) {
+    sm.red[0][t >> 6] = s1;
+    sm.red[1][t >> 6] = s2;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      a += sm.red[0][w];
+      b += sm.red[1][w];
+    }
+    const double n = (double)(I - 1);
+    sigma[f] = (float)sqrt(fmax(b - a * a / n, 0.0) / (n - 1.0));
+  }
+  __syncthreads();
+  Sort(sm.sort).SortDescendingBlockedToStriped(keys, vals);
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int64_t pos = (int64_t)k * 1024 + t;
+    if (pos < I) order[(int64_t)f * I + pos] = (int32_t)vals[k];
+  }
+}
+
+template <int ITEMS>
+static void launch_sort_factor(bpr_ctx* c) {
+  hipLaunchKernelGGL((k_sort_factor<ITEMS>), dim3(c->d), dim3(1024), 0, c->stream, c->keysT, c->I,
+                     c->order, c->sigma);
 }
 
 // composite sort key: (factor << 32) | ~orderable(value)  → ascending sort = per-factor descending
@@ -233,6 +305,18 @@ int refresh_impl(bpr_ctx* c) {
   }
   dim3 tgrid((unsigned)((I + 31) / 32), (unsigned)((d + 31) / 32));
   hipLaunchKernelGGL(k_transpose, tgrid, dim3(256), 0, c->stream, c->Q, c->keysT, I, d);
+  static const bool no_fast = getenv("BPR_NO_FAST_REFRESH") != nullptr;
+  if (I <= 1024 * 36 && !no_fast) {
+    const int items = (int)((I + 1023) / 1024);
+    if (items <= 6) launch_sort_factor<6>(c);
+    else if (items <= 12) launch_sort_factor<12>(c);
+    else if (items <= 20) launch_sort_factor<20>(c);
+    else if (items <= 28) launch_sort_factor<28>(c);
+    else launch_sort_factor<36>(c);
+    BPR_HIP_CHECK(hipGetLastError());
+    c->have_snapshot = true;
+    return BPR_OK;
+  }
   hipLaunchKernelGGL(k_sigma, dim3(d), dim3(256), 0, c->stream, c->keysT, I, c->sigma);
   uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
   hipLaunchKernelGGL(k_compose_keys, dim3(2048), dim3(256), 0, c->stream, c->keysT, k64, n, I);
