@@ -17,6 +17,11 @@
 namespace bpr {
 
 enum { MODE_FORWARD = 0, MODE_GRAD = 1, MODE_STREAM = 2 };
+
+// occupancy request for k_stream (waves per SIMD). Measured on MI355X, ML-20M shape, adaptive: 4 → 0.325 ms, 5 → 0.305 ms, 6 → 0.444 ms, 8 → 0.544 ms per chunk (above 5 the allocator spills to scratch)
+#ifndef BPR_STREAM_WAVES_PER_EU
+#define BPR_STREAM_WAVES_PER_EU 5
+#endif
 enum { NEG_GIVEN = 0, NEG_UNIFORM = 1, NEG_ADAPTIVE = 2 };
 enum { OPT_SGD = 0, OPT_MOMENTUM = 1, OPT_ADAM = 2, OPT_RMSPROP = 3 };
 
@@ -143,10 +148,6 @@ struct TripleArgs {
   const int32_t* pos;
   int32_t* neg;
   int64_t n;
-  int run_len;  // STREAM: consecutive triples walked by one group
-  int grouped;  // STREAM: 1 = triples of a user are contiguous in this chunk (exclusive rows)
-  int bm_words; // STREAM: 32-bit words of one group's seen-bitmap in LDS (0 = use the CSR)
-  int dbg;      // measurement only (BPR_DEBUG env): 1 = drop item-row updates, 2 = plain stores
   // outputs
   float* lpos;
   float* lneg;
@@ -235,57 +236,79 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 extern __shared__ uint32_t bpr_smem[];
 
+// kernel arguments of k_stream only (kept small: every field costs SGPRs for the whole kernel)
+struct StreamArgs {
+  float* P;
+  float* Q;
+  float* bias;
+  const int64_t* indptr;
+  const int32_t* indices;
+  const int32_t* order;
+  const float* sigma;
+  const int32_t* users;
+  const int32_t* pos;
+  int32_t* neg;
+  float* partials;  // NULL = no statistics
+  uint64_t seed, offset;
+  int32_t n, I, d;
+  int32_t pad_user, pad_item;
+  int32_t run_len, grouped, bm_words, dbg;
+  float au, ai, an, lr, inv_log1mp;
+};
+
 template <int G, int E, int SAMPLER, bool BM>
-__global__ __launch_bounds__(256) void k_stream(const TripleArgs a) {
+__global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const StreamArgs a) {
   constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
   const int gw = lane / G;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
   const int d = a.d;
   const int L = a.run_len;
-  const int64_t n_runs = (a.n + L - 1) / L;
-  const bool stats = a.scalars != nullptr;
+  const int n_runs = (a.n + L - 1) / L;
+  const bool stats = a.partials != nullptr;
   float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
   // per-group seen-items bitmap of the current user in LDS (I bits): one ds_read answers "seen?"
   const int W = a.bm_words;
-  uint32_t* bm = bpr_smem + (size_t)(threadIdx.x / G) * W;
+  uint32_t* bm = bpr_smem + (threadIdx.x / G) * W;
   if constexpr (BM) {
     for (int k = gl; k < W; k += G) bm[k] = 0u;
   }
   int64_t cur_lo = 0, cur_hi = 0;  // CSR slice of the current user
 
-  for (int64_t rbase = wave * GPW; rbase < n_runs; rbase += n_waves * GPW) {
-    const int64_t run = rbase + gw;
+  for (int rbase = wave * GPW; rbase < n_runs; rbase += n_waves * GPW) {
+    const int run = rbase + gw;
     const bool run_act = run < n_runs;
-    const int64_t t0 = run_act ? run * L : 0;
-    const int64_t t1 = run_act ? min(t0 + L, a.n) : 0;
+    const int t0 = run_act ? run * L : 0;
+    const int t1 = run_act ? min(t0 + L, a.n) : 0;
     int32_t cur_u = -1;
     bool cur_starts_inside = false;
-    float p[E], dp[E];
+    // pl = live user row (memory value + this group's pending updates dp)
+    float pl[E], dp[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) p[e] = dp[e] = 0.f;
+    for (int e = 0; e < E; ++e) pl[e] = dp[e] = 0.f;
 
     for (int step = 0; step < L; ++step) {
-      const int64_t t = t0 + step;
+      const int t = t0 + step;
       const bool act = run_act && t < t1;
-      const int64_t tt = act ? t : (a.n - 1);
+      const int tt = act ? t : (a.n - 1);
       const int32_t u = a.users[tt];
       const int32_t i = a.pos[tt];
+      float* __restrict__ irow = a.Q + (uint32_t)i * (uint32_t)d;
+      float qi[E];
+      load_row<G, E>(qi, irow, d, gl);
       if (act && u != cur_u) {
         // ---- user change: write the previous user's row back, fetch the new one
         if (cur_u >= 0 && cur_u != a.pad_user) {
-          float* row = a.P + (int64_t)cur_u * d;
+          float* row = a.P + (uint32_t)cur_u * (uint32_t)d;
           if (a.grouped && cur_starts_inside) {  // run of cur_u ended here, inside my range
-#pragma unroll
-            for (int e = 0; e < E; ++e) p[e] += dp[e];
-            store_row<G, E>(row, p, d, gl);
+            store_row<G, E>(row, pl, d, gl);
           } else {
             atomic_add_row<G, E>(row, dp, d, gl);
           }
         }
-        load_row<G, E>(p, a.P + (int64_t)u * d, d, gl);
+        load_row<G, E>(pl, a.P + (uint32_t)u * (uint32_t)d, d, gl);
 #pragma unroll
         for (int e = 0; e < E; ++e) dp[e] = 0.f;
         if constexpr (SAMPLER != NEG_GIVEN) {
@@ -308,14 +331,7 @@ __global__ __launch_bounds__(256) void k_stream(const TripleArgs a) {
         cur_u = u;
         cur_starts_inside = (step > 0) || (t == 0) || (a.users[t - 1] != u);
       }
-      // live user row = p + dp (dp = this group's not-yet-written updates)
-      float pl[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) pl[e] = p[e] + dp[e];
 
-      float* __restrict__ irow = a.Q + (int64_t)i * d;
-      float qi[E], qj[E];
-      load_row<G, E>(qi, irow, d, gl);
       int32_t j;
       if constexpr (SAMPLER == NEG_GIVEN) {
         j = a.neg[tt];
@@ -333,11 +349,10 @@ __global__ __launch_bounds__(256) void k_stream(const TripleArgs a) {
           j = sample_adaptive<G, E>(pl, d, a.sigma, a.order, a.I, seen, cur_hi - cur_lo,
                                     a.inv_log1mp, a.seed, a.offset + (uint64_t)tt, lane).item;
         }
-      }
-      if constexpr (SAMPLER != NEG_GIVEN) {
         if (a.neg != nullptr && act && gl == 0) a.neg[t] = j;
       }
-      float* __restrict__ jrow = a.Q + (int64_t)j * d;
+      float* __restrict__ jrow = a.Q + (uint32_t)j * (uint32_t)d;
+      float qj[E];
       load_row<G, E>(qj, jrow, d, gl);
 
       float xp = group_sum<G>(dot<E>(pl, qi));
@@ -358,29 +373,24 @@ __global__ __launch_bounds__(256) void k_stream(const TripleArgs a) {
           s_cnt += 1.f;
         }
       }
-      // ---- SGD on the three rows (SURVEY §3.3 gradients), w = σ(−x)
+      // ---- SGD on the three rows (SURVEY §3.3 gradients), w = σ(−x); every gradient uses the
+      // pre-update values of this triple's rows
       const float w = 1.0f / (1.0f + expf(x));
       const float lr = a.lr;
-      float gi[E], gj[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        gi[e] = -lr * (-w * pl[e] + a.ai * qi[e]);
-        gj[e] = -lr * (w * pl[e] + a.an * qj[e]);
-      }
       if (act) {
+        const bool upd_i = (i != a.pad_item) && a.dbg == 0;
+        const bool upd_j = (j != a.pad_item) && a.dbg == 0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) dp[e] += -lr * (-w * (qi[e] - qj[e]) + a.au * pl[e]);
-        if (a.dbg == 0) {
-          if (i != a.pad_item) atomic_add_row<G, E>(irow, gi, d, gl);
-          if (j != a.pad_item) atomic_add_row<G, E>(jrow, gj, d, gl);
-        } else if (a.dbg == 2) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            gi[e] += qi[e];
-            gj[e] += qj[e];
+        for (int e = 0; e < E; ++e) {
+          const int f = e * G + gl;
+          const float pe = pl[e];
+          const float du = -lr * (-w * (qi[e] - qj[e]) + a.au * pe);
+          dp[e] += du;
+          pl[e] = pe + du;
+          if (f < d) {
+            if (upd_i) atomic_add_f32(irow + f, -lr * (-w * pe + a.ai * qi[e]));
+            if (upd_j) atomic_add_f32(jrow + f, -lr * (w * pe + a.an * qj[e]));
           }
-          store_row<G, E>(irow, gi, d, gl);
-          store_row<G, E>(jrow, gj, d, gl);
         }
         if (a.bias != nullptr && gl == 0) {
           atomic_add_f32(a.bias + i, lr * w);
@@ -390,12 +400,10 @@ __global__ __launch_bounds__(256) void k_stream(const TripleArgs a) {
     }
     // ---- end of run: flush the last user
     if (run_act && cur_u >= 0 && cur_u != a.pad_user) {
-      float* row = a.P + (int64_t)cur_u * d;
+      float* row = a.P + (uint32_t)cur_u * (uint32_t)d;
       const bool ends_inside = (t1 == a.n) || (a.users[t1] != cur_u);
       if (a.grouped && cur_starts_inside && ends_inside) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) p[e] += dp[e];
-        store_row<G, E>(row, p, d, gl);
+        store_row<G, E>(row, pl, d, gl);
       } else {
         atomic_add_row<G, E>(row, dp, d, gl);
       }

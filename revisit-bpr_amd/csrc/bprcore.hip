@@ -223,7 +223,7 @@ static int launch_triples(bpr_ctx* c, TripleArgs a, bool timed) {
 // STREAM: one group per run of a.run_len triples; max_inflight caps the number of groups (= triples
 // in flight).  A cap below one 256-thread block shrinks the block (whole waves), so
 // max_inflight = 1 at G = 64 really is ONE wave walking the stream sequentially.
-static int launch_stream(bpr_ctx* c, TripleArgs a, int sampler, int64_t cap_groups) {
+static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_groups, float* out_scalars) {
   if (a.n <= 0) return BPR_OK;
   return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
@@ -258,9 +258,9 @@ static int launch_stream(bpr_ctx* c, TripleArgs a, int sampler, int64_t cap_grou
         hipLaunchKernelGGL((k_stream<G, E, NEG_ADAPTIVE, false>), dim3(grid), dim3(block), 0,
                            c->stream, a);
     }
-    if (a.scalars != nullptr)
+    if (out_scalars != nullptr)
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, a.partials, (int)grid,
-                         a.scalars);
+                         out_scalars);
     BPR_HIP_CHECK(hipGetLastError());
     return BPR_OK;
   });
@@ -579,18 +579,29 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
   if (c->pending != 0)
     return fail(BPR_ERR_INVALID, "bpr_train_stream: unapplied STRICT gradients pending");
   BPR_HIP_CHECK(hipSetDevice(c->device));
-  TripleArgs a = triple_args(c);
-  a.users = users; a.pos = pos; a.neg = neg; a.n = n;
+  if (n >= ((int64_t)1 << 31) || c->U * c->d >= ((int64_t)1 << 31) ||
+      c->I * c->d >= ((int64_t)1 << 31))
+    return fail(BPR_ERR_UNSUPPORTED,
+                "bpr_train_stream: n and rows*d must be < 2^31 (32-bit offsets in the kernel)");
+  StreamArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = c->P; a.Q = c->Q; a.bias = c->bias;
+  a.indptr = c->indptr; a.indices = c->indices;
+  a.order = c->order; a.sigma = c->sigma;
+  a.users = users; a.pos = pos; a.neg = neg;
+  a.partials = out_scalars != nullptr ? c->dev_scalars : nullptr;
   a.seed = seed; a.offset = offset;
-  a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
-  a.scalars = out_scalars;
+  a.n = (int32_t)n; a.I = (int32_t)c->I; a.d = c->d;
+  a.pad_user = c->pad_user; a.pad_item = c->pad_item;
   a.run_len = c->run_len;
   a.grouped = c->grouped;
   {
     static const int dbg = getenv("BPR_DEBUG") ? atoi(getenv("BPR_DEBUG")) : 0;
     a.dbg = dbg;
   }
-  return launch_stream(c, a, sampler, max_inflight);
+  a.au = c->au; a.ai = c->ai; a.an = c->an; a.lr = c->opt.lr;
+  a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
+  return launch_stream(c, a, sampler, max_inflight, out_scalars);
 }
 
 int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t B,

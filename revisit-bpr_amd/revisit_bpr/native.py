@@ -10,7 +10,11 @@ import ctypes
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent.parent / "libbprcore.so"
+import os
+
+# BPR_LIB_PATH: tuning builds only (A/B of compile-time knobs on the GPU box)
+LIB_PATH = Path(os.environ.get("BPR_LIB_PATH") or
+                Path(__file__).resolve().parent.parent / "libbprcore.so")
 
 OK = 0
 OPT_SGD, OPT_MOMENTUM, OPT_ADAM, OPT_RMSPROP = 0, 1, 2, 3
