@@ -526,6 +526,10 @@ struct SampleArgs {
   int32_t* neg;
   int32_t* factor_out;
   int32_t* rank_out;
+  // stateful optimizers: read the user row "as of now" (lazy dense-optimizer replay)
+  const float *mP, *vP;
+  const int32_t* lastP;
+  OptDev o;
 };
 
 enum { SAMPLE_UNIFORM = 0, SAMPLE_ADAPTIVE = 1, SAMPLE_PICK = 2 };
@@ -551,6 +555,10 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
     } else if constexpr (WHAT == SAMPLE_ADAPTIVE) {
       float p[E];
       load_row<G, E>(p, a.P + (int64_t)u * a.d, a.d, gl);
+      if (a.o.kind != OPT_SGD && a.lastP != nullptr) {
+        const int64_t su = a.lastP[u];
+        catch_up_row<G, E>(p, a.mP, a.vP, u, a.d, gl, su, (a.o.t - 1) - su, a.o);
+      }
       const AdaptiveDraw r =
           sample_adaptive<G, E>(p, a.d, a.sigma, a.order, a.I, seen, hi - lo, a.inv_log1mp,
                                 a.seed, a.offset + (uint64_t)tt, lane);

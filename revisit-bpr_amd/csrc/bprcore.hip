@@ -398,6 +398,8 @@ static SampleArgs sample_args(const bpr_ctx* c) {
   a.P = c->P; a.I = c->I; a.d = c->d;
   a.indptr = c->indptr; a.indices = c->indices;
   a.order = c->order; a.sigma = c->sigma;
+  a.mP = c->mP; a.vP = c->vP; a.lastP = c->lastP;
+  a.o = opt_dev(c, c->step + 1);
   return a;
 }
 

@@ -1,0 +1,4 @@
+from revisit_bpr.models.bpr.loss import Loss
+from revisit_bpr.models.bpr.model import MF, BaseLogitModel, Model, get_backend, set_backend
+
+__all__ = ["Model", "MF", "BaseLogitModel", "Loss", "set_backend", "get_backend"]

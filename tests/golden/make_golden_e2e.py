@@ -1,0 +1,131 @@
+#!/usr/bin/env python
+"""End-to-end parity target: train the REFERENCE (imported from /root/reference, build container
+only) on a small synthetic user-split dataset and record nDCG@100 / Recall@20 per epoch for several
+negative-sampler seeds.  Output: tests/golden/e2e_data.npz (the dataset — data, not code) and
+tests/golden/e2e_reference.json (the reference's curves).
+
+Setting (SURVEY §8d pitfalls): lr is chosen so that the reference visibly learns in a few epochs
+(the repo's tuned lr 0.0094 leaves a d=32 model at the untrained floor); the untrained-model metric
+is recorded as the floor; several sampler seeds give the reference's own spread.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_e2e.py
+"""
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, "/root/reference")
+sys.path.insert(1, str(ROOT / "revisit-bpr_amd" / "revisit_bpr" / "datasets"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from accelerate.utils import set_seed  # noqa: E402
+
+import synthetic  # noqa: E402  (our generator, imported by path so that `revisit_bpr` is the reference)
+from revisit_bpr.metrics import NDCG, Recall  # noqa: E402
+from revisit_bpr.models import BPR  # noqa: E402
+from revisit_bpr.models.bpr import MF  # noqa: E402
+from revisit_bpr.modules import AdaptiveSampler, UniformSampler  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+USERS, ITEMS, ACTIONS, D, B, EPOCHS, LR = 4000, 1500, 120_000, 32, 256, 5, 0.2
+REG = {"user": 0.0016, "item": 0.0001, "neg": 0.00375}
+INIT_SEED, ORDER_SEED = 13, 13
+SAMPLER_SEEDS = [1, 2, 3, 4, 5]
+ADAPTIVE_P = 0.05
+
+
+def padded_seen(data, users):
+    lens = (data.indptr[users + 1] - data.indptr[users])
+    S = int(lens.max())
+    out = np.zeros((len(users), max(S, 1)), np.int64)
+    for r, u in enumerate(users):
+        row = data.indices[data.indptr[u]:data.indptr[u + 1]]
+        out[r, :len(row)] = row
+    return torch.from_numpy(out)
+
+
+@torch.no_grad()
+def evaluate(model, data, seen_all):
+    model.eval()
+    nd, rc = NDCG(topk=100), Recall(topk=20)
+    items = torch.arange(data.num_items)
+    for lo in range(0, len(data.eval_users), 512):
+        eu = data.eval_users[lo:lo + 512].astype(np.int64)
+        tgt = torch.zeros(len(eu), data.num_items)
+        for r in range(len(eu)):
+            tgt[r, data.eval_items[data.eval_indptr[lo + r]:data.eval_indptr[lo + r + 1]]] = 1.0
+        logits = model({"user": torch.from_numpy(eu), "item": items.expand(len(eu), -1)})["logits"]
+        logits.scatter_(-1, seen_all[eu], -1e13)
+        logits[:, 0] = -1e13
+        nd(logits, tgt)
+        rc(logits, tgt)
+    model.train()
+    return float(nd.get_metric()), float(rc.get_metric())
+
+
+def run(data, seen_all, sampler_kind, sampler_seed):
+    set_seed(INIT_SEED)
+    model = BPR(fuse_forward=True, reg_alphas=REG,
+                logits_model=MF(torch.nn.Embedding(data.num_users, D, padding_idx=0),
+                                torch.nn.Embedding(data.num_items, D, padding_idx=0)))
+    opt = torch.optim.SGD(model.parameters(), lr=LR)
+    gen = torch.Generator().manual_seed(sampler_seed)
+    if sampler_kind == "uniform":
+        sampler = UniformSampler(data.num_items, gen)
+    else:
+        sampler = AdaptiveSampler(model, data.num_items, ADAPTIVE_P, gen,
+                                  every=int(data.num_items * math.log(data.num_items) / B))
+        sampler.update_stats()
+    users_t, items_t = torch.from_numpy(data.users.astype(np.int64)), torch.from_numpy(
+        data.items.astype(np.int64))
+    order_rng = np.random.default_rng(ORDER_SEED)
+    curve = [evaluate(model, data, seen_all)]
+    model.train()
+    for _ in range(EPOCHS):
+        perm = torch.from_numpy(order_rng.permutation(data.nnz))
+        for lo in range(0, data.nnz, B):
+            idx = perm[lo:lo + B]
+            batch = {"user": users_t[idx], "item": items_t[idx].unsqueeze(-1),
+                     "seen_items": seen_all[users_t[idx]]}
+            batch["neg"] = sampler.sample(batch)
+            out = model(batch)
+            out["loss"].backward()
+            opt.step()
+            opt.zero_grad()
+        curve.append(evaluate(model, data, seen_all))
+    return curve
+
+
+def main():
+    torch.set_num_threads(8)
+    data = synthetic.generate(USERS, ITEMS, ACTIONS, median_per_user=20, min_per_user=5,
+                              eval_users=USERS, seed=7)
+    np.savez_compressed(OUT / "e2e_data.npz", num_users=data.num_users, num_items=data.num_items,
+                        users=data.users, items=data.items, indptr=data.indptr,
+                        indices=data.indices, eval_users=data.eval_users,
+                        eval_indptr=data.eval_indptr, eval_items=data.eval_items)
+    seen_all = padded_seen(data, np.arange(data.num_users))
+    res = {"config": {"users": USERS, "items": ITEMS, "train_triples": data.nnz, "d": D, "B": B,
+                      "epochs": EPOCHS, "lr": LR, "reg": REG, "init_seed": INIT_SEED,
+                      "order_seed": ORDER_SEED, "adaptive_p": ADAPTIVE_P,
+                      "eval_users": int(len(data.eval_users))},
+           "runs": {}}
+    for kind in ("uniform", "adaptive"):
+        for s in SAMPLER_SEEDS:
+            t0 = time.time()
+            curve = run(data, seen_all, kind, s)
+            res["runs"][f"{kind}_{s}"] = {"ndcg@100": [c[0] for c in curve],
+                                          "recall@20": [c[1] for c in curve]}
+            print(kind, s, f"{time.time() - t0:.0f}s", [round(c[0], 4) for c in curve], flush=True)
+            (OUT / "e2e_reference.json").write_text(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

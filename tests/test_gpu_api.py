@@ -1,0 +1,242 @@
+"""GPU tests of the host-side mirror of the reference API: BPR / MF with a stock torch.optim
+optimizer, the samplers, the trainer — all driving the HIP engine — against (a) the dense PyTorch
+restatement on the same device (`set_backend("torch")`, the "PyTorch-ROCm ref" of BASELINE config 2)
+and (b) the reference's golden vectors."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def build(U, I, d, reg, item_bias=False, seed=0):
+    from revisit_bpr.models import BPR
+    from revisit_bpr.models.bpr import MF
+
+    torch.manual_seed(seed)
+    model = BPR(fuse_forward=True, reg_alphas=reg,
+                logits_model=MF(torch.nn.Embedding(U, d, padding_idx=0),
+                                torch.nn.Embedding(I, d, padding_idx=0), item_bias=item_bias))
+    return model.cuda()
+
+
+def batches(U, I, B, steps, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(steps):
+        u = torch.randint(1, U, (B,), generator=g)
+        i = torch.randint(1, I, (B, 1), generator=g)
+        j = torch.randint(1, I, (B, 1), generator=g)
+        u[1] = u[0]
+        i[3] = i[2]
+        j[5] = i[4]
+        out.append({"user": u.cuda(), "item": i.cuda(), "neg": j.cuda()})
+    return out
+
+
+OPTS = {
+    "sgd": lambda p: torch.optim.SGD(p, lr=0.05),
+    "nesterov": lambda p: torch.optim.SGD(p, lr=0.05, momentum=0.9, nesterov=True),
+    "adam": lambda p: torch.optim.Adam(p, lr=0.01, betas=(0.9, 0.999)),
+    "adam01": lambda p: torch.optim.Adam(p, lr=0.01, betas=(0.1, 0.999)),
+    "rmsprop": lambda p: torch.optim.RMSprop(p, lr=0.01, alpha=0.9),
+}
+
+
+@pytest.mark.parametrize("opt_name", list(OPTS))
+@pytest.mark.parametrize("item_bias", [False, True])
+def test_reference_loop_fused_equals_dense_torch(opt_name, item_bias):
+    """model(batch) / loss.backward() / optimizer.step() / zero_grad() — the reference's loop — gives
+    the same parameters through the HIP engine as through dense autograd + torch.optim."""
+    from revisit_bpr.models.bpr import set_backend
+
+    U, I, d, B, steps = 300, 200, 64, 128, 6
+    reg = {"user": 0.0016, "item": 0.0001, "neg": 0.00375}
+    data = batches(U, I, B, steps, seed=3)
+    results = {}
+    for backend in ("hip", "torch"):
+        set_backend(backend)
+        try:
+            model = build(U, I, d, reg, item_bias, seed=11)
+            if item_bias:
+                with torch.no_grad():
+                    model.logits_model._item_bias.copy_(torch.linspace(-0.1, 0.1, I))
+            opt = OPTS[opt_name](model.parameters())
+            model.train()
+            losses = []
+            for b in data:
+                out = model(b)
+                assert set(out) >= {"logits_pos", "logits_neg", "logits", "bpr_loss", "l2_reg", "loss"}
+                assert out["logits"].shape == (B, 1)
+                out["loss"].backward()
+                opt.step()
+                opt.zero_grad()
+                losses.append(float(out["loss"].detach()))
+            model.eval()  # fused: brings lazily-updated rows up to date
+            results[backend] = ({k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                                losses)
+            if backend == "hip":
+                assert all(p.grad is None for p in model.parameters())
+        finally:
+            set_backend("hip")
+    (sd_h, l_h), (sd_t, l_t) = results["hip"], results["torch"]
+    assert np.allclose(l_h, l_t, rtol=2e-5)
+    # RMSprop divides by sqrt(v) ~ |g|: elements whose gradient is ~0 amplify fp32 rounding of g
+    atol = 1e-4 if opt_name == "rmsprop" else 2e-5
+    for k in sd_t:
+        assert torch.allclose(sd_h[k], sd_t[k], rtol=0, atol=atol), (k, (sd_h[k] - sd_t[k]).abs().max())
+
+
+def test_fused_against_reference_golden(golden_dir):
+    """Same loop on the reference's own fixture (tables from the reference's init, torch.optim.Adam)."""
+    from revisit_bpr.models import BPR
+    from revisit_bpr.models.bpr import MF
+
+    g = np.load(golden_dir / "math_13_uin_bias.npz")
+    U, d = g["P0"].shape
+    I = g["Q0"].shape[0]
+    model = BPR(fuse_forward=True, reg_alphas={"user": 0.0016, "item": 0.0001, "neg": 0.00375},
+                logits_model=MF(torch.nn.Embedding(U, d, padding_idx=0),
+                                torch.nn.Embedding(I, d, padding_idx=0), item_bias=True))
+    with torch.no_grad():
+        model.logits_model._user_emb.weight.copy_(torch.from_numpy(g["P0"]))
+        model.logits_model._item_emb.weight.copy_(torch.from_numpy(g["Q0"]))
+        model.logits_model._item_bias.copy_(torch.from_numpy(g["b0"]))
+    model = model.cuda().train()
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.9, 0.999))
+    for s in range(5):
+        b = {"user": torch.from_numpy(g[f"users{s}"]).cuda(),
+             "item": torch.from_numpy(g[f"pos{s}"]).unsqueeze(-1).cuda(),
+             "neg": torch.from_numpy(g[f"neg{s}"]).unsqueeze(-1).cuda()}
+        out = model(b)
+        out["loss"].backward()
+        opt.step()
+        opt.zero_grad()
+        assert abs(float(out["loss"]) - float(g[f"adam_09_loss{s + 1}"])) < 1e-4
+    feats = model.eval().logits_model.get_features()
+    assert np.allclose(feats["user"].detach().cpu().numpy(), g["adam_09_P5"], atol=1e-5)
+    assert np.allclose(feats["item"].detach().cpu().numpy(), g["adam_09_Q5"], atol=1e-5)
+    assert np.allclose(feats["item_bias"].detach().cpu().numpy(), g["adam_09_b5"], atol=1e-5)
+    # the optimizer's state tensors are the live ones (checkpointable)
+    st = opt.state[model.logits_model._item_emb.weight]
+    assert st["exp_avg"].abs().sum() > 0 and st["exp_avg_sq"].abs().sum() > 0
+
+
+def test_no_cpu_fallback_in_training():
+    from revisit_bpr.models import BPR
+    from revisit_bpr.models.bpr import MF
+
+    model = BPR(MF(torch.nn.Embedding(10, 8, padding_idx=0), torch.nn.Embedding(10, 8, padding_idx=0)))
+    model.train()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model({"user": torch.tensor([1]), "item": torch.tensor([[1]]), "neg": torch.tensor([[2]])})
+
+
+def _seen_batch(U, I, B, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    users = torch.randint(1, U, (B,), generator=g)
+    rows = {}
+    seen = torch.zeros(B, S, dtype=torch.long)
+    for r, u in enumerate(users.tolist()):
+        if u not in rows:
+            n = int(torch.randint(0, S + 1, (1,), generator=g))
+            rows[u] = torch.randperm(I - 1, generator=g)[:n] + 1
+        seen[r, :len(rows[u])] = rows[u]
+    return users, seen
+
+
+def test_uniform_sampler_api():
+    from revisit_bpr.modules import UniformSampler
+
+    U, I, B, S = 500, 120, 4096, 40
+    users, seen = _seen_batch(U, I, B, S, seed=1)
+    batch = {"user": users.cuda(), "item": torch.ones(B, 1, dtype=torch.long).cuda(),
+             "seen_items": seen.cuda()}
+    sampler = UniformSampler(I, torch.Generator(device="cuda").manual_seed(13))
+    neg = sampler.sample(batch)
+    assert neg.shape == (B, 1) and neg.dtype == torch.long and neg.is_cuda
+    n = neg.cpu().squeeze(-1)
+    assert n.min() >= 1 and n.max() < I
+    assert not (seen == n.unsqueeze(-1)).any()
+    neg2 = sampler.sample(batch)
+    assert not torch.equal(neg, neg2)  # the stream advances
+    # distribution: uniform over unseen for one user (chi-square)
+    u0 = int(users[0])
+    mask_rows = users == u0
+    allowed = torch.ones(I, dtype=torch.bool)
+    allowed[0] = False
+    allowed[seen[mask_rows][0]] = False
+    big = {"user": torch.full((60000,), u0).cuda(), "item": torch.ones(60000, 1, dtype=torch.long).cuda(),
+           "seen_items": seen[mask_rows][:1].expand(60000, -1).cuda()}
+    cnt = torch.bincount(sampler.sample(big).cpu().squeeze(-1), minlength=I).double()
+    assert cnt[~allowed].sum() == 0
+    k = int(allowed.sum())
+    chi2 = float(((cnt[allowed] - 60000 / k) ** 2 / (60000 / k)).sum())
+    assert chi2 < (k - 1) + 5 * math.sqrt(2 * (k - 1)), chi2
+
+
+def test_adaptive_sampler_api_and_refresh_period():
+    from revisit_bpr.modules import AdaptiveSampler
+
+    U, I, d, B, S = 400, 300, 32, 512, 30
+    model = build(U, I, d, None, seed=5)
+    users, seen = _seen_batch(U, I, B, S, seed=2)
+    batch = {"user": users.cuda(), "item": torch.ones(B, 1, dtype=torch.long).cuda(),
+             "seen_items": seen.cuda()}
+    sampler = AdaptiveSampler(model, I, sampling_prob=0.05,
+                              neg_gen=torch.Generator(device="cuda").manual_seed(7), every=3)
+    sampler.update_stats()
+    order0, _ = model.engine().adaptive_snapshot()
+    for it in range(1, 4):
+        neg = sampler.sample(batch)
+        assert neg.shape == (B, 1) and neg.dtype == torch.long
+        n = neg.cpu().squeeze(-1)
+        assert n.min() >= 1 and n.max() < I and not (seen == n.unsqueeze(-1)).any()
+        with torch.no_grad():  # move the item table so a refresh is visible
+            model.logits_model._item_emb.weight[1:].add_(torch.randn(I - 1, d, device="cuda") * 0.01)
+        order, _ = model.engine().adaptive_snapshot()
+        assert torch.equal(order, order0) == (it < 3)  # refreshed after the 3rd call
+    # picks concentrate on the extremes of the chosen factor: rank << I/2 on average
+    order, sigma = model.engine().adaptive_snapshot()
+    assert sigma.min() > 0
+
+
+def test_trainer_drives_the_engine():
+    from experiments.trainer import ModelEvents, NullAccelerator, Trainer
+    from revisit_bpr.modules import UniformSampler
+
+    try:
+        from ignite.engine import Events
+    except ImportError:
+        from experiments.engine_lite import Events
+
+    U, I, d, B, S = 200, 150, 32, 64, 20
+    model = build(U, I, d, {"all": 0.001}, seed=3)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    trainer = Trainer(model, opt, NullAccelerator(torch.device("cuda")))
+    sampler = UniformSampler(I, torch.Generator(device="cuda").manual_seed(1))
+    loader = []
+    for k in range(10):
+        users, seen = _seen_batch(U, I, B, S, seed=100 + k)
+        loader.append({"user": users.cuda(), "item": torch.randint(1, I, (B,)).cuda(),
+                       "seen_items": seen.cuda()})
+    seen_events = []
+
+    def add_negatives(engine):
+        batch = engine.state.batch
+        if batch["item"].dim() < 2:
+            batch["item"] = batch["item"].unsqueeze(-1)
+        batch["neg"] = sampler.sample(batch)
+
+    trainer.add_event("train", Events.GET_BATCH_COMPLETED, add_negatives)
+    trainer.add_event("train", ModelEvents.OPTIMIZER_COMPLETED,
+                      lambda e: seen_events.append(e.state.optimizer_iteration))
+    before = model.logits_model._user_emb.weight.detach().clone()
+    state = trainer.run({"train": loader}, epochs=3)
+    assert seen_events == list(range(1, 31))
+    assert state.iteration == 30 and float(state.metrics["loss"]) > 0
+    first, last = float(trainer.engines["train"].state.metrics["loss"]), None
+    assert not torch.equal(before, model.logits_model._user_emb.weight)
+    assert first < B * math.log(2) * 1.05  # mean batch loss below the untrained value ~B·ln2
