@@ -100,6 +100,46 @@ def generate(users: int, items: int, actions: int, median_per_user: float = 37.0
         eval_indptr=eval_indptr, eval_items=he_i.astype(np.int32))
 
 
+def generate_latent(users: int, items: int, actions: int, factors: int = 8, strength: float = 1.5,
+                    median_per_user: float = 20.0, min_per_user: int = 5, seed: int = 13,
+                    item_skew: float = 1.0, item_shift: float = 30.0, holdout: float = 0.2,
+                    eval_users: int = -1) -> Interactions:
+    """Small sets with learnable structure (for nDCG parity runs): user u picks its n_u items
+    without replacement with probability ∝ popularity_i · exp(strength · <z_u, y_i>) (Gumbel top-k),
+    z, y ~ N(0, I_factors / factors).  O(users × items) memory — not for the benchmark shapes."""
+    rng = np.random.default_rng(seed)
+    U, I = users + 1, items + 1
+    mean = actions / users
+    sigma = np.sqrt(2.0 * np.log(max(mean / median_per_user, 1.05)))
+    n_u = np.exp(np.log(median_per_user) + sigma * rng.standard_normal(users))
+    n_u = np.clip(np.round(n_u * (actions / n_u.sum())), min_per_user, items // 3).astype(np.int64)
+    logpop = -item_skew * np.log(rng.permutation(items) + 1.0 + item_shift)
+    Z = rng.standard_normal((users, factors)) / np.sqrt(factors)
+    Y = rng.standard_normal((items, factors)) / np.sqrt(factors)
+    score = logpop[None, :] + strength * factors * (Z @ Y.T) + rng.gumbel(size=(users, items))
+    order = np.argsort(-score, axis=1)
+    ku = np.repeat(np.arange(1, U, dtype=np.int64), n_u)
+    ki = np.concatenate([order[u, :n_u[u]] + 1 for u in range(users)]).astype(np.int64)
+    n_eval = users if eval_users < 0 else min(eval_users, users)
+    ev = np.sort(rng.choice(np.arange(1, U), size=n_eval, replace=False))
+    is_ev = np.zeros(U, bool)
+    is_ev[ev] = True
+    held = is_ev[ku] & (rng.random(ku.shape[0]) < holdout)
+    tr_u, tr_i = ku[~held], ki[~held]
+    o = np.lexsort((tr_i, tr_u))
+    tr_u, tr_i = tr_u[o], tr_i[o]
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(tr_u, minlength=U))]).astype(np.int64)
+    he_u, he_i = ku[held], ki[held]
+    o = np.lexsort((he_i, he_u))
+    he_u, he_i = he_u[o], he_i[o]
+    cnt = np.bincount(he_u, minlength=U)[ev]
+    return Interactions(
+        num_users=U, num_items=I, users=tr_u.astype(np.int32), items=tr_i.astype(np.int32),
+        indptr=indptr, indices=tr_i.astype(np.int32), eval_users=ev.astype(np.int32),
+        eval_indptr=np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64),
+        eval_items=he_i.astype(np.int32))
+
+
 def generate_named(name: str, eval_users: int = 0, seed: int = 13, scale: float = 1.0,
                    **kw) -> Interactions:
     users, items, actions, med, mn = SHAPES[name]

@@ -1,0 +1,78 @@
+"""The throughput training loop: the reference's ``train_one_epoch`` (example.py:157-192) with the
+whole inner loop on the device.
+
+Per epoch: ``bpr_plan_epoch`` (seeded shuffle into chunks of one sampler-refresh period, grouped by
+user) and then, per chunk, ``bpr_adaptive_refresh`` (adaptive sampler only) + ONE fused STREAM
+launch (sample negative → gather → gradient → SGD scatter).  The host ships no per-batch data.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from revisit_bpr import engine as eng
+
+
+class StreamTrainer:
+    def __init__(self, model, users: torch.Tensor, items: torch.Tensor, seen_indptr: torch.Tensor,
+                 seen_indices: torch.Tensor, lr: float, sampler: str = "adaptive",
+                 adaptive_p: float = 0.01, batch_size: int = 256, seed: int = 13,
+                 max_inflight: Optional[int] = None, run_len: int = 8, rank: int = 0,
+                 item_sync=None, sync_every: int = 1) -> None:
+        """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
+        the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
+        adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302."""
+        if users.dtype != torch.int32 or items.dtype != torch.int32:
+            raise ValueError("users / items must be int32 device tensors")
+        self.model = model
+        self.engine = model.engine()
+        self.users, self.items = users.contiguous(), items.contiguous()
+        self.n = users.numel()
+        self.engine.bind_seen_csr(seen_indptr, seen_indices)
+        model._has_csr = True
+        self.engine.set_optimizer(eng.OPT_SGD, lr=lr)
+        self.sampler = {"adaptive": eng.NEG_ADAPTIVE, "uniform": eng.NEG_UNIFORM}[sampler]
+        self.adaptive_p = adaptive_p
+        I = self.engine.I
+        every = max(1, int(I * math.log(I) / batch_size))
+        self.chunk = min(every * batch_size, self.n)
+        U = self.engine.U
+        # staleness budget: at most ~U/4 triples in flight against one parameter cut
+        self.max_inflight = max(64, U // 4) if max_inflight is None else max_inflight
+        self.engine.set_stream_opts(True, run_len)
+        self.seed, self.rank = seed, rank
+        self.epoch = 0
+        self.drawn = 0
+        self._pu = torch.empty_like(self.users)
+        self._pi = torch.empty_like(self.items)
+        self._scalars = torch.zeros(4, dtype=torch.float32, device=users.device)
+        self.item_sync, self.sync_every = item_sync, sync_every
+
+    def train_epoch(self) -> dict:
+        e = self.engine
+        e.plan_epoch(self.users, self.items, self.chunk, self.seed + self.epoch,
+                     out=(self._pu, self._pi))
+        self._scalars.zero_()
+        k = 0
+        for lo in range(0, self.n, self.chunk):
+            hi = min(lo + self.chunk, self.n)
+            if self.sampler == eng.NEG_ADAPTIVE:
+                e.adaptive_refresh()
+            e.train_stream(self._pu[lo:hi], self._pi[lo:hi], sampler=self.sampler,
+                           adaptive_p=self.adaptive_p, seed=self.seed,
+                           offset=(self.rank << 40) + self.drawn, max_inflight=self.max_inflight,
+                           scalars=self._scalars)
+            self.drawn += hi - lo
+            k += 1
+            if self.item_sync is not None and k % self.sync_every == 0:
+                self.item_sync.finish()
+                self.item_sync.start()
+        if self.item_sync is not None:
+            self.item_sync.finish()
+        self.epoch += 1
+        sc = self._scalars.tolist()
+        cnt = max(sc[3], 1.0)
+        return {"bpr_loss": sc[0] / cnt, "l2_reg": sc[1] / cnt, "logits_diff": sc[2] / cnt,
+                "loss": (sc[0] + sc[1]) / cnt, "triples": int(sc[3])}

@@ -34,7 +34,7 @@ from revisit_bpr.models.bpr import MF  # noqa: E402
 from revisit_bpr.modules import AdaptiveSampler, UniformSampler  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
-USERS, ITEMS, ACTIONS, D, B, EPOCHS, LR = 4000, 1500, 120_000, 32, 256, 5, 0.2
+USERS, ITEMS, ACTIONS, D, B, EPOCHS, LR = 4000, 1500, 120_000, 32, 256, 12, 0.05
 REG = {"user": 0.0016, "item": 0.0001, "neg": 0.00375}
 INIT_SEED, ORDER_SEED = 13, 13
 SAMPLER_SEEDS = [1, 2, 3, 4, 5]
@@ -105,8 +105,9 @@ def run(data, seen_all, sampler_kind, sampler_seed):
 
 def main():
     torch.set_num_threads(8)
-    data = synthetic.generate(USERS, ITEMS, ACTIONS, median_per_user=20, min_per_user=5,
-                              eval_users=USERS, seed=7)
+    only = sys.argv[1:] or None
+    data = synthetic.generate_latent(USERS, ITEMS, ACTIONS, factors=8, strength=1.5,
+                                     median_per_user=20, min_per_user=5, seed=7)
     np.savez_compressed(OUT / "e2e_data.npz", num_users=data.num_users, num_items=data.num_items,
                         users=data.users, items=data.items, indptr=data.indptr,
                         indices=data.indices, eval_users=data.eval_users,
@@ -119,6 +120,8 @@ def main():
            "runs": {}}
     for kind in ("uniform", "adaptive"):
         for s in SAMPLER_SEEDS:
+            if only and f"{kind}_{s}" not in only:
+                continue
             t0 = time.time()
             curve = run(data, seen_all, kind, s)
             res["runs"][f"{kind}_{s}"] = {"ndcg@100": [c[0] for c in curve],

@@ -1,0 +1,133 @@
+"""N>1 path on CPU (gloo, world_size 2): user sharding + replicated item table reconciled by an
+all-reduce of deltas (revisit_bpr/distributed.py).  The per-rank training step is played by the CPU
+oracle here (tests may use it); on GPUs it is the HIP engine — the protocol is the same."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from revisit_bpr.datasets import synthetic
+from revisit_bpr.distributed import ItemSync, balanced_user_shards, owner_of
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_balanced_user_shards():
+    data = synthetic.generate(3000, 400, 60000, median_per_user=10, seed=2)
+    for world in (1, 2, 4, 8):
+        b = balanced_user_shards(data.indptr, world)
+        assert b[0] == 0 and b[-1] == data.num_users and np.all(np.diff(b) >= 0)
+        loads = np.diff(data.indptr[b])
+        assert loads.sum() == data.nnz
+        assert loads.max() <= data.nnz / world * 1.1 + np.diff(data.indptr).max()
+        own = owner_of(data.users, b)
+        assert own.min() >= 0 and own.max() < world
+        for r in range(world):
+            u = data.users[own == r]
+            assert u.size == 0 or (u.min() >= b[r] and u.max() < b[r + 1])
+
+
+def _worker_sync(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    Q0 = torch.randn(50, 8)
+    Q = Q0.clone()
+    sync = ItemSync([Q])
+    mine = torch.zeros_like(Q)
+    mine[rank::world] = float(rank + 1)
+    Q += mine
+    sync.sync()
+    want = Q0 + sum((torch.zeros_like(Q0).index_fill_(0, torch.arange(r, 50, world), float(r + 1))
+                     for r in range(world)))
+    ok_blocking = torch.allclose(Q, want)
+    # asynchronous form: contributions made after start() survive finish()
+    sync.start()
+    late = torch.zeros_like(Q)
+    late[rank] = 100.0 * (rank + 1)
+    Q += late
+    sync.finish()
+    mid = Q.clone()
+    sync.sync()
+    late_all = torch.zeros_like(Q0)
+    for r in range(world):
+        late_all[r] = 100.0 * (r + 1)
+    ok_async = torch.allclose(mid, want + late) and torch.allclose(Q, want + late_all)
+    # DDP-style mean scale
+    Q2 = Q0.clone()
+    s2 = ItemSync([Q2], scale=1.0 / world)
+    Q2 += float(rank + 1)
+    s2.sync()
+    ok_scale = torch.allclose(Q2, Q0 + sum(range(1, world + 1)) / world)
+    out[rank] = (ok_blocking, ok_async, ok_scale)
+    dist.destroy_process_group()
+
+
+def test_item_sync_gloo_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_sync, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: (True, True, True), 1: (True, True, True)}
+
+
+def _worker_train(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data = synthetic.generate(600, 150, 9000, median_per_user=10, seed=4)
+    d, B, lr, reg = 16, 128, 0.05, (0.001, 0.002, 0.003)
+    rng = np.random.default_rng(0)
+    P = ((rng.random((data.num_users, d)) - 0.5) / d).astype(np.float32)
+    Q = ((rng.random((data.num_items, d)) - 0.5) / d).astype(np.float32)
+    P0 = P.copy()
+    bounds = balanced_user_shards(data.indptr, world)
+    sel = owner_of(data.users, bounds) == rank
+    users, items = data.users[sel], data.items[sel]
+    tQ = torch.from_numpy(Q)  # shares memory with Q
+    sync = ItemSync([tQ])
+    for step in range(5):
+        u, i = users[step * B:(step + 1) * B], items[step * B:(step + 1) * B]
+        neg = oracle.sample_uniform(data.indptr, data.indices, data.num_items, u, seed=1,
+                                    offset=(rank << 40) + step * B)
+        oracle.step_sgd_sparse(P, Q, None, np.ascontiguousarray(u), np.ascontiguousarray(i), neg, lr, reg)
+        sync.sync()
+    touched = np.unique(np.nonzero(np.abs(P - P0).sum(1))[0])
+    out[rank] = (Q.copy(), touched, bounds)
+    dist.destroy_process_group()
+
+
+def test_user_sharded_training_gloo_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_train, args=(2, _free_port(), out), nprocs=2, join=True)
+    (Q0, t0, bounds), (Q1, t1, _) = out[0], out[1]
+    assert np.array_equal(Q0, Q1)  # replicas identical after every sync
+    assert t0.size and t1.size
+    assert t0.max() < bounds[1] <= t1.min()  # each rank only ever touched its own user shard
+    # same protocol emulated in one process
+    data = synthetic.generate(600, 150, 9000, median_per_user=10, seed=4)
+    d, B, lr, reg = 16, 128, 0.05, (0.001, 0.002, 0.003)
+    rng = np.random.default_rng(0)
+    P = ((rng.random((data.num_users, d)) - 0.5) / d).astype(np.float32)
+    Q = ((rng.random((data.num_items, d)) - 0.5) / d).astype(np.float32)
+    own = owner_of(data.users, bounds)
+    shards = [(data.users[own == r], data.items[own == r]) for r in range(2)]
+    for step in range(5):
+        deltas = []
+        for r, (users, items) in enumerate(shards):
+            Pr, Qr = P, Q.copy()  # P rows are disjoint across ranks
+            u, i = users[step * B:(step + 1) * B], items[step * B:(step + 1) * B]
+            neg = oracle.sample_uniform(data.indptr, data.indices, data.num_items, u, seed=1,
+                                        offset=(r << 40) + step * B)
+            oracle.step_sgd_sparse(Pr, Qr, None, np.ascontiguousarray(u), np.ascontiguousarray(i), neg, lr, reg)
+            deltas.append(Qr - Q)
+        Q = Q + deltas[0] + deltas[1]
+    assert np.allclose(Q, Q0, atol=1e-6)
