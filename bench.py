@@ -200,6 +200,16 @@ def main():
         triples = args.steps * chunk * world
         value = triples / dt
         bytes_per_triple = 24 * d + 8  # read 3 rows + write 3 rows (fp32) + 2 int32 ids
+        # HBM-side bytes per k_stream launch from the rocprofv3 PMC passes of this same command
+        # (profiles/r01_pmc_traffic.md: FETCH_SIZE x2 correction + WRITE_SIZE); null when the run
+        # is not the profiled configuration
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic_r01.json"
+        if tfile.exists() and args.workload == "ml-20m" and d == 128 and args.sampler == "adaptive" \
+                and args.scale == 1.0:
+            tj = json.loads(tfile.read_text())
+            if tj.get("triples_per_launch") == chunk:
+                traffic = tj["traffic_bytes_per_launch"]
         achieved = (bytes_per_triple * chunk) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
             "metric": "BPR triples/sec at d=128 (1/2/4/8 GPU) + nDCG@100 parity vs reference",
@@ -232,7 +242,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" if traffic else None,
+                "algorithmic_bytes_per_launch": bytes_per_triple * chunk,
                 "bytes_per_triple": bytes_per_triple,
                 "kernel_ms_avg": kernel_ms,
                 "launches": launches,
