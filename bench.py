@@ -110,10 +110,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libbprcore has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters for functional tests of the N>1 path on a 1-GPU box
+    # (BPR_DIST_BACKEND=gloo, several ranks sharing cuda:0) — RCCL itself needs one device per rank
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BPR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from revisit_bpr import engine as eng
     from revisit_bpr.datasets import synthetic

@@ -159,7 +159,8 @@ __device__ __forceinline__ int32_t sample_uniform(const Seen& seen, int64_t I, u
 // Adaptive negative: AdaptiveSampler.sample (neg_samplers.py:74-124).
 //   order [d, I]  per-factor descending item order of the last snapshot (bpr_adaptive_refresh)
 //   sigma [d]     per-factor unbiased std of the snapshot
-// p[] are the caller's register copies of the LIVE user row (element layout of this file).
+// p[] are the caller's register copies of the LIVE user row, sigma[] of the snapshot's per-factor
+// std (both in the element layout of this file: entry e is factor e*G + gl).
 // ---------------------------------------------------------------------------------------------
 struct AdaptiveDraw {
   int32_t factor;
@@ -214,7 +215,7 @@ __device__ __forceinline__ int32_t adaptive_walk(const int32_t* __restrict__ ord
 
 template <int G, int E, typename Seen>
 __device__ __forceinline__ AdaptiveDraw sample_adaptive(
-    const float (&p)[E], int d, const float* __restrict__ sigma,
+    const float (&p)[E], int d, const float (&sigma)[E],
     const int32_t* __restrict__ order, int64_t I, const Seen& seen, int64_t n_seen,
     float inv_log1mp, uint64_t seed, uint64_t t, int lane) {
   const int gl = lane & (G - 1);
@@ -227,7 +228,7 @@ __device__ __forceinline__ AdaptiveDraw sample_adaptive(
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int f = e * G + gl;
-    w[e] = (f < d) ? fabsf(p[e]) * sigma[f] : 0.f;
+    w[e] = (f < d) ? fabsf(p[e]) * sigma[e] : 0.f;
     incl[e] = group_scan_incl<G>(w[e], gl);
     carry[e] = total;
     total += group_bcast<G>(incl[e], G - 1, lane);

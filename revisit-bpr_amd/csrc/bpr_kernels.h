@@ -276,12 +276,36 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
     for (int k = gl; k < W; k += G) bm[k] = 0u;
   }
   int64_t cur_lo = 0, cur_hi = 0;  // CSR slice of the current user
+  float sg[E];                     // snapshot sigma of this lane's factors (adaptive only)
+  if constexpr (SAMPLER == NEG_ADAPTIVE) {
+    load_row<G, E>(sg, a.sigma, d, gl);
+  }
 
   for (int rbase = wave * GPW; rbase < n_runs; rbase += n_waves * GPW) {
     const int run = rbase + gw;
     const bool run_act = run < n_runs;
     const int t0 = run_act ? run * L : 0;
     const int t1 = run_act ? min(t0 + L, a.n) : 0;
+    // ---- run prologue: ONE coalesced load brings the ids of the whole run (lane k holds triple
+    // t0+k; lane L the successor, lane G-1 the predecessor) and one more the users' CSR bounds,
+    // so the per-triple dependent chain starts at the row gathers instead of at the ids.
+    int32_t my_u = 0, my_i = 0;
+    int64_t my_lo = 0, my_hi = 0;
+    {
+      const int tk = (gl == G - 1) ? t0 - 1 : t0 + gl;
+      const bool in_run = run_act && gl < L && tk < t1;
+      const bool neighbour = run_act && ((gl == L && tk < a.n) || (gl == G - 1 && tk >= 0));
+      if (in_run || neighbour) my_u = a.users[tk];
+      if (in_run) {
+        my_i = a.pos[tk];
+        if constexpr (SAMPLER != NEG_GIVEN) {
+          my_lo = a.indptr[my_u];
+          my_hi = a.indptr[my_u + 1];
+        }
+      }
+    }
+    const int32_t prev_u = (run_act && t0 > 0) ? group_bcast<G>(my_u, G - 1, lane) : -1;
+    const int32_t next_u = (run_act && t1 < a.n) ? group_bcast<G>(my_u, t1 - t0, lane) : -1;
     int32_t cur_u = -1;
     bool cur_starts_inside = false;
     // pl = live user row (memory value + this group's pending updates dp)
@@ -293,8 +317,10 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
       const int t = t0 + step;
       const bool act = run_act && t < t1;
       const int tt = act ? t : (a.n - 1);
-      const int32_t u = a.users[tt];
-      const int32_t i = a.pos[tt];
+      const int32_t u = group_bcast<G>(my_u, step, lane);
+      const int32_t i = group_bcast<G>(my_i, step, lane);
+      const int64_t u_lo = group_bcast<G>(my_lo, step, lane);
+      const int64_t u_hi = group_bcast<G>(my_hi, step, lane);
       float* __restrict__ irow = a.Q + (uint32_t)i * (uint32_t)d;
       float qi[E];
       load_row<G, E>(qi, irow, d, gl);
@@ -319,8 +345,8 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
               for (int k = gl; k < W; k += G) bm[k] = 0u;
             }
           }
-          cur_lo = a.indptr[u];
-          cur_hi = a.indptr[u + 1];
+          cur_lo = u_lo;
+          cur_hi = u_hi;
           if constexpr (BM) {
             for (int64_t k = cur_lo + gl; k < cur_hi; k += G) {
               const int32_t it = a.indices[k];
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
           }
         }
         cur_u = u;
-        cur_starts_inside = (step > 0) || (t == 0) || (a.users[t - 1] != u);
+        cur_starts_inside = (step > 0) || (t == 0) || (prev_u != u);
       }
 
       int32_t j;
@@ -346,7 +372,7 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
         if constexpr (SAMPLER == NEG_UNIFORM) {
           j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane);
         } else {
-          j = sample_adaptive<G, E>(pl, d, a.sigma, a.order, a.I, seen, cur_hi - cur_lo,
+          j = sample_adaptive<G, E>(pl, d, sg, a.order, a.I, seen, cur_hi - cur_lo,
                                     a.inv_log1mp, a.seed, a.offset + (uint64_t)tt, lane).item;
         }
         if (a.neg != nullptr && act && gl == 0) a.neg[t] = j;
@@ -401,7 +427,7 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
     // ---- end of run: flush the last user
     if (run_act && cur_u >= 0 && cur_u != a.pad_user) {
       float* row = a.P + (uint32_t)cur_u * (uint32_t)d;
-      const bool ends_inside = (t1 == a.n) || (a.users[t1] != cur_u);
+      const bool ends_inside = (t1 == a.n) || (next_u != cur_u);
       if (a.grouped && cur_starts_inside && ends_inside) {
         store_row<G, E>(row, pl, d, gl);
       } else {
@@ -559,8 +585,10 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
         const int64_t su = a.lastP[u];
         catch_up_row<G, E>(p, a.mP, a.vP, u, a.d, gl, su, (a.o.t - 1) - su, a.o);
       }
+      float sg[E];
+      load_row<G, E>(sg, a.sigma, a.d, gl);
       const AdaptiveDraw r =
-          sample_adaptive<G, E>(p, a.d, a.sigma, a.order, a.I, seen, hi - lo, a.inv_log1mp,
+          sample_adaptive<G, E>(p, a.d, sg, a.order, a.I, seen, hi - lo, a.inv_log1mp,
                                 a.seed, a.offset + (uint64_t)tt, lane);
       if (act && gl == 0) {
         a.neg[t] = r.item;

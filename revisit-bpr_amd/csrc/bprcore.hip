@@ -635,8 +635,9 @@ int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg,
 
 int bpr_set_stream_opts(bpr_ctx* c, int32_t grouped_by_user, int32_t run_len) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: ctx is NULL");
-  if (run_len < 1 || run_len > 4096)
-    return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: run_len must be in [1, 4096]");
+  if (run_len < 1 || run_len > 30)
+    return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: run_len must be in [1, 30] (one lane of a "
+                                 "32-lane group per triple of the run, plus two neighbours)");
   c->grouped = grouped_by_user != 0;
   c->run_len = run_len;
   return BPR_OK;
