@@ -165,6 +165,18 @@ int bpr_step(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* ne
              int32_t mode, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
              float* out_logits_pos, float* out_logits_neg, float* out_scalars);
 
+/* STRICT epoch driver — `for batch in loader: sample; forward; backward; step` (example.py:172-180,
+ * trainer.py:64-83) with the loop on the host side of the library, so that the reference's exact
+ * mini-batch semantics (any optimizer) cost three kernel launches per batch and no interpreter
+ * time.  users/pos [n] are the epoch's triple stream (already shuffled); batches of B consecutive
+ * triples; neg_scratch [>= B] int32 receives each batch's negatives (sampler != GIVEN) or, for
+ * BPR_NEG_GIVEN, is the full [n] negative stream.  refresh_every > 0 calls bpr_adaptive_refresh
+ * after every refresh_every-th batch (AdaptiveSampler: neg_samplers.py:122-123) — with lazy
+ * optimizers it flushes first.  out_scalars accumulates over the epoch. */
+int bpr_train_strict(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg_scratch,
+                     int64_t n, int64_t B, int32_t sampler, float adaptive_p, uint64_t seed,
+                     uint64_t offset, int64_t refresh_every, float* out_scalars);
+
 /* STREAM throughput entry (train_one_epoch's inner loop, example.py:172-180, over n triples in ONE
  * launch): users/pos are the (already shuffled) triple stream resident in HBM.  `max_inflight`
  * bounds how many triples are processed concurrently (0 = fill the chip); see DESIGN.md §staleness. */

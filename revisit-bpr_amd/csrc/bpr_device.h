@@ -171,7 +171,10 @@ struct AdaptiveDraw {
 // item number `skip` (0-based) among the items of order_f that are not in seen(u) ∪ {0}, counting
 // from the top (from_top) or from the bottom of the order.  WALK_UNROLL chunks of G order entries
 // are fetched per trip so the (coalesced, independent) loads overlap.
-constexpr int WALK_UNROLL = 4;
+#ifndef BPR_WALK_UNROLL
+#define BPR_WALK_UNROLL 4
+#endif
+constexpr int WALK_UNROLL = BPR_WALK_UNROLL;
 
 template <int G, typename Seen>
 __device__ __forceinline__ int32_t adaptive_walk(const int32_t* __restrict__ order_f, int64_t I,

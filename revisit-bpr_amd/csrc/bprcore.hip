@@ -633,6 +633,29 @@ int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg,
   return bpr_apply(c);
 }
 
+int bpr_train_strict(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg_scratch,
+                     int64_t n, int64_t B, int32_t sampler, float adaptive_p, uint64_t seed,
+                     uint64_t offset, int64_t refresh_every, float* out_scalars) {
+  if (int rc = check_triples(c, "bpr_train_strict", users, pos, n)) return rc;
+  if (B < 1) return fail(BPR_ERR_INVALID, "bpr_train_strict: B must be >= 1");
+  if (int rc = check_sampler(c, "bpr_train_strict", sampler, adaptive_p, neg_scratch, n)) return rc;
+  if (sampler != BPR_NEG_GIVEN && neg_scratch == nullptr && n > 0)
+    return fail(BPR_ERR_INVALID, "bpr_train_strict: neg_scratch is NULL");
+  int64_t batch = 0;
+  for (int64_t lo = 0; lo < n; lo += B, ++batch) {
+    const int64_t b = n - lo < B ? n - lo : B;
+    int32_t* neg = sampler == BPR_NEG_GIVEN ? neg_scratch + lo : neg_scratch;
+    if (int rc = bpr_step(c, users + lo, pos + lo, neg, b, BPR_MODE_STRICT, sampler, adaptive_p,
+                          seed, offset + (uint64_t)lo, nullptr, nullptr, out_scalars))
+      return rc;
+    if (refresh_every > 0 && (batch + 1) % refresh_every == 0) {
+      if (int rc = bpr_flush_lazy(c)) return rc;
+      if (int rc = bpr_adaptive_refresh(c)) return rc;
+    }
+  }
+  return BPR_OK;
+}
+
 int bpr_set_stream_opts(bpr_ctx* c, int32_t grouped_by_user, int32_t run_len) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: ctx is NULL");
   if (run_len < 1 || run_len > 30)

@@ -248,6 +248,23 @@ class Engine:
                                                 _ptr(neg), users.numel(), sampler, adaptive_p, seed,
                                                 offset, max_inflight, _ptr(scalars)))
 
+    def train_strict(self, users, pos, batch_size: int, sampler: int = NEG_UNIFORM,
+                     neg: Optional[torch.Tensor] = None, adaptive_p: float = 0.01, seed: int = 0,
+                     offset: int = 0, refresh_every: int = 0,
+                     scalars: Optional[torch.Tensor] = None) -> None:
+        """STRICT mini-batch epoch (any optimizer) with the batch loop inside the library."""
+        self._sync_stream()
+        if users.dtype != torch.int32 or pos.dtype != torch.int32:
+            raise ValueError("train_strict takes int32 id tensors")
+        if neg is None:
+            if sampler == NEG_GIVEN:
+                raise ValueError("sampler NEG_GIVEN needs `neg`")
+            neg = torch.empty(max(batch_size, 1), dtype=torch.int32, device=self.device)
+        native.check(self._lib.bpr_train_strict(self._ctx, users.data_ptr(), pos.data_ptr(),
+                                                neg.data_ptr(), users.numel(), batch_size, sampler,
+                                                adaptive_p, seed, offset, refresh_every,
+                                                _ptr(scalars)))
+
     def set_stream_opts(self, grouped_by_user: bool, run_len: int = 8) -> None:
         native.check(self._lib.bpr_set_stream_opts(self._ctx, int(grouped_by_user), run_len))
 

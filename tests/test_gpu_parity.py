@@ -470,3 +470,56 @@ def test_stream_grouped_matches_atomic_mode_at_full_concurrency():
     assert step > 1e-4
     assert np.abs(Pg - Pa).max() < 0.05 * step, (np.abs(Pg - Pa).max(), step)
     assert np.abs(Qg - Qa).max() < 0.05 * np.abs(Qg - Q0).max()
+
+
+@pytest.mark.parametrize("opt_name", ["sgd", "adam_01"])
+def test_train_strict_epoch_driver(opt_name):
+    """bpr_train_strict == the same batches stepped one by one through bpr_step (and, for SGD,
+    == the oracle's mini-batch steps with the oracle's own Philox negatives)."""
+    from revisit_bpr.datasets import synthetic
+
+    data = synthetic.generate(300, 200, 6000, median_per_user=12, seed=2)
+    d, B = 64, 256
+    rng = np.random.default_rng(1)
+    P = ((rng.random((data.num_users, d)) - 0.5) / d * 4).astype(np.float32)
+    Q = ((rng.random((data.num_items, d)) - 0.5) / d * 4).astype(np.float32)
+    P[0] = 0
+    Q[0] = 0
+    reg = (0.001, 0.002, 0.003)
+    perm = rng.permutation(data.nnz)
+    users, pos = data.users[perm].copy(), data.items[perm].copy()
+    res = []
+    for mode in ("driver", "loop"):
+        e = make_engine(P, Q, None, reg)
+        e.bind_seen_csr(dev(data.indptr), dev(data.indices))
+        e.set_optimizer(**OPT_CFG[opt_name])
+        e.alloc_opt_state()
+        e.adaptive_refresh()
+        sc = torch.zeros(4, device="cuda")
+        tu, tp = dev(users), dev(pos)
+        if mode == "driver":
+            e.train_strict(tu, tp, B, sampler=2, adaptive_p=0.05, seed=4, refresh_every=5, scalars=sc)
+        else:
+            for k, lo in enumerate(range(0, data.nnz, B)):
+                e.step(tu[lo:lo + B], tp[lo:lo + B], sampler=2, adaptive_p=0.05, seed=4, offset=lo,
+                       scalars=sc)
+                if (k + 1) % 5 == 0:
+                    e.flush_lazy()
+                    e.adaptive_refresh()
+        e.flush_lazy()
+        res.append((e.P.cpu().numpy(), e.Q.cpu().numpy(), sc.cpu().numpy()))
+    assert close(res[0][0], res[1][0], 2e-5) and close(res[0][1], res[1][1], 2e-5)
+    assert close(res[0][2], res[1][2], 1e-4) and res[0][2][3] == data.nnz
+    if opt_name == "sgd":  # uniform negatives are bit-identical to the oracle's → full-epoch check
+        e = make_engine(P, Q, None, reg)
+        e.bind_seen_csr(dev(data.indptr), dev(data.indices))
+        e.set_optimizer(kind=0, lr=0.05)
+        e.train_strict(dev(users), dev(pos), B, sampler=1, seed=9)
+        Po, Qo = P.copy(), Q.copy()
+        for lo in range(0, data.nnz, B):
+            u, i = users[lo:lo + B], pos[lo:lo + B]
+            neg = oracle.sample_uniform(data.indptr, data.indices, data.num_items, u, seed=9, offset=lo)
+            oracle.step_sgd_sparse(Po, Qo, None, np.ascontiguousarray(u), np.ascontiguousarray(i), neg,
+                                   0.05, reg)
+        assert close(e.P.cpu().numpy(), Po, 1e-4), maxerr(e.P.cpu().numpy(), Po)
+        assert close(e.Q.cpu().numpy(), Qo, 1e-4), maxerr(e.Q.cpu().numpy(), Qo)
