@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""Train BPR-MF on a JSONL dataset directory with the MI355X engine — same command line as the
+reference's example.py (`python example.py DATASET_PATH [--num-users ...]`), same files, same
+hyper-parameters, same metrics; the epoch loop runs on the device (revisit_bpr.fast.StreamTrainer)
+or, with --mode strict, through the reference's batch loop (sampler → model → backward → step).
+
+    python example.py /data/ml-20m --embedding-dim 1024 --epochs 72
+    python example.py --synthetic ml-20m --embedding-dim 128 --epochs 2      # no files needed
+"""
+from __future__ import annotations
+
+import logging
+import math
+import time
+from pathlib import Path
+
+import click
+import torch
+
+from revisit_bpr.datasets import interactions, synthetic
+from revisit_bpr.evaluation import evaluate
+from revisit_bpr.fast import StreamTrainer
+from revisit_bpr.metrics import NDCG, Precision, Recall, RocAucManySlow
+from revisit_bpr.models import BPR
+from revisit_bpr.models.bpr import MF
+from revisit_bpr.modules import AdaptiveSampler
+
+log = logging.getLogger("example")
+
+
+def build_metrics() -> dict:
+    out = {}
+    for k in (100, 10, 5, 50):
+        out[f"ndcg@{k}"] = NDCG(topk=k)
+        out[f"recall@{k}"] = Recall(topk=k)
+    out["recall@20"] = Recall(topk=20)
+    for k in (5, 10, 50, 100):
+        out[f"precision@{k}"] = Precision(topk=k)
+    out["auc"] = RocAucManySlow()
+    return out
+
+
+def strict_epoch(model, optimizer, sampler, users, items, seen_pad, batch_size, generator):
+    """The reference's train_one_epoch (example.py:157-192) verbatim in structure."""
+    perm = torch.randperm(users.numel(), device=users.device, generator=generator)
+    total, steps = 0.0, 0
+    for lo in range(0, perm.numel(), batch_size):
+        idx = perm[lo:lo + batch_size]
+        batch = {"user": users[idx].long(), "item": items[idx].long().unsqueeze(-1)}
+        if seen_pad is not None:
+            batch["seen_items"] = seen_pad[batch["user"]]
+        batch["neg"] = sampler.sample(batch)
+        out = model(batch)
+        out["loss"].backward()
+        optimizer.step()
+        optimizer.zero_grad()
+        total += float(out["loss"].detach())
+        steps += 1
+    return {"loss": total / max(steps, 1)}
+
+
+@click.command(context_settings={"help_option_names": ["-h", "--help"]})
+@click.argument("dataset_path", required=False,
+                type=click.Path(exists=True, dir_okay=True, file_okay=False, path_type=Path))
+@click.option("--synthetic", "synthetic_name", default=None,
+              help="generate a synthetic dataset of this shape instead of reading files")
+@click.option("--num-users", type=int, default=136678, show_default=True)
+@click.option("--num-items", type=int, default=20109, show_default=True)
+@click.option("--embedding-dim", type=int, default=1024, show_default=True)
+@click.option("--batch-size", type=int, default=256, show_default=True)
+@click.option("--epochs", type=int, default=72, show_default=True)
+@click.option("--seed", type=int, default=13, show_default=True)
+@click.option("--lr", type=float, default=0.00943667980759196, show_default=True)
+@click.option("--sampling-prob", type=float, default=1 / 700, show_default=True)
+@click.option("--mode", type=click.Choice(["stream", "strict"]), default="stream", show_default=True)
+def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batch_size, epochs,
+         seed, lr, sampling_prob, mode):
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s | %(message)s")
+    if not torch.cuda.is_available():
+        raise SystemExit("example.py needs an MI355X (no CPU path)")
+    dev = torch.device("cuda")
+    if synthetic_name:
+        data = synthetic.generate_named(synthetic_name, eval_users=10_000, seed=seed)
+        num_users, num_items = data.num_users, data.num_items
+    elif dataset_path is not None:
+        data = interactions.load_dataset(dataset_path, num_users, num_items)
+    else:
+        raise SystemExit("give DATASET_PATH or --synthetic NAME")
+    torch.manual_seed(seed)
+    model = BPR(
+        fuse_forward=True,
+        logits_model=MF(torch.nn.Embedding(num_users, embedding_dim, padding_idx=0),
+                        torch.nn.Embedding(num_items, embedding_dim, padding_idx=0)),
+        reg_alphas={"user": 0.0016, "item": 0.0001, "neg": 0.00375},
+    ).to(dev)
+    t = {k: torch.from_numpy(getattr(data, k)).to(dev)
+         for k in ("users", "items", "indptr", "indices", "eval_users", "eval_indptr", "eval_items")}
+    metrics = build_metrics()
+    every = int(num_items * math.log(num_items) / batch_size)
+    if mode == "stream":
+        trainer = StreamTrainer(model, t["users"], t["items"], t["indptr"], t["indices"], lr=lr,
+                                sampler="adaptive", adaptive_p=sampling_prob,
+                                batch_size=batch_size, seed=seed)
+        run_epoch = trainer.train_epoch
+    else:
+        model.bind_seen_csr(t["indptr"], t["indices"])
+        optimizer = torch.optim.SGD(model.parameters(), lr=lr)
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        sampler = AdaptiveSampler(model, num_items=num_items, sampling_prob=sampling_prob,
+                                  every=every, neg_gen=gen)
+        sampler.update_stats()
+        model.train()
+
+        def run_epoch():
+            return strict_epoch(model, optimizer, sampler, t["users"], t["items"], None,
+                                batch_size, gen)
+
+    for epoch in range(epochs):
+        t0 = time.perf_counter()
+        stats = run_epoch()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        log.info("epoch %d | %s | %.2fs (%.1f M triples/s)", epoch + 1,
+                 " ".join(f"{k}={v:.4f}" for k, v in stats.items() if isinstance(v, float)), dt,
+                 data.nnz / dt / 1e6)
+        if t["eval_users"].numel():
+            model.eval()
+            f = model.logits_model.get_features()
+            res = evaluate(f["user"].detach(), f["item"].detach(), f["item_bias"], t["eval_users"],
+                           t["eval_indptr"], t["eval_items"], t["indptr"], t["indices"], metrics)
+            model.train()
+            for name in sorted(res, key=lambda x: (len(x), x)):
+                log.info("%-14s | %.4f", name, res[name])
+        log.info("Finished epoch: %d", epoch + 1)
+    return 0
+
+
+if __name__ == "__main__":
+    main()
