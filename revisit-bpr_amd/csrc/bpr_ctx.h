@@ -42,6 +42,7 @@ struct bpr_ctx {
   float* keys_sorted = nullptr;  // 2 x [d, I] uint64 composite sort keys (in | out)
   int32_t* ids_in = nullptr;
   int32_t* seg_offsets = nullptr;  // [d+1]
+  double* sig_acc = nullptr;       // [d, 2] shifted sum / sum of squares per factor
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   bool have_snapshot = false;

@@ -9,6 +9,12 @@
 // significant bits — measured 2.1x faster than DeviceSegmentedRadixSort / DeviceSegmentedSort for
 // d = 128 segments of 20 k keys (tools/ubench/sort_bench.hip: 0.23 ms vs 0.49 ms).
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
+
+// bits per pass of the in-LDS block radix sort (0 = rocPRIM's default, 8)
+#ifndef BPR_SORT_RADIX_BITS
+#define BPR_SORT_RADIX_BITS 0
+#endif
 
 #include <stdlib.h>
 
@@ -75,16 +81,25 @@ __global__ __launch_bounds__(256) void k_sigma(const float* __restrict__ T, int6
 // computes sigma_f on the way: d independent workgroups, no inter-block traffic, no memsets.
 // The column sits in 1024 x ITEMS registers; the ~100 KiB of LDS is the radix exchange buffer.
 // ---------------------------------------------------------------------------------------------
+// Block (s, f) sorts sub-column s of factor f: items [s*len, min((s+1)*len, I)).  With SUB == 1 the
+// result is the final order; otherwise sorted (key, id) runs go to scratch for k_merge_runs, so
+// that 2 (or 4) workgroups per factor share the work and all 256 CUs are busy.
 template <int ITEMS>
-__global__ __launch_bounds__(1024) void k_sort_factor(const float* __restrict__ T, int64_t I,
-                                                      int32_t* __restrict__ order,
-                                                      float* __restrict__ sigma) {
-  using Sort = hipcub::BlockRadixSort<float, 1024, ITEMS, uint16_t>;
+__global__ __launch_bounds__(1024) void k_sort_sub(const float* __restrict__ T, int64_t I,
+                                                   int64_t len, int32_t* __restrict__ order,
+                                                   float* __restrict__ keys_out,
+                                                   int32_t* __restrict__ ids_out,
+                                                   float* __restrict__ sigma,
+                                                   double* __restrict__ sig_acc) {
+  using Sort = rocprim::block_radix_sort<float, 1024, ITEMS, uint16_t, 1, 1, BPR_SORT_RADIX_BITS>;
   __shared__ union {
-    typename Sort::TempStorage sort;
+    typename Sort::storage_type sort;
     double red[2][16];
   } sm;
-  const int f = blockIdx.x;
+  const int f = blockIdx.y;
+  const int64_t base = (int64_t)blockIdx.x * len;
+  const int64_t cnt = min(len, I - base);
+  const bool single = gridDim.x == 1;
   const float* row = T + (int64_t)f * I;
   const int t = threadIdx.x;
   float keys[ITEMS];
@@ -93,12 +108,12 @@ __global__ __launch_bounds__(1024) void k_sort_factor(const float* __restrict__ 
   const float first = row[1];  // shift: removes the mean's magnitude from the sums
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
-    const int64_t i = (int64_t)t * ITEMS + k;  // blocked arrangement: sort stability = item order
-    const bool valid = i < I;
-    const float v = valid ? row[i] : -__builtin_huge_valf();
+    const int64_t l = (int64_t)t * ITEMS + k;  // blocked arrangement: sort stability = item order
+    const bool valid = l < cnt;
+    const float v = valid ? row[base + l] : -__builtin_huge_valf();
     keys[k] = v;
-    vals[k] = (uint16_t)i;
-    if (valid && i >= 1) {
+    vals[k] = (uint16_t)l;
+    if (valid && base + l >= 1) {
       const double c = (double)v - (double)first;
       s1 += c;
       s2 += c * c;
@@ -121,22 +136,86 @@ __global__ __launch_bounds__(1024) void k_sort_factor(const float* __restrict__ 
       a += sm.red[0][w];
       b += sm.red[1][w];
     }
-    const double n = (double)(I - 1);
-    sigma[f] = (float)sqrt(fmax(b - a * a / n, 0.0) / (n - 1.0));
+    if (single) {
+      const double n = (double)(I - 1);
+      sigma[f] = (float)sqrt(fmax(b - a * a / n, 0.0) / (n - 1.0));
+    } else {  // finalised by k_merge_runs (last level)
+      atomicAdd(&sig_acc[2 * f + 0], a);
+      atomicAdd(&sig_acc[2 * f + 1], b);
+    }
   }
   __syncthreads();
-  Sort(sm.sort).SortDescendingBlockedToStriped(keys, vals);
+  Sort().sort_desc_to_striped(keys, vals, sm.sort);
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const int64_t pos = (int64_t)k * 1024 + t;
-    if (pos < I) order[(int64_t)f * I + pos] = (int32_t)vals[k];
+    if (pos < cnt) {
+      const int64_t o = (int64_t)f * I + base + pos;
+      if (single) {
+        order[o] = (int32_t)(base + vals[k]);
+      } else {
+        keys_out[o] = keys[k];
+        ids_out[o] = (int32_t)(base + vals[k]);
+      }
+    }
+  }
+}
+
+// Merge neighbouring sorted runs of length `run` (descending keys; on equal keys the left run —
+// lower item ids — goes first, which keeps the order identical to a stable full sort).
+// Merge path: every thread finds where its MERGE_PER_THREAD outputs start in the two runs by a
+// binary search along the cross diagonal, then merges serially.
+constexpr int MERGE_PER_THREAD = 16;
+
+__global__ __launch_bounds__(256) void k_merge_runs(const float* __restrict__ keys_in,
+                                                    const int32_t* __restrict__ ids_in, int64_t I,
+                                                    int64_t run, float* __restrict__ keys_out,
+                                                    int32_t* __restrict__ ids_out, int last,
+                                                    float* __restrict__ sigma,
+                                                    const double* __restrict__ sig_acc) {
+  const int f = blockIdx.y;
+  const int64_t o0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * MERGE_PER_THREAD;
+  if (last && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double a = sig_acc[2 * f], b = sig_acc[2 * f + 1], n = (double)(I - 1);
+    sigma[f] = (float)sqrt(fmax(b - a * a / n, 0.0) / (n - 1.0));
+  }
+  if (o0 >= I) return;
+  const float* K = keys_in + (int64_t)f * I;
+  const int32_t* V = ids_in + (int64_t)f * I;
+  const int64_t pair = o0 / (2 * run);
+  const int64_t a0 = pair * 2 * run;
+  const int64_t lenA = min(run, I - a0);
+  const int64_t b0 = a0 + lenA;
+  const int64_t lenB = max((int64_t)0, min(run, I - b0));
+  const int64_t k = o0 - a0;  // outputs of this pair that precede mine
+  int64_t lo = max((int64_t)0, k - lenB), hi = min(k, lenA);
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (K[a0 + mid] >= K[b0 + (k - mid - 1)]) lo = mid + 1; else hi = mid;
+  }
+  int64_t a = lo, b = k - lo;
+  const int64_t n_out = min((int64_t)MERGE_PER_THREAD, (a0 + lenA + lenB) - o0);
+  float ka = a < lenA ? K[a0 + a] : 0.f, kb = b < lenB ? K[b0 + b] : 0.f;
+  for (int64_t q = 0; q < n_out; ++q) {
+    const bool take_a = (a < lenA) && (b >= lenB || ka >= kb);
+    const int64_t src = take_a ? a0 + a : b0 + b;
+    const int64_t o = (int64_t)f * I + o0 + q;
+    ids_out[o] = V[src];
+    if (!last) keys_out[o] = take_a ? ka : kb;
+    if (take_a) {
+      ++a;
+      ka = a < lenA ? K[a0 + a] : 0.f;
+    } else {
+      ++b;
+      kb = b < lenB ? K[b0 + b] : 0.f;
+    }
   }
 }
 
 template <int ITEMS>
-static void launch_sort_factor(bpr_ctx* c) {
-  hipLaunchKernelGGL((k_sort_factor<ITEMS>), dim3(c->d), dim3(1024), 0, c->stream, c->keysT, c->I,
-                     c->order, c->sigma);
+static void launch_sort_sub(bpr_ctx* c, int sub, int64_t len, float* keysA, int32_t* idsA) {
+  hipLaunchKernelGGL((k_sort_sub<ITEMS>), dim3(sub, c->d), dim3(1024), 0, c->stream, c->keysT,
+                     c->I, len, c->order, keysA, idsA, c->sigma, c->sig_acc);
 }
 
 // composite sort key: (factor << 32) | ~orderable(value)  → ascending sort = per-factor descending
@@ -265,6 +344,8 @@ void refresh_free(bpr_ctx* c) {
   hipFree(c->keys_sorted);
   hipFree(c->ids_in);
   hipFree(c->seg_offsets);
+  hipFree(c->sig_acc);
+  c->sig_acc = nullptr;
   hipFree(c->sort_tmp);
   c->order = nullptr;
   c->sigma = nullptr;
@@ -294,6 +375,7 @@ int refresh_impl(bpr_ctx* c) {
     BPR_HIP_CHECK(hipMalloc(&c->keys_sorted, sizeof(uint64_t) * 2 * n));  // composite keys in|out
     BPR_HIP_CHECK(hipMalloc(&c->ids_in, sizeof(int32_t) * n));
     BPR_HIP_CHECK(hipMalloc(&c->seg_offsets, sizeof(int32_t) * (d + 1)));
+    BPR_HIP_CHECK(hipMalloc(&c->sig_acc, sizeof(double) * 2 * d));
     hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, c->stream, c->ids_in, c->seg_offsets, I,
                        d);
     size_t bytes = 0;
@@ -306,13 +388,38 @@ int refresh_impl(bpr_ctx* c) {
   dim3 tgrid((unsigned)((I + 31) / 32), (unsigned)((d + 31) / 32));
   hipLaunchKernelGGL(k_transpose, tgrid, dim3(256), 0, c->stream, c->Q, c->keysT, I, d);
   static const bool no_fast = getenv("BPR_NO_FAST_REFRESH") != nullptr;
-  if (I <= 1024 * 36 && !no_fast) {
-    const int items = (int)((I + 1023) / 1024);
-    if (items <= 6) launch_sort_factor<6>(c);
-    else if (items <= 12) launch_sort_factor<12>(c);
-    else if (items <= 20) launch_sort_factor<20>(c);
-    else if (items <= 28) launch_sort_factor<28>(c);
-    else launch_sort_factor<36>(c);
+  const char* fs = getenv("BPR_REFRESH_SUB");  // tests force the split/merge paths on small tables
+  const int force_sub = fs ? atoi(fs) : 0;
+  // one workgroup per factor when the column fits the in-LDS sort (<= 36 keys per thread) — measured
+  // faster than splitting (ML-20M: 0.090 ms vs 0.106 ms with 2 workgroups + merge); larger item
+  // tables are split over 2 or 4 workgroups per factor and the sorted runs merged pairwise.
+  // Run lengths are multiples of MERGE_PER_THREAD so that a thread's outputs never straddle runs.
+  int sub = 1;
+  while (sub < 4 && (I + sub - 1) / sub > 1024 * 36) sub *= 2;
+  if (force_sub == 1 || force_sub == 2 || force_sub == 4) sub = force_sub;
+  int64_t len = (I + sub - 1) / sub;
+  len = (len + MERGE_PER_THREAD - 1) / MERGE_PER_THREAD * MERGE_PER_THREAD;
+  if (len <= 1024 * 36 && !no_fast) {
+    float* keysA = reinterpret_cast<float*>(c->keys_sorted);
+    int32_t* idsA = reinterpret_cast<int32_t*>(keysA + n);
+    float* keysB = reinterpret_cast<float*>(idsA + n);
+    int32_t* idsB = reinterpret_cast<int32_t*>(keysB + n);
+    if (sub > 1) BPR_HIP_CHECK(hipMemsetAsync(c->sig_acc, 0, sizeof(double) * 2 * d, c->stream));
+    const int items = (int)((len + 1023) / 1024);
+    if (items <= 6) launch_sort_sub<6>(c, sub, len, keysA, idsA);
+    else if (items <= 12) launch_sort_sub<12>(c, sub, len, keysA, idsA);
+    else if (items <= 20) launch_sort_sub<20>(c, sub, len, keysA, idsA);
+    else if (items <= 28) launch_sort_sub<28>(c, sub, len, keysA, idsA);
+    else launch_sort_sub<36>(c, sub, len, keysA, idsA);
+    const unsigned mgrid = (unsigned)((I + 256 * MERGE_PER_THREAD - 1) / (256 * MERGE_PER_THREAD));
+    int64_t run = len;
+    for (int level = sub; level > 1; level /= 2, run *= 2) {
+      const int last = level == 2;
+      hipLaunchKernelGGL(k_merge_runs, dim3(mgrid, d), dim3(256), 0, c->stream, keysA, idsA, I, run,
+                         keysB, last ? c->order : idsB, last, c->sigma, c->sig_acc);
+      std::swap(keysA, keysB);
+      std::swap(idsA, idsB);
+    }
     BPR_HIP_CHECK(hipGetLastError());
     c->have_snapshot = true;
     return BPR_OK;

@@ -523,3 +523,27 @@ def test_train_strict_epoch_driver(opt_name):
                                    0.05, reg)
         assert close(e.P.cpu().numpy(), Po, 1e-4), maxerr(e.P.cpu().numpy(), Po)
         assert close(e.Q.cpu().numpy(), Qo, 1e-4), maxerr(e.Q.cpu().numpy(), Qo)
+
+
+@pytest.mark.parametrize("I,d,force_sub", [(45000, 16, 0), (80001, 8, 0), (20109, 128, 0),
+                                           (36865, 300, 0), (150000, 8, 0), (5003, 24, 2),
+                                           (5003, 24, 4), (777, 40, 4)])
+def test_refresh_large_item_counts(I, d, force_sub, monkeypatch):
+    """Refresh paths: in-LDS sort with 1, 2 or 4 workgroups per factor + merge (I <= 147k), and the
+    device-wide rocPRIM sort beyond.  Exact order (ties by item id) and sigma vs the oracle."""
+    if force_sub:
+        monkeypatch.setenv("BPR_REFRESH_SUB", str(force_sub))
+    rng = np.random.default_rng(I + d)
+    Q = (rng.standard_normal((I, d)) * 0.05).astype(np.float32)
+    Q[0] = 0
+    Q[5] = Q[7]  # exact ties
+    Q[I // 2] = Q[I // 2 + 3]
+    Q[I - 1] = Q[1]
+    P = np.zeros((4, d), np.float32)
+    e = make_engine(P, Q)
+    e.adaptive_refresh()
+    order, sigma = e.adaptive_snapshot()
+    QT, sigma_o = oracle.adaptive_stats(Q)
+    order_o = oracle.adaptive_order(QT)
+    assert np.array_equal(order.cpu().numpy(), order_o)
+    assert close(sigma.cpu().numpy(), sigma_o, 2e-6)

@@ -26,7 +26,7 @@ __device__ __forceinline__ void aadd_wg(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-enum { V_READ = 0, V_RMW = 1, V_ATOM4 = 2, V_ATOMS = 3, V_ATOM4_WG = 4, V_ATOM_LDS = 5, V_ATOMS_Q_RMW_P = 6, V_NT = 7 };
+enum { V_ATOMS_SYS = 8, V_ATOMS_ONLYQ = 9, V_READ = 0, V_RMW = 1, V_ATOM4 = 2, V_ATOMS = 3, V_ATOM4_WG = 4, V_ATOM_LDS = 5, V_ATOMS_Q_RMW_P = 6, V_NT = 7 };
 
 template <int V>
 __global__ __launch_bounds__(256) void k(float* P, float* Q, const int* us, const int* is, const int* js,
@@ -44,7 +44,31 @@ __global__ __launch_bounds__(256) void k(float* P, float* Q, const int* us, cons
     float* pr = P + (int64_t)u * D;
     float* ir = Q + (int64_t)i * D;
     float* jr = Q + (int64_t)j * D;
-    if constexpr (V == V_ATOMS) {
+    if constexpr (V == V_ATOMS_SYS || V == V_ATOMS_ONLYQ) {
+      float p[4], qi[4], qj[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { p[e] = pr[e * G + gl]; qi[e] = ir[e * G + gl]; qj[e] = jr[e * G + gl]; }
+      float x = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x += p[e] * (qi[e] - qj[e]);
+      x = gsum(x);
+      const float w = 1.f / (1.f + __expf(x));
+      acc += x;
+      if (act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (V == V_ATOMS_SYS) {
+            __hip_atomic_fetch_add(pr + e * G + gl, lr * (w * (qi[e] - qj[e]) - 0.01f * p[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_add(ir + e * G + gl, lr * (w * p[e] - 0.01f * qi[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_add(jr + e * G + gl, lr * (-w * p[e] - 0.01f * qj[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          } else {
+            pr[e * G + gl] = p[e] + lr * (w * (qi[e] - qj[e]) - 0.01f * p[e]);
+            aadd(ir + e * G + gl, lr * (w * p[e] - 0.01f * qi[e]));
+            aadd(jr + e * G + gl, lr * (-w * p[e] - 0.01f * qj[e]));
+          }
+        }
+      }
+    } else if constexpr (V == V_ATOMS) {
       float p[4], qi[4], qj[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { p[e] = pr[e * G + gl]; qi[e] = ir[e * G + gl]; qj[e] = jr[e * G + gl]; }
@@ -177,13 +201,15 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(is, hi.data(), n * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(js, hj.data(), n * 4, hipMemcpyHostToDevice));
   printf("n=%lld U=%lld I=%lld d=%d hot=%d\n", (long long)n, (long long)U, (long long)I, D, hot);
-  for (int blocks : {1024, 2048, 4096, 8192}) {
+  for (int blocks : {2048}) {
     run<V_READ>("read-only", blocks, P, Q, us, is, js, n, out);
     run<V_RMW>("rmw-store", blocks, P, Q, us, is, js, n, out);
     run<V_ATOM4>("atomic-strided4", blocks, P, Q, us, is, js, n, out);
     run<V_NT>("atomic4+nt-load", blocks, P, Q, us, is, js, n, out);
     run<V_ATOMS>("atomic-contig", blocks, P, Q, us, is, js, n, out);
     run<V_ATOM_LDS>("atomic-lds-T", blocks, P, Q, us, is, js, n, out);
+    run<V_ATOMS_SYS>("atomic-contig-sys", blocks, P, Q, us, is, js, n, out);
+    run<V_ATOMS_ONLYQ>("P-store+Q-contig", blocks, P, Q, us, is, js, n, out);
     run<V_ATOM4_WG>("atomic4-wgscope", blocks, P, Q, us, is, js, n, out);
     run<V_ATOMS_Q_RMW_P>("P-rmw+Q-atomic4", blocks, P, Q, us, is, js, n, out);
   }
