@@ -52,3 +52,55 @@ def evaluate(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch.Tens
         for m in metrics.values():
             m(logits, target)
     return {k: float(m.get_metric()) for k, m in metrics.items()}
+
+
+@torch.no_grad()
+def evaluate_topk(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch.Tensor,
+                  eval_indptr: torch.Tensor, eval_items: torch.Tensor, seen_indptr: torch.Tensor,
+                  seen_indices: torch.Tensor, ks=(5, 10, 20, 50, 100), block: int = 4096) -> dict:
+    """NDCG / Recall / Precision at every k in `ks` from ONE top-max(ks) per block of users (the
+    reference runs a full argsort of I scores per metric object: 14 sorts per batch,
+    experiments/bpr/exp.py:369-374 + metrics/metric.py:110-113).  Same values as the metric classes
+    (tests/test_gpu_api.py::test_evaluate_topk_equals_metric_classes)."""
+    dev = P.device
+    I = Q.shape[0]
+    kmax = min(max(ks), I)
+    disc = 1.0 / torch.log2(torch.arange(kmax, dtype=torch.float, device=dev) + 2.0)
+    sums = {f"{m}@{k}": torch.zeros((), device=dev, dtype=torch.float64)
+            for k in ks for m in ("ndcg", "recall", "precision")}
+    E = eval_users.numel()
+    for lo in range(0, E, block):
+        hi = min(lo + block, E)
+        users = eval_users[lo:hi].long()
+        n = hi - lo
+        rows = torch.arange(n, device=dev)
+        logits = P[users] @ Q.T
+        if item_bias is not None:
+            logits += item_bias
+        s_lo, s_hi = seen_indptr[users], seen_indptr[users + 1]
+        s_cnt = s_hi - s_lo
+        tot = int(s_cnt.sum())
+        if tot > 0:
+            r = torch.repeat_interleave(rows, s_cnt)
+            offs = torch.arange(tot, device=dev) - torch.repeat_interleave(
+                torch.cumsum(s_cnt, 0) - s_cnt, s_cnt)
+            logits[r, seen_indices[torch.repeat_interleave(s_lo, s_cnt) + offs].long()] = -1e13
+        logits[:, 0] = -1e13
+        t_lo, t_hi = eval_indptr[lo:hi], eval_indptr[lo + 1:hi + 1]
+        t_cnt = t_hi - t_lo
+        target = torch.zeros(n, I, device=dev)
+        if int(t_cnt.sum()) > 0:
+            target[torch.repeat_interleave(rows, t_cnt),
+                   eval_items[int(t_lo[0]):int(t_hi[-1])].long()] = 1.0
+        rel = torch.gather(target, 1, torch.topk(logits, kmax, dim=1).indices)  # [n, kmax]
+        n_pos = t_cnt.float()
+        gains = rel * disc
+        for k in ks:
+            kk = min(k, I)
+            hits = rel[:, :kk].sum(1)
+            ideal = torch.cumsum(disc, 0)[(n_pos.clamp(max=kk).long() - 1).clamp(min=0)]
+            ideal = torch.where(n_pos > 0, ideal, torch.zeros_like(ideal))
+            sums[f"ndcg@{k}"] += torch.nan_to_num(gains[:, :kk].sum(1) / ideal).double().sum()
+            sums[f"recall@{k}"] += torch.nan_to_num(hits / n_pos).double().sum()
+            sums[f"precision@{k}"] += (hits / kk).double().sum()
+    return {k: float(v / max(E, 1)) for k, v in sums.items()}

@@ -240,3 +240,27 @@ def test_trainer_drives_the_engine():
     first, last = float(trainer.engines["train"].state.metrics["loss"]), None
     assert not torch.equal(before, model.logits_model._user_emb.weight)
     assert first < B * math.log(2) * 1.05  # mean batch loss below the untrained value ~B·ln2
+
+
+def test_evaluate_topk_equals_metric_classes():
+    from revisit_bpr.datasets import synthetic
+    from revisit_bpr.evaluation import evaluate, evaluate_topk
+    from revisit_bpr.metrics import NDCG, Precision, Recall
+
+    data = synthetic.generate_latent(700, 260, 15000, seed=8)
+    g = torch.Generator().manual_seed(0)
+    P = torch.randn(data.num_users, 32, generator=g).cuda()
+    Q = torch.randn(data.num_items, 32, generator=g).cuda()
+    b = torch.randn(data.num_items, generator=g).cuda()
+    t = {k: torch.from_numpy(getattr(data, k)).cuda()
+         for k in ("eval_users", "eval_indptr", "eval_items", "indptr", "indices")}
+    ks = (5, 10, 20, 50, 100)
+    metrics = {}
+    for k in ks:
+        metrics[f"ndcg@{k}"], metrics[f"recall@{k}"], metrics[f"precision@{k}"] = \
+            NDCG(topk=k), Recall(topk=k), Precision(topk=k)
+    args = (P, Q, b, t["eval_users"], t["eval_indptr"], t["eval_items"], t["indptr"], t["indices"])
+    slow = evaluate(*args, metrics, block=128)
+    fast = evaluate_topk(*args, ks=ks, block=300)
+    for name, v in slow.items():
+        assert abs(fast[name] - v) < 2e-6, (name, fast[name], v)
