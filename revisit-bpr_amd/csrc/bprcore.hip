@@ -229,14 +229,28 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     using T = decltype(tag);
     constexpr int G = T::G, E = T::E;
     const int64_t n_runs = (a.n + a.run_len - 1) / a.run_len;
-    const unsigned grid = grid_for(n_runs, G, cap_groups);
     unsigned block = 256;
     if (cap_groups > 0 && cap_groups * G < 256) block = (unsigned)(((cap_groups * G + 63) / 64) * 64);
-    // LDS seen-bitmap: I bits per group, if the block's groups fit in 64 KiB (keeps >= 2 blocks/CU)
+    // LDS seen-bitmap: I bits per group.  The block's bitmaps must fit 64 KiB (>= 2 blocks per CU);
+    // large item tables get smaller blocks (fewer groups per block) before falling back to the CSR.
     const int words = (int)((c->I + 31) / 32);
-    const size_t lds = (size_t)(block / G) * (size_t)words * sizeof(uint32_t);
     static const bool no_bm = getenv("BPR_NO_BITMAP") != nullptr;
-    const bool bm = sampler != NEG_GIVEN && lds <= 64 * 1024 && !no_bm;
+    bool bm = sampler != NEG_GIVEN && !no_bm;
+    if (bm) {
+      while (block > 64 && (size_t)(block / G) * words * sizeof(uint32_t) > 64 * 1024) block /= 2;
+      if ((size_t)(block / G) * words * sizeof(uint32_t) > 64 * 1024) {
+        bm = false;
+        block = 256;
+      }
+    }
+    const size_t lds = (size_t)(block / G) * (size_t)words * sizeof(uint32_t);
+    int64_t want = n_runs;
+    if (cap_groups > 0 && want > cap_groups) want = cap_groups;
+    const int64_t per_block = block / G;
+    int64_t nblk = (want + per_block - 1) / per_block;
+    const int64_t max_blk = (int64_t)max_blocks() * (256 / block);
+    if (nblk > max_blk) nblk = max_blk;
+    const unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
     a.bm_words = bm ? words : 0;
     const size_t shmem = bm ? lds : 0;
     {
