@@ -1,0 +1,225 @@
+"""``experiments.bpr.Experiment`` — what the reference's BPR configs instantiate
+(experiments/bpr/exp.py:44-405 of the reference), reduced to the training path: build model /
+optimizer / loaders from the config, wire negative sampling, seen-item masking, metrics, early
+stopping and per-epoch logging onto the two-engine ``Trainer``, run.  Trackers (W&B / ClearML),
+accelerate checkpoints, S3 and Optuna are out of scope; the constructor
+still accepts their arguments so configs load unchanged.
+
+Negative sampling runs on the device: the training dataset's seen-items CSR is bound to the engine
+once, and the per-batch handler calls the device samplers (uniform when
+``adaptive_sampling_prob`` is unset — exp.py:356-367 of the reference).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import math
+import random
+from pathlib import Path
+from typing import Any, Callable, Literal, Optional
+
+import numpy as np
+import torch
+
+from experiments.config import instantiate
+from experiments.trainer import Events, ModelEvents, NullAccelerator, Trainer
+from revisit_bpr.modules import AdaptiveSampler, UniformSampler
+
+log = logging.getLogger("experiments.bpr")
+
+
+def _seed_worker(worker_id: int) -> None:
+    seed = torch.initial_seed() % 2 ** 32
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+class BPRExperiment:
+    def __init__(self, exp_config, dir: Optional[Path] = None, n_checkpoints: int = 2,
+                 mixed_precision: Optional[str] = None, datasets_key: str = "datasets",
+                 metrics: Optional[dict] = None, trackers_params: Optional[dict] = None,
+                 events: Optional[dict] = None, seed: int = 13, debug: bool = False,
+                 skip_seen: bool = True, save_logits: bool = False,
+                 save_user_metrics: bool = False, log_momentum: bool = False,
+                 early_stopping_metric: Optional[str] = None, early_stopping_patience: int = 200,
+                 early_stopping_direction: Literal["min", "max"] = "max",
+                 neg_sampling_alpha: float = 0.0,
+                 adaptive_sampling_prob: Optional[float] = None) -> None:
+        self._config = exp_config if isinstance(exp_config, dict) else exp_config()
+        self._dir = Path(dir) if dir is not None else None
+        self._datasets_key = datasets_key
+        self._metrics = metrics or {}
+        self._events = events or {}
+        self._seed = seed
+        self._debug = debug
+        self._skip_seen = skip_seen
+        self._early = (early_stopping_metric, early_stopping_patience, early_stopping_direction)
+        self._adaptive_p = adaptive_sampling_prob
+        if neg_sampling_alpha != 0.0:
+            raise NotImplementedError("popularity-weighted negatives (neg_sampling_alpha != 0) are "
+                                      "not implemented by the device samplers")
+        self._state = None
+        self.history: list[dict] = []
+
+    @property
+    def metrics(self) -> dict[str, Any]:
+        return self._state.metrics if self._state is not None else {}
+
+    # ---- setup ------------------------------------------------------------------------------
+    def _seed_everything(self) -> None:
+        random.seed(self._seed)
+        np.random.seed(self._seed)
+        torch.manual_seed(self._seed)
+
+    def run(self) -> Any:
+        cfg = self._config
+        self._accelerator = acc = NullAccelerator()
+        self._seed_everything()
+        self._model = instantiate(cfg["model"]).to(acc.device)
+        self._optimizer = instantiate(cfg["optimizer"])(self._model.parameters())
+        dcfg = cfg[self._datasets_key]
+        max_iters = {k: d.pop("max_iters", None) for k, d in dcfg.items() if isinstance(d, dict)}
+        self._datasets = {}
+        for key, loader_cfg in dcfg.items():
+            loader = instantiate(loader_cfg, generator=torch.Generator().manual_seed(self._seed),
+                                 worker_init_fn=_seed_worker)
+            if hasattr(loader.dataset, "collate_fn"):
+                loader.collate_fn = loader.dataset.collate_fn
+            self._datasets[key] = loader
+        for m in self._metrics.values():
+            m.set_accelerator(acc)
+        train_ds = self._datasets["train"].dataset
+        if hasattr(train_ds, "seen_csr") and hasattr(self._model, "bind_seen_csr"):
+            indptr, indices = train_ds.seen_csr()
+            self._model.bind_seen_csr(indptr.to(acc.device), indices.to(acc.device))
+        self._neg_gen = torch.Generator(device=acc.device).manual_seed(self._seed)
+        num_items = cfg["num_items"]
+        if isinstance(self._adaptive_p, float):
+            # the refresh is driven by the GET_BATCH_COMPLETED(every=...) handler below, which
+            # runs BEFORE the sampling handler, as in the reference (exp.py:197-208)
+            self._sampler = AdaptiveSampler(self._model, num_items, self._adaptive_p,
+                                            self._neg_gen, every=10 ** 18)
+        else:
+            self._sampler = UniformSampler(num_items, self._neg_gen)
+        self.trainer = self._build_trainer()
+        if isinstance(self._adaptive_p, float):
+            self._sampler.update_stats()
+        self._state = self.trainer.run(self._datasets, max_iters=max_iters, epochs=cfg["epochs"])
+        if self._dir is not None:
+            self._dir.mkdir(parents=True, exist_ok=True)
+            (self._dir / "history.json").write_text(json.dumps(self.history, indent=1))
+        return self._state
+
+    def interrupt(self) -> None:
+        for engine in self.trainer.engines.values():
+            engine.interrupt()
+
+    def clean(self) -> None:
+        del self.trainer
+
+    # ---- wiring -----------------------------------------------------------------------------
+    def _build_trainer(self) -> Trainer:
+        cfg = self._config
+        trainer = Trainer(self._model, self._optimizer, self._accelerator,
+                          custom_engines=cfg.get("custom_engines", {}))
+        if isinstance(self._adaptive_p, float):
+            batch = self._datasets["train"].batch_size or 1
+            every = max(1, int(cfg["num_items"] * math.log(cfg["num_items"]) / batch))
+            trainer.add_event("train", Events.GET_BATCH_COMPLETED(every=every),
+                              lambda: self._sampler.update_stats())
+        trainer.add_event("train", Events.GET_BATCH_COMPLETED, self._train_batch)
+        trainer.add_event("eval", Events.GET_BATCH_COMPLETED, self._to_device)
+        if self._skip_seen:
+            trainer.add_event("eval", ModelEvents.FORWARD_COMPLETED, self._remove_seen_items)
+        if self._debug:
+            trainer.add_event("train", Events.ITERATION_COMPLETED(every=2000),
+                              lambda engine: engine.terminate_epoch())
+        trainer.add_event("eval", Events.EPOCH_STARTED, self._reset_eval_metrics)
+        trainer.add_event("eval", Events.ITERATION_COMPLETED, self._update_eval_metrics)
+        trainer.add_event("eval", Events.COMPLETED, self._log_eval)
+        trainer.add_event("train", Events.EPOCH_STARTED, self._reset_train_metrics)
+        trainer.add_event("train", Events.ITERATION_COMPLETED, self._update_train_metrics)
+        trainer.add_event("train", Events.EPOCH_COMPLETED, self._log_train)
+        for key, handlers in self._events.items():
+            for event, handler in handlers:
+                trainer.add_event(key, event, handler, accelerator=self._accelerator)
+        self._best, self._bad_evals = None, 0
+        return trainer
+
+    # ---- handlers ---------------------------------------------------------------------------
+    def _to_device(self, engine) -> None:
+        dev = self._accelerator.device
+        engine.state.batch = {k: (v.to(dev) if torch.is_tensor(v) else v)
+                              for k, v in engine.state.batch.items()}
+
+    @torch.no_grad()
+    def _train_batch(self, engine) -> None:
+        self._to_device(engine)
+        batch = engine.state.batch
+        if batch["item"].dim() < 2:
+            batch["item"] = batch["item"].unsqueeze(-1)
+        batch["neg"] = self._sampler.sample(batch)
+
+    def _remove_seen_items(self, engine) -> None:
+        batch, output = engine.state.batch, engine.state.output
+        seen = batch.get("seen_items")
+        if seen is not None:
+            output["logits"].scatter_(dim=-1, index=seen, value=-1e13)
+            output["logits"][:, 0] = -1e13
+
+    def _reset_eval_metrics(self, engine) -> None:
+        for m in self._metrics.values():
+            m.reset()
+
+    def _update_eval_metrics(self, engine) -> None:
+        batch, output = engine.state.batch, engine.state.output
+        if "target" not in batch:
+            return
+        for name, m in self._metrics.items():
+            if "mask" in batch and hasattr(m, "compute") and m.__class__.__name__.startswith("RocAuc"):
+                m(output["logits"], batch["target"], batch["mask"])
+            else:
+                m(output["logits"], batch["target"])
+            engine.state.metrics[name] = m.get_metric()
+
+    def _reset_train_metrics(self, engine) -> None:
+        for key in ("bpr_loss", "l2_reg", "logits_diff"):
+            engine.state.metrics[f"_{key}"] = torch.tensor(0.0, device=self._accelerator.device)
+
+    @torch.no_grad()
+    def _update_train_metrics(self, engine) -> None:
+        st, out = engine.state, engine.state.output
+        for key in ("bpr_loss", "l2_reg"):
+            st.metrics[f"_{key}"] += out[key]
+            st.metrics[key] = st.metrics[f"_{key}"] / st.epoch_iteration
+        st.metrics["_logits_diff"] += out["logits"].abs().mean()
+        st.metrics["logits_diff"] = st.metrics["_logits_diff"] / st.epoch_iteration
+
+    @staticmethod
+    def _public(metrics: dict) -> dict:
+        return {k: (float(v) if torch.is_tensor(v) else v) for k, v in metrics.items()
+                if not k.startswith("_")}
+
+    def _log_train(self, engine) -> None:
+        row = {"engine": "train", "epoch": engine.state.epoch, **self._public(engine.state.metrics)}
+        self.history.append(row)
+        log.info("train epoch %d | %s", engine.state.epoch,
+                 " ".join(f"{k}={v:.4f}" for k, v in row.items() if isinstance(v, float)))
+
+    def _log_eval(self, engine) -> None:
+        train_epoch = self.trainer.engines["train"].state.epoch
+        row = {"engine": "eval", "epoch": train_epoch, **self._public(engine.state.metrics)}
+        self.history.append(row)
+        log.info("eval before epoch %d | %s", train_epoch,
+                 " ".join(f"{k}={v:.4f}" for k, v in row.items() if isinstance(v, float)))
+        name, patience, direction = self._early
+        if name is None or name not in row:
+            return
+        value = row[name] if direction == "max" else -row[name]
+        if self._best is None or value > self._best:
+            self._best, self._bad_evals = value, 0
+        else:
+            self._bad_evals += 1
+            if self._bad_evals >= patience:
+                log.info("early stopping on %s", name)
+                self.trainer.engines["train"].terminate()

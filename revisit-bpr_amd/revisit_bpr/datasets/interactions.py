@@ -80,4 +80,5 @@ def write_dataset(data: Interactions, path) -> None:
     with (path / TEST).open("w") as fh:
         for k, u in enumerate(data.eval_users):
             row = data.eval_items[data.eval_indptr[k]:data.eval_indptr[k + 1]]
-            fh.write(json.dumps({"user": int(u), "item": [int(x) for x in row]}) + "\n")
+            if len(row):  # the reference's test files list only users with held-out items
+                fh.write(json.dumps({"user": int(u), "item": [int(x) for x in row]}) + "\n")

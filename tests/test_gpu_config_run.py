@@ -1,0 +1,36 @@
+"""`python -m experiments.run CONFIG --extra-vars ...` on a config in the reference's schema:
+jinja2 → YAML → instantiate → BPRExperiment → Trainer → HIP engine."""
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+CONFIG = Path(__file__).parent / "configs" / "bpr_small.yaml.j2"
+
+
+@pytest.mark.parametrize("variant", ["uniform-sgd-bias", "adaptive-adam"])
+def test_config_run_learns(tmp_path, variant):
+    from click.testing import CliRunner
+
+    from experiments import run as run_mod
+    from revisit_bpr.datasets import interactions, synthetic
+
+    data = synthetic.generate_latent(900, 320, 24000, seed=6)
+    interactions.write_dataset(data, tmp_path / "data")
+    extra = (f"dataset={tmp_path / 'data'};num_users={data.num_users - 1};num_items={data.num_items - 1};"
+             "embedding_dim=32;train_batch_size=256;epochs=4")
+    if variant == "adaptive-adam":
+        extra += ";adaptive=1;optimizer=torch.optim.Adam;lr=0.01;item_bias=false"
+    res = CliRunner().invoke(run_mod.main, [str(CONFIG), "--extra-vars", extra, "-d", str(tmp_path / "exp")],
+                             catch_exceptions=False, standalone_mode=False)
+    assert res.exit_code == 0
+    exp = res.return_value
+    evals = [r for r in exp.history if r["engine"] == "eval"]
+    trains = [r for r in exp.history if r["engine"] == "train"]
+    assert len(evals) == 5 and len(trains) == 4  # eval before every epoch + once at the end
+    assert evals[-1]["ndcg@100"] > evals[0]["ndcg@100"] + 0.05
+    assert 0.5 < evals[-1]["auc"] <= 1.0
+    assert trains[-1]["bpr_loss"] < trains[0]["bpr_loss"]
+    assert (tmp_path / "exp" / "history.json").exists()
