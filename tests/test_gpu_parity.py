@@ -586,3 +586,39 @@ def test_atomics_lose_nothing_under_chip_wide_contention():
     dQ = e2.Q.cpu().numpy().astype(np.float64) / -lr
     s0 = np.abs(gQ0).max()
     assert s0 > 3 and np.abs(dQ - gQ0).max() < 0.005 * s0, np.abs(dQ - gQ0).max() / s0
+
+
+@pytest.mark.parametrize("I,d", [(20109, 128), (5001, 32), (12937, 64), (20480, 8), (300, 16)])
+def test_refresh_follows_a_moving_table(I, d):
+    """Refresh over a sequence of table states:
+    small drifts, a large jump, an all-equal table (order = item ids),
+    and back — every snapshot must equal the oracle's stable descending order exactly."""
+    rng = np.random.default_rng(I * 31 + d)
+    Q = (rng.standard_normal((I, d)) * 0.05).astype(np.float32)
+    Q[0] = 0
+    P = np.zeros((4, d), np.float32)
+    e = make_engine(P, Q)
+
+    def check():
+        e.adaptive_refresh()
+        order, sigma = e.adaptive_snapshot()
+        Qh = e.Q.cpu().numpy()
+        QT, sigma_o = oracle.adaptive_stats(Qh)
+        assert np.array_equal(order.cpu().numpy(), oracle.adaptive_order(QT))
+        if np.all(sigma_o > 0):
+            assert close(sigma.cpu().numpy(), sigma_o, 2e-6)
+
+    check()  # first refresh: linear splitters
+    for step in range(3):  # small drift, ties included
+        e.Q.add_(torch.randn(I, d, device="cuda") * 0.002)
+        e.Q[7] = e.Q[5]
+        e.Q[0] = 0
+        check()
+    e.Q.mul_(-3.0)  # every order reversed
+    check()
+    e.Q.add_(torch.randn(I, d, device="cuda") * 0.5)  # distribution shift
+    check()
+    e.Q.zero_()  # all keys equal → one bucket → radix fallback → ids ascending
+    check()
+    e.Q.copy_(torch.from_numpy(Q).cuda())
+    check()
