@@ -6,6 +6,9 @@ or, with --mode strict, through the reference's batch loop (sampler â†’ model â†
 
     python example.py /data/ml-20m --embedding-dim 1024 --epochs 72
     python example.py --synthetic ml-20m --embedding-dim 128 --epochs 2      # no files needed
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 example.py ...
+        # one rank per GPU: users sharded by interaction count, item table replicated and
+        # reconciled by an asynchronous all-reduce of item deltas (revisit_bpr/distributed.py)
 """
 from __future__ import annotations
 
@@ -78,7 +81,20 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
     logging.basicConfig(level=logging.INFO, format="%(asctime)s | %(message)s")
     if not torch.cuda.is_available():
         raise SystemExit("example.py needs an MI355X (no CPU path)")
-    dev = torch.device("cuda")
+    import os
+
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("BPR_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        if mode != "stream":
+            raise SystemExit("multi-GPU training uses --mode stream")
     if synthetic_name:
         data = synthetic.generate_named(synthetic_name, eval_users=10_000, seed=seed)
         num_users, num_items = data.num_users, data.num_items
@@ -98,9 +114,18 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
     metrics = build_metrics()
     every = int(num_items * math.log(num_items) / batch_size)
     if mode == "stream":
-        trainer = StreamTrainer(model, t["users"], t["items"], t["indptr"], t["indices"], lr=lr,
+        users_t, items_t, sync = t["users"], t["items"], None
+        if world > 1:  # this rank trains the triples of its own user range only
+            from revisit_bpr.distributed import ItemSync, balanced_user_shards, owner_of
+
+            bounds = balanced_user_shards(data.indptr, world)
+            mine = torch.from_numpy(owner_of(data.users, bounds) == rank).to(dev)
+            users_t, items_t = users_t[mine].contiguous(), items_t[mine].contiguous()
+            f = model.logits_model.get_features()
+            sync = ItemSync([f["item"].data] + ([f["item_bias"].data] if f["item_bias"] is not None else []))
+        trainer = StreamTrainer(model, users_t, items_t, t["indptr"], t["indices"], lr=lr,
                                 sampler="adaptive", adaptive_p=sampling_prob,
-                                batch_size=batch_size, seed=seed)
+                                batch_size=batch_size, seed=seed, rank=rank, item_sync=sync)
         run_epoch = trainer.train_epoch
     else:
         model.bind_seen_csr(t["indptr"], t["indices"])
@@ -123,7 +148,13 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
         log.info("epoch %d | %s | %.2fs (%.1f M triples/s)", epoch + 1,
                  " ".join(f"{k}={v:.4f}" for k, v in stats.items() if isinstance(v, float)), dt,
                  data.nnz / dt / 1e6)
-        if t["eval_users"].numel():
+        if world > 1:  # user rows live on their owner: gather them on every rank for the eval
+            P = model.logits_model.get_features()["user"].data
+            for r in range(world):
+                lo_r, hi_r = int(bounds[r]), int(bounds[r + 1])
+                if hi_r > lo_r:
+                    dist.broadcast(P[lo_r:hi_r], src=r)
+        if t["eval_users"].numel() and rank == 0:
             model.eval()
             f = model.logits_model.get_features()
             res = evaluate(f["user"].detach(), f["item"].detach(), f["item_bias"], t["eval_users"],
@@ -132,6 +163,9 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
             for name in sorted(res, key=lambda x: (len(x), x)):
                 log.info("%-14s | %.4f", name, res[name])
         log.info("Finished epoch: %d", epoch + 1)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 
