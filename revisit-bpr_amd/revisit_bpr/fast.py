@@ -20,7 +20,7 @@ class StreamTrainer:
                  seen_indices: torch.Tensor, lr: float, sampler: str = "adaptive",
                  adaptive_p: float = 0.01, batch_size: int = 256, seed: int = 13,
                  max_inflight: Optional[int] = None, run_len: int = 8, rank: int = 0,
-                 item_sync=None, sync_every: int = 1) -> None:
+                 item_sync=None, sync_every: int = 1, world: Optional[int] = None) -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
         adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302."""
@@ -37,7 +37,12 @@ class StreamTrainer:
         self.adaptive_p = adaptive_p
         I = self.engine.I
         every = max(1, int(I * math.log(I) / batch_size))
-        self.chunk = min(every * batch_size, self.n)
+        # one refresh period = every*batch_size triples of the WHOLE job: with the users sharded
+        # over `world` ranks each rank advances 1/world of it per chunk, so the snapshot refresh
+        # and the item reconciliation keep their single-GPU cadence
+        if world is None:
+            world = item_sync.world if item_sync is not None else 1
+        self.chunk = max(1, min(every * batch_size // max(world, 1), self.n))
         U = self.engine.U
         # staleness budget: at most ~U/4 triples in flight against one parameter cut
         self.max_inflight = max(64, U // 4) if max_inflight is None else max_inflight

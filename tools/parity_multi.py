@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""N-rank STREAM training on the e2e parity set (tests/golden/e2e_data.npz) — user shards + ItemSync —
+to compare nDCG@100 / Recall@20 with the reference's single-process curves.  Launch with
+torch.distributed.run; rank 0 prints one JSON line per seed.  BPR_DIST_BACKEND=gloo lets several
+ranks share one GPU (functional/parity check of the protocol; RCCL needs a device per rank)."""
+import json
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "revisit-bpr_amd")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from revisit_bpr.distributed import ItemSync, balanced_user_shards, owner_of  # noqa: E402
+from revisit_bpr.evaluation import evaluate_topk  # noqa: E402
+from revisit_bpr.fast import StreamTrainer  # noqa: E402
+from revisit_bpr.models import BPR  # noqa: E402
+from revisit_bpr.models.bpr import MF  # noqa: E402
+
+
+def main():
+    kind = sys.argv[1] if len(sys.argv) > 1 else "uniform"
+    seeds = [int(s) for s in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2", "3"])]
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        backend = os.environ.get("BPR_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    ref = json.loads((ROOT / "tests/golden/e2e_reference.json").read_text())
+    cfg = ref["config"]
+    d = np.load(ROOT / "tests/golden/e2e_data.npz")
+    U, I = int(d["num_users"]), int(d["num_items"])
+    t = {k: torch.from_numpy(d[k]).to(dev) for k in ("users", "items", "indptr", "indices", "eval_users",
+                                                     "eval_indptr", "eval_items")}
+    bounds = balanced_user_shards(d["indptr"], world)
+    mine = torch.from_numpy(owner_of(d["users"], bounds) == rank).to(dev)
+    for seed in seeds:
+        torch.manual_seed(cfg["init_seed"])
+        model = BPR(fuse_forward=True, reg_alphas=cfg["reg"],
+                    logits_model=MF(torch.nn.Embedding(U, cfg["d"], padding_idx=0),
+                                    torch.nn.Embedding(I, cfg["d"], padding_idx=0))).to(dev)
+        f = model.logits_model.get_features()
+        sync = ItemSync([f["item"].data]) if world > 1 else None
+        tr = StreamTrainer(model, t["users"][mine].contiguous(), t["items"][mine].contiguous(),
+                           t["indptr"], t["indices"], lr=cfg["lr"], sampler=kind,
+                           adaptive_p=cfg["adaptive_p"], batch_size=cfg["B"], seed=seed, rank=rank,
+                           item_sync=sync)
+        curve = []
+        for _ in range(cfg["epochs"]):
+            tr.train_epoch()
+            if world > 1:
+                for r in range(world):
+                    lo, hi = int(bounds[r]), int(bounds[r + 1])
+                    if hi > lo:
+                        dist.broadcast(f["user"].data[lo:hi], src=r)
+            if rank == 0:
+                m = evaluate_topk(f["user"].data, f["item"].data, None, t["eval_users"], t["eval_indptr"],
+                                  t["eval_items"], t["indptr"], t["indices"], ks=(20, 100))
+                curve.append((m["ndcg@100"], m["recall@20"]))
+        if rank == 0:
+            print(json.dumps({"kind": kind, "seed": seed, "world": world,
+                              "ndcg@100": [c[0] for c in curve], "recall@20": [c[1] for c in curve]}),
+                  flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
