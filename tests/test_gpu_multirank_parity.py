@@ -1,0 +1,43 @@
+"""Row 8e parity: user-sharded training with the replicated item table reconciled by ItemSync,
+against the reference's SINGLE-process curves on the e2e parity set.  Two ranks share cuda:0 over
+gloo here (RCCL needs one device per rank; the protocol — shards, chunk = refresh period / world,
+asynchronous delta all-reduce — is identical).  Tolerance as in test_gpu_e2e_parity.py."""
+import json
+import math
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.mark.parametrize("kind", ["uniform", "adaptive"])
+def test_two_rank_training_matches_reference_curves(golden_dir, kind):
+    env = dict(os.environ, BPR_DIST_BACKEND="gloo")
+    port = {"uniform": "29631", "adaptive": "29632"}[kind]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "tools" / "parity_multi.py"),
+           kind, "1,2,3,4,5"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    runs = [json.loads(line) for line in res.stdout.splitlines() if line.startswith("{")]
+    assert len(runs) == 5 and all(r["world"] == 2 for r in runs)
+    ref = json.loads((golden_dir / "e2e_reference.json").read_text())
+    report, ok = [], True
+    for key in ("ndcg@100", "recall@20"):
+        for epoch in (-2, -1):
+            o = np.array([r[key][epoch] for r in runs])
+            rr = np.array([v[key][epoch] for k, v in ref["runs"].items() if k.startswith(kind)])
+            se = math.sqrt(o.var(ddof=1) / len(o) + rr.var(ddof=1) / len(rr))
+            tol = 0.002 + 2 * se
+            diff = o.mean() - rr.mean()
+            report.append(f"2 ranks {kind} {key} epoch {epoch}: ours {o.mean():.4f}±{o.std(ddof=1):.4f} "
+                          f"ref {rr.mean():.4f}±{rr.std(ddof=1):.4f} diff {diff:+.4f} tol {tol:.4f}")
+            ok &= abs(diff) <= tol
+    print("\n".join(report))
+    assert ok, "\n".join(report)
