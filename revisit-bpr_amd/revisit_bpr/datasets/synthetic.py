@@ -106,7 +106,7 @@ def generate_latent(users: int, items: int, actions: int, factors: int = 8, stre
                     eval_users: int = -1) -> Interactions:
     """Small sets with learnable structure (for nDCG parity runs): user u picks its n_u items
     without replacement with probability ∝ popularity_i · exp(strength · <z_u, y_i>) (Gumbel top-k),
-    z, y ~ N(0, I_factors / factors).  O(users × items) memory — not for the benchmark shapes."""
+    z, y ~ N(0, I_factors / factors).  O(users x items) time (blocked over users)."""
     rng = np.random.default_rng(seed)
     U, I = users + 1, items + 1
     mean = actions / users
@@ -116,10 +116,18 @@ def generate_latent(users: int, items: int, actions: int, factors: int = 8, stre
     logpop = -item_skew * np.log(rng.permutation(items) + 1.0 + item_shift)
     Z = rng.standard_normal((users, factors)) / np.sqrt(factors)
     Y = rng.standard_normal((items, factors)) / np.sqrt(factors)
-    score = logpop[None, :] + strength * factors * (Z @ Y.T) + rng.gumbel(size=(users, items))
-    order = np.argsort(-score, axis=1)
+    # Gumbel top-k per user, in blocks of users so that memory stays O(block x items)
     ku = np.repeat(np.arange(1, U, dtype=np.int64), n_u)
-    ki = np.concatenate([order[u, :n_u[u]] + 1 for u in range(users)]).astype(np.int64)
+    picks = []
+    block = max(1, min(users, (64 << 20) // max(items, 1)))
+    for lo in range(0, users, block):
+        hi = min(lo + block, users)
+        score = logpop[None, :] + strength * factors * (Z[lo:hi] @ Y.T) + rng.gumbel(size=(hi - lo, items))
+        kmax = int(n_u[lo:hi].max())
+        top = np.argpartition(-score, kmax - 1, axis=1)[:, :kmax]
+        top = np.take_along_axis(top, np.argsort(-np.take_along_axis(score, top, axis=1), axis=1), axis=1)
+        picks.extend(top[r, :n_u[lo + r]] + 1 for r in range(hi - lo))
+    ki = np.concatenate(picks).astype(np.int64)
     n_eval = users if eval_users < 0 else min(eval_users, users)
     ev = np.sort(rng.choice(np.arange(1, U), size=n_eval, replace=False))
     is_ev = np.zeros(U, bool)
