@@ -16,7 +16,7 @@
 
 namespace bpr {
 
-enum { MODE_FORWARD = 0, MODE_GRAD = 1, MODE_STREAM = 2 };
+enum { MODE_FORWARD = 0, MODE_GRAD = 1 };
 
 // occupancy request for k_stream (waves per SIMD). Measured on MI355X, ML-20M shape, adaptive: 4 → 0.325 ms, 5 → 0.305 ms, 6 → 0.444 ms, 8 → 0.544 ms per chunk (above 5 the allocator spills to scratch)
 #ifndef BPR_STREAM_WAVES_PER_EU
@@ -135,18 +135,11 @@ struct TripleArgs {
   int64_t I;
   int d;
   int pad_user, pad_item;
-  float au, ai, an, lr;
-  // sampling
-  const int64_t* indptr;
-  const int32_t* indices;
-  const int32_t* order;
-  const float* sigma;
-  float inv_log1mp;
-  uint64_t seed, offset;
-  // triple stream
+  float au, ai, an;
+  // the batch
   const int32_t* users;
   const int32_t* pos;
-  int32_t* neg;
+  const int32_t* neg;
   int64_t n;
   // outputs
   float* lpos;

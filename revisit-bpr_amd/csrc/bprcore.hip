@@ -107,9 +107,7 @@ static TripleArgs triple_args(const bpr_ctx* c) {
   a.P = c->P; a.Q = c->Q; a.bias = c->bias;
   a.I = c->I; a.d = c->d;
   a.pad_user = c->pad_user; a.pad_item = c->pad_item;
-  a.au = c->au; a.ai = c->ai; a.an = c->an; a.lr = c->opt.lr;
-  a.indptr = c->indptr; a.indices = c->indices;
-  a.order = c->order; a.sigma = c->sigma;
+  a.au = c->au; a.ai = c->ai; a.an = c->an;
   a.GP = c->GP; a.GQ = c->GQ; a.Gb = c->Gb;
   a.flagP = c->flagP; a.flagQ = c->flagQ;
   a.touched = c->touched; a.touched_cnt = c->touched_cnt;
@@ -491,7 +489,7 @@ int bpr_forward(bpr_ctx* c, const int32_t* users, const int32_t* pos, const int3
   if (int rc = check_triples(c, "bpr_forward", users, pos, B)) return rc;
   if (neg == nullptr && B > 0) return fail(BPR_ERR_INVALID, "bpr_forward: neg is NULL");
   TripleArgs a = triple_args(c);
-  a.users = users; a.pos = pos; a.neg = const_cast<int32_t*>(neg); a.n = B;
+  a.users = users; a.pos = pos; a.neg = neg; a.n = B;
   a.lpos = out_logits_pos; a.lneg = out_logits_neg; a.scalars = out_scalars;
   return launch_triples<MODE_FORWARD>(c, a, false);
 }
@@ -503,7 +501,7 @@ int bpr_forward_grad(bpr_ctx* c, const int32_t* users, const int32_t* pos, const
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (int rc = ensure_strict_scratch(c)) return rc;
   TripleArgs a = triple_args(c);
-  a.users = users; a.pos = pos; a.neg = const_cast<int32_t*>(neg); a.n = B;
+  a.users = users; a.pos = pos; a.neg = neg; a.n = B;
   a.lpos = out_logits_pos; a.lneg = out_logits_neg; a.scalars = out_scalars;
   c->pending += 3 * B;
   if (c->pending > c->U + c->I) c->pending = c->U + c->I;
