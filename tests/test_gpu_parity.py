@@ -532,7 +532,8 @@ def test_train_strict_epoch_driver(opt_name):
 
 @pytest.mark.parametrize("I,d,force_sub", [(45000, 16, 0), (80001, 8, 0), (20109, 128, 0),
                                            (36865, 300, 0), (150000, 8, 0), (5003, 24, 2),
-                                           (5003, 24, 4), (777, 40, 4)])
+                                           (5003, 24, 4), (777, 40, 4), (20109, 128, 2),
+                                           (24576, 16, 2), (24577, 16, 2)])
 def test_refresh_large_item_counts(I, d, force_sub, monkeypatch):
     """Refresh paths: in-LDS sort with 1, 2 or 4 workgroups per factor + merge (I <= 147k), and the
     device-wide rocPRIM sort beyond.  Exact order (ties by item id) and sigma vs the oracle."""
