@@ -161,8 +161,7 @@ class Model(torch.nn.Module):
     # ---- fused engine plumbing ------------------------------------------------------------
     def _fusable(self) -> bool:
         lm = self.logits_model
-        return (isinstance(lm, MF) and lm._user_bias is None
-                and lm._user_emb.weight.dtype == torch.float32)
+        return isinstance(lm, MF) and lm._user_emb.weight.dtype == torch.float32
 
     def engine(self):
         """The HIP engine bound to the current parameter storage (created on first use)."""
@@ -305,6 +304,12 @@ class Model(torch.nn.Module):
         if self._anchor is None or self._anchor.device != lp.device:
             self._anchor = torch.zeros((), device=lp.device, requires_grad=True)
         lp, ln = lp.view(shape), ln.view(shape)
+        ub = self.logits_model._user_bias
+        if ub is not None:
+            # a user bias shifts both logits equally: it cancels in x = pos - neg, so its gradient
+            # is exactly zero and only the reported logits carry it
+            shift = ub.detach()[user].reshape(user.shape + (1,) * (lp.dim() - user.dim()))
+            lp, ln = lp + shift, ln + shift
         out = {"logits_pos": lp, "logits_neg": ln, "logits": lp - ln,
                "bpr_loss": sc[0], "l2_reg": sc[1]}
         out["loss"] = _ArmUpdate.apply(self._anchor, sc[0] + sc[1], weakref.ref(self))

@@ -264,3 +264,36 @@ def test_evaluate_topk_equals_metric_classes():
     fast = evaluate_topk(*args, ks=ks, block=300)
     for name, v in slow.items():
         assert abs(fast[name] - v) < 2e-6, (name, fast[name], v)
+
+
+def test_user_bias_is_carried_but_never_updated():
+    """MF(user_bias=True): the bias cancels in pos - neg; the fused path reports it in the logits and
+    leaves it untouched, as dense autograd does (zero gradient)."""
+    from revisit_bpr.models import BPR
+    from revisit_bpr.models.bpr import MF, set_backend
+
+    U, I, d, B = 50, 40, 16, 32
+    data = batches(U, I, B, 2, seed=1)
+    outs = {}
+    for backend in ("hip", "torch"):
+        set_backend(backend)
+        try:
+            torch.manual_seed(3)
+            model = BPR(MF(torch.nn.Embedding(U, d, padding_idx=0), torch.nn.Embedding(I, d, padding_idx=0),
+                           item_bias=True, user_bias=True), reg_alphas={"all": 0.01}).cuda()
+            with torch.no_grad():
+                model.logits_model._user_bias.copy_(torch.linspace(-1, 1, U))
+            opt = torch.optim.SGD(model.parameters(), lr=0.1)
+            model.train()
+            for b in data:
+                out = model(b)
+                out["loss"].backward()
+                opt.step()
+                opt.zero_grad()
+            outs[backend] = (out["logits_pos"].detach().cpu(), model.logits_model._user_bias.detach().cpu(),
+                             model.logits_model._item_emb.weight.detach().cpu())
+        finally:
+            set_backend("hip")
+    assert torch.allclose(outs["hip"][0], outs["torch"][0], atol=1e-5)
+    assert torch.equal(outs["hip"][1], torch.linspace(-1, 1, U)) and torch.allclose(outs["hip"][1], outs["torch"][1])
+    assert torch.allclose(outs["hip"][2], outs["torch"][2], atol=1e-5)
