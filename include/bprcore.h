@@ -207,6 +207,19 @@ int bpr_flush_lazy(bpr_ctx* ctx);
 int bpr_get_step_host(bpr_ctx* ctx, int64_t* step_host);
 int bpr_set_step(bpr_ctx* ctx, int64_t step);
 
+/* ---- multi-GPU item-table reconciliation (no reference counterpart: the reference's DDP path is
+ * never enabled by a config, experiments/launcher.py:35-73).  The all-reduce itself is RCCL via
+ * torch.distributed; these two fused elementwise kernels bracket it (revisit_bpr/distributed.py).
+ * Context-free: arrays of n floats and the HIP stream to run on. */
+/* own[k] = tot[k] = q[k] - base[k]   (this rank's delta since the last reconciliation) */
+int bpr_item_delta(const float* q, const float* base, float* own, float* tot, int64_t n,
+                   void* hip_stream);
+/* tot = all-reduced sum of every rank's delta.  base += scale*tot (bit-identical on every rank);
+ * rebase == 0: q += scale*tot - own   (asynchronous: q keeps what it learned since bpr_item_delta)
+ * rebase == 1: q  = base              (blocking reconcile: every replica becomes the same cut) */
+int bpr_item_fold(float* q, float* base, const float* own, const float* tot, float scale,
+                  int32_t rebase, int64_t n, void* hip_stream);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 /* Average duration (ms) of the dominant kernel over the launches recorded since the last reset,
  * measured with hipEvents on the ctx stream (bench.py's roofline.achieved uses this).

@@ -727,4 +727,33 @@ __global__ __launch_bounds__(256) void k_flush_lazy(const ApplyArgs a, const int
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// item-table reconciliation (multi-GPU): the two elementwise passes around the RCCL all-reduce,
+// each ONE pass over the table (HBM bound: 12 B / 24 B moved per element)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_item_delta(const float* __restrict__ q,
+                                                    const float* __restrict__ base,
+                                                    float* __restrict__ own,
+                                                    float* __restrict__ tot, int64_t n) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const float dlt = q[k] - base[k];
+    own[k] = dlt;
+    tot[k] = dlt;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_item_fold(float* __restrict__ q, float* __restrict__ base,
+                                                   const float* __restrict__ own,
+                                                   const float* __restrict__ tot, float scale,
+                                                   int rebase, int64_t n) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const float st = scale * tot[k];
+    const float nb = base[k] + st;  // identical on every rank: the bases never drift apart
+    base[k] = nb;
+    q[k] = rebase ? nb : q[k] + (st - own[k]);
+  }
+}
+
 }  // namespace bpr

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <type_traits>
 
@@ -665,6 +666,30 @@ int bpr_train_strict(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
       if (int rc = bpr_adaptive_refresh(c)) return rc;
     }
   }
+  return BPR_OK;
+}
+
+int bpr_item_delta(const float* q, const float* base, float* own, float* tot, int64_t n,
+                   void* hip_stream) {
+  if (n < 0 || (n > 0 && (!q || !base || !own || !tot)))
+    return fail(BPR_ERR_INVALID, "bpr_item_delta: bad argument");
+  if (n == 0) return BPR_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 1023) / 1024, 4096);
+  hipLaunchKernelGGL(k_item_delta, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, q, base, own,
+                     tot, n);
+  BPR_HIP_CHECK(hipGetLastError());
+  return BPR_OK;
+}
+
+int bpr_item_fold(float* q, float* base, const float* own, const float* tot, float scale,
+                  int32_t rebase, int64_t n, void* hip_stream) {
+  if (n < 0 || (n > 0 && (!q || !base || !own || !tot)))
+    return fail(BPR_ERR_INVALID, "bpr_item_fold: bad argument");
+  if (n == 0) return BPR_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 1023) / 1024, 4096);
+  hipLaunchKernelGGL(k_item_fold, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, q, base, own,
+                     tot, scale, rebase, n);
+  BPR_HIP_CHECK(hipGetLastError());
   return BPR_OK;
 }
 

@@ -52,69 +52,98 @@ class _null:
 
 
 class ItemSync:
-    """Keeps the replicated tensors (item table, optional item bias) consistent across ranks."""
+    """Keeps the replicated tensors (item table, optional item bias) consistent across ranks.
+
+    On a ROCm device the two elementwise passes around the all-reduce are the fused kernels
+    ``bpr_item_delta`` / ``bpr_item_fold`` of libbprcore (one pass over the table each, buffers
+    allocated once); on CPU tensors (gloo tests) the same algebra runs as torch ops."""
 
     def __init__(self, tensors: list[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
                  scale: float = 1.0) -> None:
-        self.tensors = [t for t in tensors if t is not None]
+        self.tensors = [t.detach() for t in tensors if t is not None]
         self.group = group
         self.scale = scale  # 1.0: apply every rank's update; 1/world: DDP-style mean
-        self.base = [t.detach().clone() for t in self.tensors]
-        self._pending = None
-        self._side = torch.cuda.Stream() if self.tensors and self.tensors[0].is_cuda else None
+        self.base = [t.clone() for t in self.tensors]
+        self._own = [torch.empty_like(t) for t in self.tensors]
+        self._tot = [torch.empty_like(t) for t in self.tensors]
+        self._pending = False
+        self._cuda = bool(self.tensors) and self.tensors[0].is_cuda
+        self._side = torch.cuda.Stream() if self._cuda else None
+        self._lib = None
+        if self._cuda:
+            from revisit_bpr import native
+
+            self._lib, self._check = native.load(), native.check
+            for t in self.tensors:
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise ValueError("ItemSync needs contiguous float32 tensors")
 
     @property
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
-    def sync(self) -> None:
-        """Blocking reconcile: Q <- Q_base + scale * all_reduce(Q - Q_base)."""
-        if self._pending is not None:
-            self.finish()
-        for t, b in zip(self.tensors, self.base):
-            delta = t.detach() - b
-            if self.world > 1:
-                dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group)
-            if self.scale != 1.0:
-                delta.mul_(self.scale)
-            with torch.no_grad():
-                t.copy_(b + delta)
-                b.copy_(t)
+    # ---- the two elementwise passes ---------------------------------------------------------
+    def _delta(self, t, b, own, tot) -> None:
+        if self._lib is not None:
+            self._check(self._lib.bpr_item_delta(t.data_ptr(), b.data_ptr(), own.data_ptr(),
+                                                 tot.data_ptr(), t.numel(),
+                                                 torch.cuda.current_stream().cuda_stream))
+        else:
+            torch.sub(t, b, out=own)
+            tot.copy_(own)
 
+    def _fold(self, t, b, own, tot, rebase: bool) -> None:
+        if self._lib is not None:
+            self._check(self._lib.bpr_item_fold(t.data_ptr(), b.data_ptr(), own.data_ptr(),
+                                                tot.data_ptr(), self.scale, int(rebase), t.numel(),
+                                                torch.cuda.current_stream().cuda_stream))
+        else:
+            st = tot * self.scale
+            b.add_(st)  # identical on every rank: the bases never drift apart
+            if rebase:
+                t.copy_(b)
+            else:
+                t.add_(st - own)
+
+    def _all_reduce(self, tot) -> None:
+        if self.world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- API ----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sync(self) -> None:
+        """Blocking reconcile: Q <- Q_base + scale * all_reduce(Q - Q_base), bit-identical on every
+        rank."""
+        self.start()
+        self.finish(rebase=True)
+
+    @torch.no_grad()
     def start(self) -> None:
-        """Snapshot the replicas and launch the all-reduce of their deltas on the side stream."""
-        if self._pending is not None:
+        """Cut this rank's deltas on the compute stream (a consistent snapshot) and launch their
+        all-reduce on the side stream."""
+        if self._pending:
             self.finish()
-        snaps, deltas = [], []
-        for t, b in zip(self.tensors, self.base):
-            s = t.detach().clone()  # on the compute stream: a consistent cut of this rank's replica
-            snaps.append(s)
+        for t, b, own, tot in zip(self.tensors, self.base, self._own, self._tot):
+            self._delta(t, b, own, tot)
         if self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream())
-        ctx = torch.cuda.stream(self._side) if self._side is not None else _null()
-        with ctx:
-            for s, b in zip(snaps, self.base):
-                own = s - b
-                tot = own.clone()
-                if self.world > 1:
-                    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
-                deltas.append((own, tot))
-        self._pending = (snaps, deltas)
+            with torch.cuda.stream(self._side):
+                for tot in self._tot:
+                    self._all_reduce(tot)
+        else:
+            for tot in self._tot:
+                self._all_reduce(tot)
+        self._pending = True
 
-    def finish(self) -> None:
-        """Fold the other ranks' contributions into the live replicas (one period late)."""
-        if self._pending is None:
+    @torch.no_grad()
+    def finish(self, rebase: bool = False) -> None:
+        """Fold the other ranks' contributions into the live replicas (one period late): the
+        replica keeps what it learned since start(); the base becomes the reconciled cut.
+        rebase=True (only valid when nothing trained since start()) sets replica = base."""
+        if not self._pending:
             return
-        snaps, deltas = self._pending
-        self._pending = None
+        self._pending = False
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
-        with torch.no_grad():
-            for t, b, s, (own, tot) in zip(self.tensors, self.base, snaps, deltas):
-                if self.scale != 1.0:
-                    # scaled total replaces this rank's own (unscaled) contribution as well
-                    others = tot * self.scale - own
-                else:
-                    others = tot - own
-                t.add_(others)          # live replica keeps what it learned since the snapshot
-                b.copy_(s + others)     # new base = the reconciled cut
+        for t, b, own, tot in zip(self.tensors, self.base, self._own, self._tot):
+            self._fold(t, b, own, tot, rebase)

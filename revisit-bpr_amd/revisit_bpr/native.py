@@ -76,6 +76,9 @@ SIGNATURES = {
                                  c_uint64, c_uint64, c_int64, c_void_p]),
     "bpr_train_strict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
                                  c_float, c_uint64, c_uint64, c_int64, c_void_p]),
+    "bpr_item_delta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "bpr_item_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int64,
+                              c_void_p]),
     "bpr_set_stream_opts": (c_int, [c_void_p, c_int32, c_int32]),
     "bpr_plan_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_void_p,
                                c_void_p]),
