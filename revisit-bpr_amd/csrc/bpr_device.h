@@ -124,6 +124,27 @@ struct SeenBitmap {  // one LDS read: the group's I-bit bitmap of the current us
   }
 };
 
+// the user's sorted seen list staged in LDS (k_stream, item tables too large for per-group
+// bitmaps): ≈ log2(n_u) LDS reads; users with more than the staged capacity use the CSR in HBM
+struct SeenList {
+  const int32_t* lst;
+  int32_t n;  // < 0: not staged, search the CSR slice
+  const int32_t* __restrict__ indices;
+  int64_t lo, hi;
+  __device__ __forceinline__ bool operator()(int32_t c) const {
+    if (n < 0) return csr_contains(indices, lo, hi, c);
+    int32_t b = 0, len = n;
+    while (len > 0) {
+      const int32_t half = len >> 1;
+      const bool right = lst[b + half] < c;
+      b = right ? b + half + 1 : b;
+      len = right ? len - half - 1 : half;
+    }
+    return b < n && lst[b] == c;
+  }
+};
+enum { SEEN_CSR = 0, SEEN_BITMAP = 1, SEEN_LIST = 2 };
+
 // ---------------------------------------------------------------------------------------------
 // Uniform negative: UniformSampler.sample (reference revisit_bpr/modules/neg_samplers.py:31-37),
 // i.e. uniform over items ∉ seen(u) ∪ {0}.  Candidate k of triple t is

@@ -249,7 +249,7 @@ struct StreamArgs {
   float au, ai, an, lr, inv_log1mp;
 };
 
-template <int G, int E, int SAMPLER, bool BM>
+template <int G, int E, int SAMPLER, int SEEN>
 __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const StreamArgs a) {
   constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -262,12 +262,15 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
   const int n_runs = (a.n + L - 1) / L;
   const bool stats = a.partials != nullptr;
   float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
-  // per-group seen-items bitmap of the current user in LDS (I bits): one ds_read answers "seen?"
+  // per-group LDS scratch of W words: the seen-items bitmap of the current user (I bits, one
+  // ds_read answers "seen?") or, for large item tables, the user's sorted seen list
+  constexpr bool BM = SEEN == SEEN_BITMAP;
   const int W = a.bm_words;
   uint32_t* bm = bpr_smem + (threadIdx.x / G) * W;
   if constexpr (BM) {
     for (int k = gl; k < W; k += G) bm[k] = 0u;
   }
+  int32_t list_n = -1;
   int64_t cur_lo = 0, cur_hi = 0;  // CSR slice of the current user
   float sg[E];                     // snapshot sigma of this lane's factors (adaptive only)
   if constexpr (SAMPLER == NEG_ADAPTIVE) {
@@ -346,6 +349,13 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
               atomicOr(&bm[it >> 5], 1u << (it & 31));
             }
           }
+          if constexpr (SEEN == SEEN_LIST) {
+            const int64_t cnt = cur_hi - cur_lo;
+            list_n = cnt <= (int64_t)W ? (int32_t)cnt : -1;
+            if (list_n > 0) {
+              for (int32_t k = gl; k < list_n; k += G) bm[k] = (uint32_t)a.indices[cur_lo + k];
+            }
+          }
         }
         cur_u = u;
         cur_starts_inside = (step > 0) || (t == 0) || (prev_u != u);
@@ -355,10 +365,14 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
       if constexpr (SAMPLER == NEG_GIVEN) {
         j = a.neg[tt];
       } else {
-        using Seen = typename std::conditional<BM, SeenBitmap, SeenCsr>::type;
+        using Seen = typename std::conditional<
+            BM, SeenBitmap,
+            typename std::conditional<SEEN == SEEN_LIST, SeenList, SeenCsr>::type>::type;
         Seen seen;
         if constexpr (BM) {
           seen = SeenBitmap{bm};
+        } else if constexpr (SEEN == SEEN_LIST) {
+          seen = SeenList{reinterpret_cast<const int32_t*>(bm), list_n, a.indices, cur_lo, cur_hi};
         } else {
           seen = SeenCsr{a.indices, cur_lo, cur_hi};
         }

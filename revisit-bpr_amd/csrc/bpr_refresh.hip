@@ -163,52 +163,107 @@ __global__ __launch_bounds__(1024) void k_sort_sub(const float* __restrict__ T, 
 
 // Merge neighbouring sorted runs of length `run` (descending keys; on equal keys the left run —
 // lower item ids — goes first, which keeps the order identical to a stable full sort).
-// Merge path: every thread finds where its MERGE_PER_THREAD outputs start in the two runs by a
-// binary search along the cross diagonal, then merges serially.
+// Two-level merge path.  A workgroup owns MERGE_TILE consecutive outputs of one pair of runs: two
+// lanes find where the tile starts and ends in both runs (binary search along the cross diagonals,
+// in HBM), the block copies those two slices — at most MERGE_TILE elements together — into LDS with
+// coalesced loads, every thread then finds its own MERGE_PER_THREAD outputs by a second diagonal
+// search in LDS and merges serially out of LDS; results go back through LDS so the stores are
+// coalesced as well.  LDS indices are padded by one word per 16 so the threads' serial walks spread
+// over the banks.  HBM traffic: keys + ids read once, written once (ids only on the last level).
 constexpr int MERGE_PER_THREAD = 16;
+constexpr int MERGE_THREADS = 256;
+constexpr int MERGE_TILE = MERGE_THREADS * MERGE_PER_THREAD;
+__device__ __forceinline__ int merge_pad(int k) { return k + (k >> 4); }
 
-__global__ __launch_bounds__(256) void k_merge_runs(const float* __restrict__ keys_in,
-                                                    const int32_t* __restrict__ ids_in, int64_t I,
-                                                    int64_t run, float* __restrict__ keys_out,
-                                                    int32_t* __restrict__ ids_out, int last,
-                                                    float* __restrict__ sigma,
-                                                    const double* __restrict__ sig_acc) {
-  const int f = blockIdx.y;
-  const int64_t o0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * MERGE_PER_THREAD;
-  if (last && blockIdx.x == 0 && threadIdx.x == 0) {
-    const double a = sig_acc[2 * f], b = sig_acc[2 * f + 1], n = (double)(I - 1);
-    sigma[f] = (float)sqrt(fmax(b - a * a / n, 0.0) / (n - 1.0));
-  }
-  if (o0 >= I) return;
-  const float* K = keys_in + (int64_t)f * I;
-  const int32_t* V = ids_in + (int64_t)f * I;
-  const int64_t pair = o0 / (2 * run);
-  const int64_t a0 = pair * 2 * run;
-  const int64_t lenA = min(run, I - a0);
-  const int64_t b0 = a0 + lenA;
-  const int64_t lenB = max((int64_t)0, min(run, I - b0));
-  const int64_t k = o0 - a0;  // outputs of this pair that precede mine
+// number of elements the first `k` merged outputs take from run A (lenA) — B (lenB) gets k - that
+template <typename KeyA, typename KeyB>
+__device__ __forceinline__ int64_t merge_split(int64_t k, int64_t lenA, int64_t lenB,
+                                               const KeyA& A, const KeyB& B) {
   int64_t lo = max((int64_t)0, k - lenB), hi = min(k, lenA);
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
-    if (K[a0 + mid] >= K[b0 + (k - mid - 1)]) lo = mid + 1; else hi = mid;
+    if (A(mid) >= B(k - mid - 1)) lo = mid + 1; else hi = mid;
   }
-  int64_t a = lo, b = k - lo;
-  const int64_t n_out = min((int64_t)MERGE_PER_THREAD, (a0 + lenA + lenB) - o0);
-  float ka = a < lenA ? K[a0 + a] : 0.f, kb = b < lenB ? K[b0 + b] : 0.f;
-  for (int64_t q = 0; q < n_out; ++q) {
-    const bool take_a = (a < lenA) && (b >= lenB || ka >= kb);
-    const int64_t src = take_a ? a0 + a : b0 + b;
-    const int64_t o = (int64_t)f * I + o0 + q;
-    ids_out[o] = V[src];
-    if (!last) keys_out[o] = take_a ? ka : kb;
-    if (take_a) {
-      ++a;
-      ka = a < lenA ? K[a0 + a] : 0.f;
-    } else {
-      ++b;
-      kb = b < lenB ? K[b0 + b] : 0.f;
+  return lo;
+}
+
+__global__ __launch_bounds__(MERGE_THREADS) void k_merge_runs(
+    const float* __restrict__ keys_in, const int32_t* __restrict__ ids_in, int64_t I, int64_t run,
+    int tiles_per_pair, float* __restrict__ keys_out, int32_t* __restrict__ ids_out, int last,
+    float* __restrict__ sigma, const double* __restrict__ sig_acc) {
+  __shared__ float lk[MERGE_TILE + MERGE_TILE / 16 + 1];
+  __shared__ int32_t lv[MERGE_TILE + MERGE_TILE / 16 + 1];
+  __shared__ int64_t cut[2];
+  const int f = blockIdx.y;
+  const int t = threadIdx.x;
+  if (last && blockIdx.x == 0 && t == 0) {
+    const double a = sig_acc[2 * f], b = sig_acc[2 * f + 1], n = (double)(I - 1);
+    sigma[f] = (float)sqrt(fmax(b - a * a / n, 0.0) / (n - 1.0));
+  }
+  const int64_t pair = blockIdx.x / tiles_per_pair;
+  const int64_t tile = blockIdx.x % tiles_per_pair;
+  const int64_t a0 = pair * 2 * run;
+  if (a0 >= I) return;
+  const int64_t lenA = min(run, I - a0);
+  const int64_t b0 = a0 + lenA;
+  const int64_t lenB = max((int64_t)0, min(run, I - b0));
+  const int64_t k0 = tile * MERGE_TILE;
+  if (k0 >= lenA + lenB) return;
+  const int64_t k1 = min(k0 + MERGE_TILE, lenA + lenB);
+  const float* K = keys_in + (int64_t)f * I;
+  const int32_t* V = ids_in + (int64_t)f * I;
+  if (t == 0 || t == 64) {
+    const int64_t k = t == 0 ? k0 : k1;
+    cut[t >> 6] = merge_split(k, lenA, lenB, [&](int64_t x) { return K[a0 + x]; },
+                              [&](int64_t x) { return K[b0 + x]; });
+  }
+  __syncthreads();
+  const int64_t a_lo = cut[0], a_hi = cut[1];
+  const int64_t b_lo = k0 - a_lo, b_hi = k1 - a_hi;
+  const int nA = (int)(a_hi - a_lo), nB = (int)(b_hi - b_lo);
+  for (int x = t; x < nA + nB; x += MERGE_THREADS) {
+    const int64_t src = x < nA ? a0 + a_lo + x : b0 + b_lo + (x - nA);
+    lk[merge_pad(x)] = K[src];
+    lv[merge_pad(x)] = V[src];
+  }
+  __syncthreads();
+  const int n_tile = (int)(k1 - k0);
+  const int kk = min(t * MERGE_PER_THREAD, n_tile);
+  const int n_out = min(MERGE_PER_THREAD, n_tile - kk);
+  int a = (int)merge_split(kk, nA, nB, [&](int64_t x) { return lk[merge_pad((int)x)]; },
+                           [&](int64_t x) { return lk[merge_pad(nA + (int)x)]; });
+  int b = kk - a;
+  float ok[MERGE_PER_THREAD];
+  int32_t ov[MERGE_PER_THREAD];
+  float ka = a < nA ? lk[merge_pad(a)] : 0.f, kb = b < nB ? lk[merge_pad(nA + b)] : 0.f;
+#pragma unroll
+  for (int q = 0; q < MERGE_PER_THREAD; ++q) {
+    const bool take_a = (a < nA) && (b >= nB || ka >= kb);
+    if (q < n_out) {
+      ov[q] = lv[merge_pad(take_a ? a : nA + b)];
+      ok[q] = take_a ? ka : kb;
+      if (take_a) {
+        ++a;
+        ka = a < nA ? lk[merge_pad(a)] : 0.f;
+      } else {
+        ++b;
+        kb = b < nB ? lk[merge_pad(nA + b)] : 0.f;
+      }
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < MERGE_PER_THREAD; ++q) {
+    if (q < n_out) {
+      lk[merge_pad(kk + q)] = ok[q];
+      lv[merge_pad(kk + q)] = ov[q];
+    }
+  }
+  __syncthreads();
+  const int64_t o_base = (int64_t)f * I + a0 + k0;
+  for (int x = t; x < n_tile; x += MERGE_THREADS) {
+    ids_out[o_base + x] = lv[merge_pad(x)];
+    if (!last) keys_out[o_base + x] = lk[merge_pad(x)];
   }
 }
 
@@ -390,12 +445,14 @@ int refresh_impl(bpr_ctx* c) {
   static const bool no_fast = getenv("BPR_NO_FAST_REFRESH") != nullptr;
   const char* fs = getenv("BPR_REFRESH_SUB");  // tests force the split/merge paths on small tables
   const int force_sub = fs ? atoi(fs) : 0;
-  // one workgroup per factor when the column fits the in-LDS sort (<= 36 keys per thread) — measured
-  // faster than splitting (ML-20M: 0.090 ms vs 0.106 ms with 2 workgroups + merge); larger item
-  // tables are split over 2 or 4 workgroups per factor and the sorted runs merged pairwise.
-  // Run lengths are multiples of MERGE_PER_THREAD so that a thread's outputs never straddle runs.
+  // One 1024-thread workgroup sorts a (sub-)column of <= 36 keys per thread in LDS.  Columns are
+  // split over 2 or 4 workgroups — sorted runs merged pairwise by k_merge_runs — when they do not
+  // fit, or when d workgroups would leave CUs idle and the pieces stay >= 5,000 keys (measured on
+  // ML-20M, refresh + launch gaps per step: d=128 0.106 -> 0.095 ms with 2, d=64 0.100 -> 0.079 ms
+  // with 4; d=256 and Netflix's 4.8 k-item columns are fastest unsplit).
   int sub = 1;
   while (sub < 4 && (I + sub - 1) / sub > 1024 * 36) sub *= 2;
+  while (sub < 4 && d * sub < 256 && I / (2 * sub) >= 5000) sub *= 2;
   if (force_sub == 1 || force_sub == 2 || force_sub == 4) sub = force_sub;
   int64_t len = (I + sub - 1) / sub;
   len = (len + MERGE_PER_THREAD - 1) / MERGE_PER_THREAD * MERGE_PER_THREAD;
@@ -411,12 +468,14 @@ int refresh_impl(bpr_ctx* c) {
     else if (items <= 20) launch_sort_sub<20>(c, sub, len, keysA, idsA);
     else if (items <= 28) launch_sort_sub<28>(c, sub, len, keysA, idsA);
     else launch_sort_sub<36>(c, sub, len, keysA, idsA);
-    const unsigned mgrid = (unsigned)((I + 256 * MERGE_PER_THREAD - 1) / (256 * MERGE_PER_THREAD));
     int64_t run = len;
     for (int level = sub; level > 1; level /= 2, run *= 2) {
       const int last = level == 2;
-      hipLaunchKernelGGL(k_merge_runs, dim3(mgrid, d), dim3(256), 0, c->stream, keysA, idsA, I, run,
-                         keysB, last ? c->order : idsB, last, c->sigma, c->sig_acc);
+      const int tiles_per_pair = (int)((2 * run + MERGE_TILE - 1) / MERGE_TILE);
+      const unsigned mgrid = (unsigned)(((I + 2 * run - 1) / (2 * run)) * tiles_per_pair);
+      hipLaunchKernelGGL(k_merge_runs, dim3(mgrid, d), dim3(MERGE_THREADS), 0, c->stream, keysA,
+                         idsA, I, run, tiles_per_pair, keysB, last ? c->order : idsB, last,
+                         c->sigma, c->sig_acc);
       std::swap(keysA, keysB);
       std::swap(idsA, idsB);
     }

@@ -230,19 +230,36 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     const int64_t n_runs = (a.n + a.run_len - 1) / a.run_len;
     unsigned block = 256;
     if (cap_groups > 0 && cap_groups * G < 256) block = (unsigned)(((cap_groups * G + 63) / 64) * 64);
-    // LDS seen-bitmap: I bits per group.  The block's bitmaps must fit 64 KiB (>= 2 blocks per CU);
-    // large item tables get smaller blocks (fewer groups per block) before falling back to the CSR.
+    // "seen?" answers (bpr_device.h): the LDS bitmap (I bits per group) while a full 256-thread
+    // block's bitmaps fit 64 KiB (>= 2 blocks per CU at full width: I <= 65,536 for d <= 128,
+    // 131,072 above); larger item tables stage the user's sorted seen list in LDS instead
+    // (LIST_CAP entries per group, heavier users search the CSR in HBM).  BPR_SEEN=csr|bitmap|list
+    // forces a structure (tests, measurements); a forced bitmap shrinks the block to fit.
     const int words = (int)((c->I + 31) / 32);
+    const char* force_env = getenv("BPR_SEEN");
     static const bool no_bm = getenv("BPR_NO_BITMAP") != nullptr;
-    bool bm = sampler != NEG_GIVEN && !no_bm;
-    if (bm) {
-      while (block > 64 && (size_t)(block / G) * words * sizeof(uint32_t) > 64 * 1024) block /= 2;
-      if ((size_t)(block / G) * words * sizeof(uint32_t) > 64 * 1024) {
-        bm = false;
-        block = 256;
+    const std::string force = force_env ? force_env : (no_bm ? "csr" : "");
+    constexpr int LIST_CAP = 512;
+    int seen = SEEN_CSR;
+    int lds_words = 0;
+    if (sampler != NEG_GIVEN && force != "csr") {
+      const bool bm_fits = (size_t)(block / G) * words * sizeof(uint32_t) <= 64 * 1024;
+      if (force == "list" || (force != "bitmap" && !bm_fits)) {
+        seen = SEEN_LIST;
+        lds_words = LIST_CAP;
+      } else {
+        while (block > 64 && (size_t)(block / G) * words * sizeof(uint32_t) > 64 * 1024) block /= 2;
+        if ((size_t)(block / G) * words * sizeof(uint32_t) <= 64 * 1024) {
+          seen = SEEN_BITMAP;
+          lds_words = words;
+        } else {
+          block = 256;
+          seen = SEEN_LIST;
+          lds_words = LIST_CAP;
+        }
       }
     }
-    const size_t lds = (size_t)(block / G) * (size_t)words * sizeof(uint32_t);
+    const size_t shmem = (size_t)(block / G) * (size_t)lds_words * sizeof(uint32_t);
     int64_t want = n_runs;
     if (cap_groups > 0 && want > cap_groups) want = cap_groups;
     const int64_t per_block = block / G;
@@ -250,26 +267,20 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     const int64_t max_blk = (int64_t)max_blocks() * (256 / block);
     if (nblk > max_blk) nblk = max_blk;
     const unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
-    a.bm_words = bm ? words : 0;
-    const size_t shmem = bm ? lds : 0;
+    a.bm_words = lds_words;
     {
       Timer tm(c, true);
       (void)tm;
-      if (sampler == NEG_GIVEN)
-        hipLaunchKernelGGL((k_stream<G, E, NEG_GIVEN, false>), dim3(grid), dim3(block), 0,
-                           c->stream, a);
-      else if (sampler == NEG_UNIFORM && bm)
-        hipLaunchKernelGGL((k_stream<G, E, NEG_UNIFORM, true>), dim3(grid), dim3(block), shmem,
-                           c->stream, a);
-      else if (sampler == NEG_UNIFORM)
-        hipLaunchKernelGGL((k_stream<G, E, NEG_UNIFORM, false>), dim3(grid), dim3(block), 0,
-                           c->stream, a);
-      else if (bm)
-        hipLaunchKernelGGL((k_stream<G, E, NEG_ADAPTIVE, true>), dim3(grid), dim3(block), shmem,
-                           c->stream, a);
-      else
-        hipLaunchKernelGGL((k_stream<G, E, NEG_ADAPTIVE, false>), dim3(grid), dim3(block), 0,
-                           c->stream, a);
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, c->stream, a);
+      };
+      if (sampler == NEG_GIVEN) go(k_stream<G, E, NEG_GIVEN, SEEN_CSR>);
+      else if (sampler == NEG_UNIFORM && seen == SEEN_BITMAP) go(k_stream<G, E, NEG_UNIFORM, SEEN_BITMAP>);
+      else if (sampler == NEG_UNIFORM && seen == SEEN_LIST) go(k_stream<G, E, NEG_UNIFORM, SEEN_LIST>);
+      else if (sampler == NEG_UNIFORM) go(k_stream<G, E, NEG_UNIFORM, SEEN_CSR>);
+      else if (seen == SEEN_BITMAP) go(k_stream<G, E, NEG_ADAPTIVE, SEEN_BITMAP>);
+      else if (seen == SEEN_LIST) go(k_stream<G, E, NEG_ADAPTIVE, SEEN_LIST>);
+      else go(k_stream<G, E, NEG_ADAPTIVE, SEEN_CSR>);
     }
     if (out_scalars != nullptr)
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, a.partials, (int)grid,

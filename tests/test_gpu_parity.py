@@ -312,12 +312,20 @@ def test_stream_unique_rows_equals_strict(d):
     assert close(sc.cpu().numpy()[:3], sco[:3], 2e-5)
 
 
+@pytest.mark.parametrize("seen", ["", "csr", "bitmap", "list", "list-overflow"])
 @pytest.mark.parametrize("sampler", [1, 2])
-def test_stream_sequential_limit_equals_b1_sgd(sampler):
+def test_stream_sequential_limit_equals_b1_sgd(sampler, seen, monkeypatch):
     """d=256 → one triple per wave; max_inflight=1 → one wave → exactly sequential SGD with the
-    on-device sampler, comparable step by step with the oracle's B=1 stream."""
+    on-device sampler, comparable step by step with the oracle's B=1 stream.  Every "seen?"
+    structure of the STREAM kernel (CSR in HBM, LDS bitmap, LDS sorted list, and the list's
+    fall-back for users with more seen items than it stages) must give the same picks."""
     d, U, I, n = 256, 60, 90, 400
-    P, Q, indptr, indices, users, pos, _ = rand_problem(U, I, d, 30, seed=5, B=n)
+    per_user = 30
+    if seen == "list-overflow":  # > 512 seen items per user: the staged list does not hold them
+        I, per_user, seen = 1500, 700, "list"
+    if seen:
+        monkeypatch.setenv("BPR_SEEN", seen)
+    P, Q, indptr, indices, users, pos, _ = rand_problem(U, I, d, per_user, seed=5, B=n)
     P *= 8
     Q *= 8
     reg = (0.01, 0.02, 0.03)
@@ -347,10 +355,14 @@ def test_stream_sequential_limit_equals_b1_sgd(sampler):
         assert close(sc.cpu().numpy()[:3], sco[:3], 1e-4)
 
 
-def test_stream_full_chip_learns_and_never_picks_seen():
+@pytest.mark.parametrize("seen", ["", "list", "csr"])
+def test_stream_full_chip_learns_and_never_picks_seen(seen, monkeypatch):
     """Full-concurrency STREAM on a small synthetic set: loss falls epoch over epoch, sampled
     negatives are valid, tables stay finite, pad rows stay zero."""
     from revisit_bpr.datasets import synthetic
+
+    if seen:
+        monkeypatch.setenv("BPR_SEEN", seen)
 
     data = synthetic.generate(2000, 1000, 60000, median_per_user=20, seed=3)
     d = 64
