@@ -282,6 +282,26 @@ def test_adaptive_sampler_matches_oracle(d):
                                               int(rnk[b]))
 
 
+@pytest.mark.parametrize("d", [32, 256])
+def test_samplers_with_heavy_users(d):
+    """Users holding up to 2,400 of 3,000 items (long CSR slices, few unseen items left): both
+    samplers must give the oracle's picks."""
+    U, I, B = 40, 3000, 3000
+    P, Q, indptr, indices, users, _, _ = rand_problem(U, I, d, 2400, seed=31 + d, B=B)
+    e = make_engine(P, Q)
+    e.bind_seen_csr(dev(indptr), dev(indices))
+    got = e.sample_uniform(dev(users), seed=99, offset=7).cpu().numpy()
+    assert np.array_equal(got, oracle.sample_uniform(indptr, indices, I, users, seed=99, offset=7))
+    e.adaptive_refresh()
+    neg, fac, rnk = (t.cpu().numpy() for t in
+                     e.sample_adaptive(dev(users), 0.02, seed=5, offset=1, return_draws=True))
+    QT, _ = oracle.adaptive_stats(Q)
+    order = oracle.adaptive_order(QT)
+    for b in range(0, B, 3):
+        assert neg[b] == oracle.adaptive_pick(order, indptr, indices, int(users[b]), int(fac[b]),
+                                              int(rnk[b]))
+
+
 # ------------------------------------------------------------------------------------------------
 # STREAM mode
 # ------------------------------------------------------------------------------------------------
