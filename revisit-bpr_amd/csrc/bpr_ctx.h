@@ -8,6 +8,8 @@
 
 #include "../../include/bprcore.h"
 
+constexpr int BPR_ORDER_PAD = 4;
+
 struct bpr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -36,7 +38,8 @@ struct bpr_ctx {
   int64_t step = 0;     // optimizer steps applied so far
   int64_t flushed_at = 0;
   // private scratch — adaptive sampler snapshot
-  int32_t* order = nullptr;  // [d, I]
+  int32_t* order = nullptr;  // [d, I], inside order_alloc with BPR_ORDER_PAD entries of slack on
+  int32_t* order_alloc = nullptr;  // both ends (the sampler's walk reads 16-byte vectors)
   float* sigma = nullptr;    // [d]
   float* keysT = nullptr;    // [d, I] transposed item table
   float* keys_sorted = nullptr;  // 2 x [d, I] uint64 composite sort keys (in | out)

@@ -49,35 +49,42 @@ enum : uint32_t { PURPOSE_UNIFORM = 0u, PURPOSE_ADAPTIVE = 1u };
 constexpr int UNIFORM_MAX_CAND = 4096;  // candidates tried before giving up (returns item 0)
 
 // ---------------------------------------------------------------------------------------------
-// group (sub-wave) collectives
+// group (sub-wave) collectives.  Sums and scans run on the VALU with DPP row operations
+// (v_add_f32 + row_shr / row_bcast modifiers: 5-6 full-rate instructions, no LDS round trips);
+// the kernels that use them are instruction-issue bound, and a ds_bpermute butterfly costs five
+// dependent LDS-pipe latencies per sum.
 // ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_zero(float v) {  // source lane's v, 0 where there is none
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL,
+                                                               ROW_MASK, 0xf, false));
+}
+// inclusive prefix sum over the lanes of a group (lane order)
 template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+__device__ __forceinline__ float group_scan_incl(float v) {
+  static_assert(G == 32 || G == 64, "groups are half or whole waves");
+  v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8   — scan inside each row of 16
+  v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 → rows 1, 3 add the total of rows 0, 2
+  if constexpr (G == 64) v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 → rows 2, 3 add row 1
   return v;
 }
+// the value lane G-1 of the caller's group holds
 template <int G>
-__device__ __forceinline__ int group_min(int v) {
-#pragma unroll
-  for (int off = G / 2; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
-}
-template <int G>
-__device__ __forceinline__ int group_max(int v) {
-#pragma unroll
-  for (int off = G / 2; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  return v;
-}
-// inclusive prefix sum over the lanes of a group
-template <int G>
-__device__ __forceinline__ float group_scan_incl(float v, int gl) {
-#pragma unroll
-  for (int off = 1; off < G; off <<= 1) {
-    const float t = __shfl_up(v, off, G);
-    if (gl >= off) v += t;
+__device__ __forceinline__ float group_last(float v, int lane) {
+  const int x = __builtin_bit_cast(int, v);
+  if constexpr (G == 64) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 63));
+  } else {
+    const int a = __builtin_amdgcn_readlane(x, 31), b = __builtin_amdgcn_readlane(x, 63);
+    return __builtin_bit_cast(float, (lane & 32) ? b : a);
   }
-  return v;
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v, int lane) {
+  return group_last<G>(group_scan_incl<G>(v), lane);
 }
 // ballot restricted to the caller's group, bit k = lane k of the group
 template <int G>
@@ -86,13 +93,57 @@ __device__ __forceinline__ uint64_t group_ballot(bool pred, int lane) {
   if constexpr (G == 64) {
     return full;
   } else {
-    return (full >> (lane & ~(G - 1))) & ((1ull << G) - 1ull);
+    static_assert(G == 32, "groups are half or whole waves");
+    return (lane & 32) ? (uint64_t)(uint32_t)(full >> 32) : (uint64_t)(uint32_t)full;
   }
 }
 // value held by lane `src` of the caller's group
 template <int G, typename T>
 __device__ __forceinline__ T group_bcast(T v, int src, int lane) {
   return __shfl(v, (lane & ~(G - 1)) + src, 64);
+}
+// Wave ballot as two scalar halves: the comparison mask itself, no per-lane work.  For G = 32 the
+// low half belongs to the first group of the wave, the high half to the second.
+struct Ballot {
+  uint32_t lo, hi;
+};
+__device__ __forceinline__ Ballot wave_ballot(bool pred) {
+  const uint64_t m = __builtin_amdgcn_ballot_w64(pred);
+  return {(uint32_t)m, (uint32_t)(m >> 32)};
+}
+// lowest lane (0..G-1) of the caller's group whose predicate is set, -1 if none
+template <int G>
+__device__ __forceinline__ int group_first(const Ballot& b, int lane) {
+  if constexpr (G == 64) {
+    return b.lo ? (int)__builtin_ctz(b.lo) : (b.hi ? 32 + (int)__builtin_ctz(b.hi) : -1);
+  } else {
+    const int a = b.lo ? (int)__builtin_ctz(b.lo) : -1, c = b.hi ? (int)__builtin_ctz(b.hi) : -1;
+    return (lane & 32) ? c : a;
+  }
+}
+// highest such lane, -1 if none
+template <int G>
+__device__ __forceinline__ int group_last_set(const Ballot& b, int lane) {
+  if constexpr (G == 64) {
+    return b.hi ? 63 - (int)__builtin_clz(b.hi) : (b.lo ? 31 - (int)__builtin_clz(b.lo) : -1);
+  } else {
+    const int a = b.lo ? 31 - (int)__builtin_clz(b.lo) : -1;
+    const int c = b.hi ? 31 - (int)__builtin_clz(b.hi) : -1;
+    return (lane & 32) ? c : a;
+  }
+}
+// v of the lowest lane of the caller's group whose predicate is set (v of the group's lane 0 if
+// none): two v_readlane with scalar lane numbers instead of a ds_bpermute
+template <int G>
+__device__ __forceinline__ int32_t group_pick(const Ballot& b, int32_t v, int lane) {
+  if constexpr (G == 64) {
+    const int src = b.lo ? (int)__builtin_ctz(b.lo) : (b.hi ? 32 + (int)__builtin_ctz(b.hi) : 0);
+    return __builtin_amdgcn_readlane(v, src);
+  } else {
+    const int32_t a = __builtin_amdgcn_readlane(v, b.lo ? (int)__builtin_ctz(b.lo) : 0);
+    const int32_t c = __builtin_amdgcn_readlane(v, b.hi ? 32 + (int)__builtin_ctz(b.hi) : 32);
+    return (lane & 32) ? c : a;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,10 +215,9 @@ __device__ __forceinline__ int32_t sample_uniform(const Seen& seen, int64_t I, u
     const uint32_t r = draw(seed, t, k >> 2, PURPOSE_UNIFORM, (int)(k & 3u));
     const int32_t c = 1 + (int32_t)__umulhi(r, (uint32_t)(I - 1));
     const bool ok = !seen(c);
-    const uint64_t m = group_ballot<G>(ok, lane);
-    const int first = m ? (__ffsll((unsigned long long)m) - 1) : 0;
-    const int32_t cand = group_bcast<G>(c, first, lane);
-    if (!done && m) {
+    const Ballot b = wave_ballot(ok);
+    const int32_t cand = group_pick<G>(b, c, lane);
+    if (!done && group_first<G>(b, lane) >= 0) {
       result = cand;
       done = true;
     }
@@ -197,54 +247,102 @@ struct AdaptiveDraw {
 #endif
 constexpr int WALK_UNROLL = BPR_WALK_UNROLL;
 
+struct __attribute__((packed, aligned(4))) OrderVec {  // 4 consecutive order entries, any dword
+  int32_t v[WALK_UNROLL];                               // alignment (columns start at f*I)
+};
+static_assert(WALK_UNROLL == 4, "the walk fetches one dwordx4 per lane and trip");
+
+// One trip covers 4*G consecutive entries of the walk with ONE 16-byte load per lane (lane gl
+// holds entries base + 4*gl + {0..3}; 512 contiguous bytes per group of 32).  `order` carries
+// ORDER_PAD entries of slack on both ends, so the last vector of the first / last column may
+// overhang; overhanging entries are masked to 0 (the pad item: never a candidate).
+constexpr int ORDER_PAD = WALK_UNROLL;  // == BPR_ORDER_PAD (bpr_ctx.h), checked in bprcore.hip
+
 template <int G, typename Seen>
-__device__ __forceinline__ int32_t adaptive_walk(const int32_t* __restrict__ order_f, int64_t I,
+__device__ __forceinline__ int32_t adaptive_walk(const int32_t* __restrict__ order_f, int64_t I64,
                                                  const Seen& seen, bool from_top, int32_t skip,
                                                  int lane) {
   const int gl = lane & (G - 1);
+  const int32_t I = (int32_t)I64;  // d*I < 2^31 (bpr_adaptive_refresh)
   int32_t result = 0;
   bool done = false;
-  for (int64_t base = 0; base < I; base += (int64_t)G * WALK_UNROLL) {
+  for (int32_t base = 0; base < I; base += G * WALK_UNROLL) {
+    // entry k of the walk is order_f[from_top ? k : I-1-k]; k0 = my first entry
+    const int32_t k0 = base + WALK_UNROLL * gl;
+    const int32_t kc = min(k0, I - 1);  // lanes wholly past the end re-read the last vector
+    const OrderVec vec = *reinterpret_cast<const OrderVec*>(
+        order_f + (from_top ? kc : I - WALK_UNROLL - kc));
     int32_t items[WALK_UNROLL];
+    bool is_seen[WALK_UNROLL], unseen[WALK_UNROLL];
 #pragma unroll
     for (int c = 0; c < WALK_UNROLL; ++c) {
-      const int64_t k = base + (int64_t)c * G + gl;
-      const int64_t tpos = from_top ? k : (I - 1 - k);
-      items[c] = (k < I) ? order_f[tpos] : 0;  // 0 = pad item = never a candidate
+      const int32_t v = from_top ? vec.v[c] : vec.v[WALK_UNROLL - 1 - c];
+      items[c] = (k0 + c < I) ? v : 0;
     }
 #pragma unroll
+    for (int c = 0; c < WALK_UNROLL; ++c) is_seen[c] = seen(items[c]);  // 4 lookups in flight
+    // unseen entries of the trip (run) and of lower lanes (lanes_below): scalar popcounts of the
+    // ballots and v_mbcnt, corrected for the group's position in the wave
+    uint32_t wave_below = 0u, cnt_lo = 0u, cnt_hi = 0u;
+#pragma unroll
     for (int c = 0; c < WALK_UNROLL; ++c) {
-      const int32_t item = items[c];
-      const bool unseen = item != 0 && !seen(item);
-      const uint64_t m = group_ballot<G>(unseen, lane);
-      const int cnt = __popcll((unsigned long long)m);
-      const int below = __popcll((unsigned long long)(m & ((1ull << gl) - 1ull)));
-      const bool mine = !done && unseen && (below == skip);
-      const uint64_t hit = group_ballot<G>(mine, lane);
-      const int src = hit ? (__ffsll((unsigned long long)hit) - 1) : 0;
-      const int32_t got = group_bcast<G>(item, src, lane);
-      if (!done) {
-        if (hit) {
-          result = got;
-          done = true;
-        } else {
-          skip -= cnt;
-        }
-      }
+      unseen[c] = (items[c] != 0) & !is_seen[c];
+      const Ballot b = wave_ballot(unseen[c]);
+      wave_below = __builtin_amdgcn_mbcnt_hi(b.hi, __builtin_amdgcn_mbcnt_lo(b.lo, wave_below));
+      cnt_lo += (uint32_t)__builtin_popcount(b.lo);
+      cnt_hi += (uint32_t)__builtin_popcount(b.hi);
     }
+    const bool second = G == 32 && (lane & 32) != 0;
+    const int32_t run = (int32_t)(G == 64 ? cnt_lo + cnt_hi : (second ? cnt_hi : cnt_lo));
+    const int32_t lanes_below = (int32_t)(wave_below - (second ? cnt_lo : 0u));
+    // unseen entries before mine in walk order = those of lower lanes + my own earlier ones
+    const bool here = !done && skip < run;
+    int32_t before = lanes_below, isel = 0;
+    bool mine = false;
+#pragma unroll
+    for (int c = 0; c < WALK_UNROLL; ++c) {
+      const bool hit_c = unseen[c] && before == skip;
+      isel = hit_c ? items[c] : isel;
+      mine |= hit_c;
+      before += unseen[c] ? 1 : 0;
+    }
+    const int32_t got = group_pick<G>(wave_ballot(here && mine), isel, lane);
+    result = here ? got : result;
+    skip = (done | here) ? skip : skip - run;
+    done |= here;
     if (__all(done)) break;
   }
   return result;
+}
+
+// The two draws of one adaptive negative that do not depend on the model: the uniform that picks
+// the factor, and r ~ Geometric(p) on {1,2,…} clamped to #unseen (neg_samplers.py:90-94).  One
+// Philox block per triple; k_stream evaluates it for all triples of a run at once (lane k = triple
+// t0+k), k_sample per triple.
+struct AdaptiveRandoms {
+  float uf;   // in [0, 1)
+  int32_t r;  // 1-based rank, <= n_unseen (0 when the user has nothing unseen)
+};
+__device__ __forceinline__ AdaptiveRandoms adaptive_randoms(uint64_t seed, uint64_t t,
+                                                            float inv_log1mp, int64_t n_unseen) {
+  const u32x4 rnd = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), 0u, PURPOSE_ADAPTIVE,
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+  AdaptiveRandoms o;
+  o.uf = (float)(rnd.x >> 8) * (1.0f / 16777216.0f);
+  const float ug = (float)((rnd.y >> 8) + 1u) * (1.0f / 16777216.0f);
+  const float rr = ceilf(logf(ug) * inv_log1mp);
+  int64_t r = rr < 1.0f ? 1 : (rr > 2.0e9f ? 2000000000ll : (int64_t)rr);
+  if (r > n_unseen) r = n_unseen;
+  o.r = (int32_t)r;
+  return o;
 }
 
 template <int G, int E, typename Seen>
 __device__ __forceinline__ AdaptiveDraw sample_adaptive(
     const float (&p)[E], int d, const float (&sigma)[E],
     const int32_t* __restrict__ order, int64_t I, const Seen& seen, int64_t n_seen,
-    float inv_log1mp, uint64_t seed, uint64_t t, int lane) {
+    const AdaptiveRandoms& rnd, int lane) {
   const int gl = lane & (G - 1);
-  const u32x4 rnd = philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), 0u, PURPOSE_ADAPTIVE,
-                                  (uint32_t)seed, (uint32_t)(seed >> 32));
   // ---- factor ~ Categorical(|p_uf|·σ_f)  (neg_samplers.py:84-88): inverse CDF in factor order
   // f = e*G + gl, i.e. chunk e after chunk e-1, lanes in order inside a chunk
   float w[E], incl[E], carry[E];
@@ -253,42 +351,38 @@ __device__ __forceinline__ AdaptiveDraw sample_adaptive(
   for (int e = 0; e < E; ++e) {
     const int f = e * G + gl;
     w[e] = (f < d) ? fabsf(p[e]) * sigma[e] : 0.f;
-    incl[e] = group_scan_incl<G>(w[e], gl);
+    incl[e] = group_scan_incl<G>(w[e]);
     carry[e] = total;
-    total += group_bcast<G>(incl[e], G - 1, lane);
+    total += group_last<G>(incl[e], lane);
   }
-  const float uf = (float)(rnd.x >> 8) * (1.0f / 16777216.0f);
-  const float thr = uf * total;
-  int fsel = 0x7fffffff, flast = -1;
+  const float thr = rnd.uf * total;
+  int fsel = -1;  // first factor with weight whose inclusive CDF exceeds thr
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const int f = e * G + gl;
-    if (w[e] > 0.f) {
-      flast = max(flast, f);
-      if (carry[e] + incl[e] > thr) fsel = min(fsel, f);
+    const int first = group_first<G>(wave_ballot(w[e] > 0.f && carry[e] + incl[e] > thr), lane);
+    if (fsel < 0 && first >= 0) fsel = e * G + first;
+  }
+  if (fsel < 0) {  // thr rounded up to the total: the last factor with weight (0 if there is none)
+    fsel = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int last = group_last_set<G>(wave_ballot(w[e] > 0.f), lane);
+      if (last >= 0) fsel = e * G + last;
     }
   }
-  fsel = group_min<G>(fsel);
-  flast = group_max<G>(flast);
-  if (fsel == 0x7fffffff) fsel = max(flast, 0);
   // ---- the user's factor value decides the orientation (:96-100)
-  float pv = 0.f;
+  float psel = p[0];
 #pragma unroll
-  for (int e = 0; e < E; ++e)
-    if (fsel == e * G + gl) pv = p[e];
-  pv = group_sum<G>(pv);
-  // ---- r ~ Geometric(p) on {1,2,…}, clamped to #unseen (:90-94)
-  const int64_t n_unseen = (I - 1) - n_seen;
-  const float ug = (float)((rnd.y >> 8) + 1u) * (1.0f / 16777216.0f);
-  const float rr = ceilf(logf(ug) * inv_log1mp);
-  int64_t r = rr < 1.0f ? 1 : (rr > 2.0e9f ? 2000000000ll : (int64_t)rr);
-  if (r > n_unseen) r = n_unseen;
+  for (int e = 1; e < E; ++e) psel = (fsel / G == e) ? p[e] : psel;
+  const float pv = group_bcast<G>(psel, fsel & (G - 1), lane);
+  const int32_t n_unseen = (int32_t)((I - 1) - n_seen);
+  const int32_t r = min(rnd.r, n_unseen);
   const bool from_top = pv > 0.f;
   AdaptiveDraw out;
   out.factor = fsel;
-  out.rank = (int32_t)(from_top ? r - 1 : n_unseen - r);
-  out.item = (n_unseen > 0) ? adaptive_walk<G>(order + (int64_t)fsel * I, I, seen, from_top,
-                                               (int32_t)(r - 1), lane)
+  out.rank = from_top ? r - 1 : n_unseen - r;
+  out.item = (n_unseen > 0) ? adaptive_walk<G>(order + (int64_t)fsel * I, I, seen, from_top, r - 1,
+                                               lane)
                             : 0;
   return out;
 }

@@ -300,6 +300,12 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
         }
       }
     }
+    // the model-independent draws of the run's triples, all at once (lane k = triple t0+k)
+    AdaptiveRandoms my_rnd = {0.f, 0};
+    if constexpr (SAMPLER == NEG_ADAPTIVE) {
+      my_rnd = adaptive_randoms(a.seed, a.offset + (uint64_t)(t0 + gl), a.inv_log1mp,
+                                (int64_t)(a.I - 1) - (my_hi - my_lo));
+    }
     const int32_t prev_u = (run_act && t0 > 0) ? group_bcast<G>(my_u, G - 1, lane) : -1;
     const int32_t next_u = (run_act && t1 < a.n) ? group_bcast<G>(my_u, t1 - t0, lane) : -1;
     int32_t cur_u = -1;
@@ -309,6 +315,8 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
 #pragma unroll
     for (int e = 0; e < E; ++e) pl[e] = dp[e] = 0.f;
 
+    float x_mine = 0.f;  // statistics: logit of step gl of this run
+    bool x_have = false;
     for (int step = 0; step < L; ++step) {
       const int t = t0 + step;
       const bool act = run_act && t < t1;
@@ -379,8 +387,9 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
         if constexpr (SAMPLER == NEG_UNIFORM) {
           j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane);
         } else {
-          j = sample_adaptive<G, E>(pl, d, sg, a.order, a.I, seen, cur_hi - cur_lo,
-                                    a.inv_log1mp, a.seed, a.offset + (uint64_t)tt, lane).item;
+          const AdaptiveRandoms rnd = {group_bcast<G>(my_rnd.uf, step, lane),
+                                       group_bcast<G>(my_rnd.r, step, lane)};
+          j = sample_adaptive<G, E>(pl, d, sg, a.order, a.I, seen, cur_hi - cur_lo, rnd, lane).item;
         }
         if (a.neg != nullptr && act && gl == 0) a.neg[t] = j;
       }
@@ -388,22 +397,19 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
       float qj[E];
       load_row<G, E>(qj, jrow, d, gl);
 
-      float xp = group_sum<G>(dot<E>(pl, qi));
-      float xn = group_sum<G>(dot<E>(pl, qj));
-      if (a.bias != nullptr) {
-        xp += a.bias[i];
-        xn += a.bias[j];
-      }
-      const float x = xp - xn;
-      if (stats) {
-        const float np2 = group_sum<G>(dot<E>(pl, pl));
-        const float ni2 = group_sum<G>(dot<E>(qi, qi));
-        const float nj2 = group_sum<G>(dot<E>(qj, qj));
-        if (act && gl == 0) {
-          s_loss += neg_logsigmoid(x);
-          s_reg += 0.5f * (a.ai * ni2 + a.an * nj2 + a.au * np2);
-          s_abs += fabsf(x);
-          s_cnt += 1.f;
+      // x_uij = <p_u, q_i - q_j> (+ bias difference): one group sum
+      float xl = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) xl = fmaf(pl[e], qi[e] - qj[e], xl);
+      float x = group_sum<G>(xl, lane);
+      if (a.bias != nullptr) x += a.bias[i] - a.bias[j];
+      if (stats && act) {
+        // the L2 term is accumulated per lane (its slice of the rows): no group sums; lane k keeps
+        // the logit of step k and the loss terms are evaluated once per run, lane-parallel
+        s_reg += 0.5f * (a.ai * dot<E>(qi, qi) + a.an * dot<E>(qj, qj) + a.au * dot<E>(pl, pl));
+        if (gl == step) {
+          x_mine = x;
+          x_have = true;
         }
       }
       // ---- SGD on the three rows (SURVEY §3.3 gradients), w = σ(−x); every gradient uses the
@@ -430,6 +436,11 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
           atomic_add_f32(a.bias + j, -lr * w);
         }
       }
+    }
+    if (stats && x_have) {
+      s_loss += neg_logsigmoid(x_mine);
+      s_abs += fabsf(x_mine);
+      s_cnt += 1.f;
     }
     // ---- end of run: flush the last user
     if (run_act && cur_u >= 0 && cur_u != a.pad_user) {
@@ -491,8 +502,8 @@ __global__ __launch_bounds__(256) void k_triples(const TripleArgs a) {
       }
     }
     // ---- MF.forward (model.py:131-145) and BPR logits (model.py:48-64)
-    const float xp = group_sum<G>(dot<E>(p, qi)) + bias_i;
-    const float xn = group_sum<G>(dot<E>(p, qj)) + bias_j;
+    const float xp = group_sum<G>(dot<E>(p, qi), lane) + bias_i;
+    const float xn = group_sum<G>(dot<E>(p, qj), lane) + bias_j;
     const float x = xp - xn;
     if (act && gl == 0) {
       if (a.lpos != nullptr) a.lpos[t] = xp;
@@ -500,9 +511,9 @@ __global__ __launch_bounds__(256) void k_triples(const TripleArgs a) {
     }
     if (stats) {
       // Loss (loss.py:20) and Model.regularization (model.py:87-93)
-      const float np2 = group_sum<G>(dot<E>(p, p));
-      const float ni2 = group_sum<G>(dot<E>(qi, qi));
-      const float nj2 = group_sum<G>(dot<E>(qj, qj));
+      const float np2 = group_sum<G>(dot<E>(p, p), lane);
+      const float ni2 = group_sum<G>(dot<E>(qi, qi), lane);
+      const float nj2 = group_sum<G>(dot<E>(qj, qj), lane);
       if (act && gl == 0) {
         s_loss += neg_logsigmoid(x);
         s_reg += 0.5f * (a.ai * ni2 + a.an * nj2 + a.au * np2);
@@ -595,8 +606,10 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
       float sg[E];
       load_row<G, E>(sg, a.sigma, a.d, gl);
       const AdaptiveDraw r =
-          sample_adaptive<G, E>(p, a.d, sg, a.order, a.I, seen, hi - lo, a.inv_log1mp,
-                                a.seed, a.offset + (uint64_t)tt, lane);
+          sample_adaptive<G, E>(p, a.d, sg, a.order, a.I, seen, hi - lo,
+                                adaptive_randoms(a.seed, a.offset + (uint64_t)tt, a.inv_log1mp,
+                                                 (a.I - 1) - (hi - lo)),
+                                lane);
       if (act && gl == 0) {
         a.neg[t] = r.item;
         if (a.factor_out != nullptr) a.factor_out[t] = r.factor;

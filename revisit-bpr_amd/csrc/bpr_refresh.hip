@@ -393,7 +393,8 @@ void refresh_free(bpr_ctx* c) {
   c->plan_keys = c->plan_keys_sorted = nullptr;
   c->plan_tmp = nullptr;
   c->plan_cap = 0;
-  hipFree(c->order);
+  hipFree(c->order_alloc);
+  c->order_alloc = nullptr;
   hipFree(c->sigma);
   hipFree(c->keysT);
   hipFree(c->keys_sorted);
@@ -424,7 +425,10 @@ int refresh_impl(bpr_ctx* c) {
     return BPR_ERR_INVALID;
   }
   if (c->order == nullptr) {
-    BPR_HIP_CHECK(hipMalloc(&c->order, sizeof(int32_t) * n));
+    BPR_HIP_CHECK(hipMalloc(&c->order_alloc, sizeof(int32_t) * (n + 2 * BPR_ORDER_PAD)));
+    BPR_HIP_CHECK(hipMemsetAsync(c->order_alloc, 0, sizeof(int32_t) * (n + 2 * BPR_ORDER_PAD),
+                                 c->stream));
+    c->order = c->order_alloc + BPR_ORDER_PAD;
     BPR_HIP_CHECK(hipMalloc(&c->sigma, sizeof(float) * d));
     BPR_HIP_CHECK(hipMalloc(&c->keysT, sizeof(float) * n));
     BPR_HIP_CHECK(hipMalloc(&c->keys_sorted, sizeof(uint64_t) * 2 * n));  // composite keys in|out

@@ -11,6 +11,7 @@
 #include "bpr_kernels.h"
 
 namespace bpr {
+static_assert(ORDER_PAD == BPR_ORDER_PAD, "walk vector width vs snapshot padding");
 
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
