@@ -356,24 +356,31 @@ __device__ __forceinline__ AdaptiveDraw sample_adaptive(
     total += group_last<G>(incl[e], lane);
   }
   const float thr = rnd.uf * total;
-  int fsel = -1;  // first factor with weight whose inclusive CDF exceeds thr
+  // first factor with weight whose inclusive CDF exceeds thr; psel = my element of its chunk
+  // (tracked here with static indices: a select chain over p[] after the fact is turned into a
+  // dynamically indexed private array by the compiler, which moves p[] to scratch memory)
+  int fsel = -1;
+  float psel = p[0];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int first = group_first<G>(wave_ballot(w[e] > 0.f && carry[e] + incl[e] > thr), lane);
-    if (fsel < 0 && first >= 0) fsel = e * G + first;
+    const bool take = fsel < 0 && first >= 0;
+    fsel = take ? e * G + first : fsel;
+    psel = take ? p[e] : psel;
   }
   if (fsel < 0) {  // thr rounded up to the total: the last factor with weight (0 if there is none)
     fsel = 0;
+    psel = p[0];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int last = group_last_set<G>(wave_ballot(w[e] > 0.f), lane);
-      if (last >= 0) fsel = e * G + last;
+      if (last >= 0) {
+        fsel = e * G + last;
+        psel = p[e];
+      }
     }
   }
   // ---- the user's factor value decides the orientation (:96-100)
-  float psel = p[0];
-#pragma unroll
-  for (int e = 1; e < E; ++e) psel = (fsel / G == e) ? p[e] : psel;
   const float pv = group_bcast<G>(psel, fsel & (G - 1), lane);
   const int32_t n_unseen = (int32_t)((I - 1) - n_seen);
   const int32_t r = min(rnd.r, n_unseen);

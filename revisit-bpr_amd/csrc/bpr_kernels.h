@@ -249,15 +249,17 @@ struct StreamArgs {
   float au, ai, an, lr, inv_log1mp;
 };
 
-template <int G, int E, int SAMPLER, int SEEN>
-__global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const StreamArgs a) {
+// FULL: d == G*E (32, 64, 128, 256, 512, 1024) — every `f < d` predicate folds away.
+template <int G, int E, int SAMPLER, int SEEN, bool FULL>
+__global__ __launch_bounds__(256, (E <= 4 ? BPR_STREAM_WAVES_PER_EU : (E <= 8 ? 3 : 2)))
+void k_stream(const StreamArgs a) {
   constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
   const int gw = lane / G;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
-  const int d = a.d;
+  const int d = FULL ? G * E : a.d;
   const int L = a.run_len;
   const int n_runs = (a.n + L - 1) / L;
   const bool stats = a.partials != nullptr;
@@ -417,8 +419,10 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
       const float w = 1.0f / (1.0f + expf(x));
       const float lr = a.lr;
       if (act) {
-        const bool upd_i = (i != a.pad_item) && a.dbg == 0;
-        const bool upd_j = (j != a.pad_item) && a.dbg == 0;
+        // pad rows stay exactly zero: their update value is masked to 0 instead of branching
+        const float mi = (i != a.pad_item) ? -lr : 0.f;
+        const float mj = (j != a.pad_item) ? -lr : 0.f;
+        const bool item_updates = a.dbg == 0;  // BPR_DEBUG=1: measurement aid, no item atomics
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const int f = e * G + gl;
@@ -426,9 +430,9 @@ __global__ __launch_bounds__(256, BPR_STREAM_WAVES_PER_EU) void k_stream(const S
           const float du = -lr * (-w * (qi[e] - qj[e]) + a.au * pe);
           dp[e] += du;
           pl[e] = pe + du;
-          if (f < d) {
-            if (upd_i) atomic_add_f32(irow + f, -lr * (-w * pe + a.ai * qi[e]));
-            if (upd_j) atomic_add_f32(jrow + f, -lr * (w * pe + a.an * qj[e]));
+          if (f < d && item_updates) {
+            atomic_add_f32(irow + f, mi * (-w * pe + a.ai * qi[e]));
+            atomic_add_f32(jrow + f, mj * (w * pe + a.an * qj[e]));
           }
         }
         if (a.bias != nullptr && gl == 0) {

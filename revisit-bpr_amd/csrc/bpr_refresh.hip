@@ -26,8 +26,12 @@ namespace bpr {
 
 // Q [I, d] → T [d, I] through a padded 32x32 LDS tile (coalesced on both sides)
 __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ Q,
-                                                   float* __restrict__ T, int64_t I, int d) {
+                                                   float* __restrict__ T, int64_t I, int d,
+                                                   double* __restrict__ sig_acc) {
   __shared__ float tile[32][33];
+  // also clears the per-factor sigma accumulators of a split sort (saves a memset launch)
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (int k = threadIdx.x; k < 2 * d; k += 256) sig_acc[k] = 0.0;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int64_t i0 = (int64_t)blockIdx.x * 32;
   const int f0 = blockIdx.y * 32;
@@ -445,7 +449,8 @@ int refresh_impl(bpr_ctx* c) {
     c->sort_tmp_bytes = bytes;
   }
   dim3 tgrid((unsigned)((I + 31) / 32), (unsigned)((d + 31) / 32));
-  hipLaunchKernelGGL(k_transpose, tgrid, dim3(256), 0, c->stream, c->Q, c->keysT, I, d);
+  hipLaunchKernelGGL(k_transpose, tgrid, dim3(256), 0, c->stream, c->Q, c->keysT, I, d,
+                     c->sig_acc);
   static const bool no_fast = getenv("BPR_NO_FAST_REFRESH") != nullptr;
   const char* fs = getenv("BPR_REFRESH_SUB");  // tests force the split/merge paths on small tables
   const int force_sub = fs ? atoi(fs) : 0;
@@ -465,11 +470,13 @@ int refresh_impl(bpr_ctx* c) {
     int32_t* idsA = reinterpret_cast<int32_t*>(keysA + n);
     float* keysB = reinterpret_cast<float*>(idsA + n);
     int32_t* idsB = reinterpret_cast<int32_t*>(keysB + n);
-    if (sub > 1) BPR_HIP_CHECK(hipMemsetAsync(c->sig_acc, 0, sizeof(double) * 2 * d, c->stream));
     const int items = (int)((len + 1023) / 1024);
     if (items <= 6) launch_sort_sub<6>(c, sub, len, keysA, idsA);
+    else if (items <= 10) launch_sort_sub<10>(c, sub, len, keysA, idsA);
     else if (items <= 12) launch_sort_sub<12>(c, sub, len, keysA, idsA);
+    else if (items <= 16) launch_sort_sub<16>(c, sub, len, keysA, idsA);
     else if (items <= 20) launch_sort_sub<20>(c, sub, len, keysA, idsA);
+    else if (items <= 24) launch_sort_sub<24>(c, sub, len, keysA, idsA);
     else if (items <= 28) launch_sort_sub<28>(c, sub, len, keysA, idsA);
     else launch_sort_sub<36>(c, sub, len, keysA, idsA);
     int64_t run = len;

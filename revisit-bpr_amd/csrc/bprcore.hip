@@ -272,16 +272,25 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     {
       Timer tm(c, true);
       (void)tm;
-      auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, c->stream, a);
+      auto go = [&](auto smp, auto sn) {
+        constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
+        if (c->d == G * E)
+          hipLaunchKernelGGL((k_stream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
+                             c->stream, a);
+        else
+          hipLaunchKernelGGL((k_stream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
+                             c->stream, a);
       };
-      if (sampler == NEG_GIVEN) go(k_stream<G, E, NEG_GIVEN, SEEN_CSR>);
-      else if (sampler == NEG_UNIFORM && seen == SEEN_BITMAP) go(k_stream<G, E, NEG_UNIFORM, SEEN_BITMAP>);
-      else if (sampler == NEG_UNIFORM && seen == SEEN_LIST) go(k_stream<G, E, NEG_UNIFORM, SEEN_LIST>);
-      else if (sampler == NEG_UNIFORM) go(k_stream<G, E, NEG_UNIFORM, SEEN_CSR>);
-      else if (seen == SEEN_BITMAP) go(k_stream<G, E, NEG_ADAPTIVE, SEEN_BITMAP>);
-      else if (seen == SEEN_LIST) go(k_stream<G, E, NEG_ADAPTIVE, SEEN_LIST>);
-      else go(k_stream<G, E, NEG_ADAPTIVE, SEEN_CSR>);
+      using std::integral_constant;
+      auto with_seen = [&](auto smp) {
+        if (seen == SEEN_BITMAP) go(smp, integral_constant<int, SEEN_BITMAP>{});
+        else if (seen == SEEN_LIST) go(smp, integral_constant<int, SEEN_LIST>{});
+        else go(smp, integral_constant<int, SEEN_CSR>{});
+      };
+      if (sampler == NEG_GIVEN)
+        go(integral_constant<int, NEG_GIVEN>{}, integral_constant<int, SEEN_CSR>{});
+      else if (sampler == NEG_UNIFORM) with_seen(integral_constant<int, NEG_UNIFORM>{});
+      else with_seen(integral_constant<int, NEG_ADAPTIVE>{});
     }
     if (out_scalars != nullptr)
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, a.partials, (int)grid,
