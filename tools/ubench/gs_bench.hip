@@ -26,7 +26,7 @@ __device__ __forceinline__ void aadd_wg(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-enum { V_ATOMS_SYS = 8, V_ATOMS_ONLYQ = 9, V_READ = 0, V_RMW = 1, V_ATOM4 = 2, V_ATOMS = 3, V_ATOM4_WG = 4, V_ATOM_LDS = 5, V_ATOMS_Q_RMW_P = 6, V_NT = 7 };
+enum { V_ATOMS_ONLYQ_256 = 10, V_ATOMS_SYS = 8, V_ATOMS_ONLYQ = 9, V_READ = 0, V_RMW = 1, V_ATOM4 = 2, V_ATOMS = 3, V_ATOM4_WG = 4, V_ATOM_LDS = 5, V_ATOMS_Q_RMW_P = 6, V_NT = 7 };
 
 template <int V>
 __global__ __launch_bounds__(256) void k(float* P, float* Q, const int* us, const int* is, const int* js,
@@ -44,7 +44,36 @@ __global__ __launch_bounds__(256) void k(float* P, float* Q, const int* us, cons
     float* pr = P + (int64_t)u * D;
     float* ir = Q + (int64_t)i * D;
     float* jr = Q + (int64_t)j * D;
-    if constexpr (V == V_ATOMS_SYS || V == V_ATOMS_ONLYQ) {
+    if constexpr (V == V_ATOMS_ONLYQ_256) {
+      // same work as V_ATOMS_ONLYQ, but every atomic instruction covers 256 contiguous bytes of ONE
+      // row (lanes 0-31: chunk e, lanes 32-63: chunk e+1 of the same triple's row) instead of
+      // 128 B of two different rows
+      float p[4], qi[4], qj[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { p[e] = pr[e * G + gl]; qi[e] = ir[e * G + gl]; qj[e] = jr[e * G + gl]; }
+      float x = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x += p[e] * (qi[e] - qj[e]);
+      x = gsum(x);
+      const float w = 1.f / (1.f + __expf(x));
+      acc += x;
+      // rows of the wave's two triples, known to all lanes
+      const int iA = __shfl(i, 0, 64), iB = __shfl(i, 32, 64), jA = __shfl(j, 0, 64), jB = __shfl(j, 32, 64);
+      const bool actA = __shfl((int)act, 0, 64), actB = __shfl((int)act, 32, 64);
+      float* rows[4] = {Q + (int64_t)iA * D, Q + (int64_t)jA * D, Q + (int64_t)iB * D, Q + (int64_t)jB * D};
+      const bool acts[4] = {actA, actA, actB, actB};
+      if (act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pr[e * G + gl] = p[e] + lr * (w * (qi[e] - qj[e]) - 0.01f * p[e]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // 2 instructions x 256 B per row
+          if (acts[r]) aadd(rows[r] + h * 64 + lane, lr * (w * p[h] - 0.01f * qi[h]));
+        }
+      }
+    } else if constexpr (V == V_ATOMS_SYS || V == V_ATOMS_ONLYQ) {
       float p[4], qi[4], qj[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { p[e] = pr[e * G + gl]; qi[e] = ir[e * G + gl]; qj[e] = jr[e * G + gl]; }
@@ -180,7 +209,7 @@ double run(const char* name, int blocks, float* P, float* Q, int* us, int* is, i
 int main(int argc, char** argv) {
   int64_t n = argc > 1 ? atoll(argv[1]) : 199168;
   int64_t U = argc > 2 ? atoll(argv[2]) : 136678, I = argc > 3 ? atoll(argv[3]) : 20109;
-  int hot = argc > 4 ? atoi(argv[4]) : 1;
+  int hot = argc > 4 ? atoi(argv[4]) : 1;  // 0 uniform items, 1 Zipf with rank r -> row r+1, 2 Zipf over permuted rows
   float *P, *Q, *out; int *us, *is, *js;
   CK(hipMalloc(&P, U * D * 4)); CK(hipMalloc(&Q, I * D * 4)); CK(hipMalloc(&out, 16));
   CK(hipMalloc(&us, n * 4)); CK(hipMalloc(&is, n * 4)); CK(hipMalloc(&js, n * 4));
@@ -192,9 +221,12 @@ int main(int argc, char** argv) {
   std::vector<double> cdf(I - 1); double tot = 0;
   for (int64_t r = 0; r < I - 1; ++r) { tot += pow(r + 1 + 60.0, -1.5); cdf[r] = tot; }
   std::uniform_real_distribution<double> ud(0, 1);
+  std::vector<int> perm(I - 1);
+  for (int64_t r = 0; r < I - 1; ++r) perm[r] = (int)r;
+  if (hot == 2) std::shuffle(perm.begin(), perm.end(), rng);
   for (int64_t t = 0; t < n; ++t) {
     hu[t] = 1 + rng() % (U - 1);
-    hi[t] = hot ? 1 + (int)(std::lower_bound(cdf.begin(), cdf.end(), ud(rng) * tot) - cdf.begin()) : 1 + rng() % (I - 1);
+    hi[t] = hot ? 1 + perm[std::min<int64_t>(I - 2, std::lower_bound(cdf.begin(), cdf.end(), ud(rng) * tot) - cdf.begin())] : 1 + rng() % (I - 1);
     hj[t] = 1 + rng() % (I - 1);
   }
   CK(hipMemcpy(us, hu.data(), n * 4, hipMemcpyHostToDevice));
@@ -210,6 +242,7 @@ int main(int argc, char** argv) {
     run<V_ATOM_LDS>("atomic-lds-T", blocks, P, Q, us, is, js, n, out);
     run<V_ATOMS_SYS>("atomic-contig-sys", blocks, P, Q, us, is, js, n, out);
     run<V_ATOMS_ONLYQ>("P-store+Q-contig", blocks, P, Q, us, is, js, n, out);
+    run<V_ATOMS_ONLYQ_256>("P-store+Q-256B", blocks, P, Q, us, is, js, n, out);
     run<V_ATOM4_WG>("atomic4-wgscope", blocks, P, Q, us, is, js, n, out);
     run<V_ATOMS_Q_RMW_P>("P-rmw+Q-atomic4", blocks, P, Q, us, is, js, n, out);
   }
