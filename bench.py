@@ -59,6 +59,11 @@ def parse_args():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink users/actions (debug)")
     ap.add_argument("--max-inflight", type=int, default=0)
     ap.add_argument("--run-len", type=int, default=8)
+    ap.add_argument("--hot-rows", type=int, default=None,
+                    help="delta rows for the N most popular item rows (library default 256; 0 = off)")
+    ap.add_argument("--hot-replicas", type=int, default=1)
+    ap.add_argument("--item-skew", type=float, default=None,
+                    help="override the item popularity exponent (debug: 0 = uniform popularity)")
     ap.add_argument("--ungrouped", action="store_true", help="all-atomic user rows (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -128,8 +133,9 @@ def main():
 
     d = args.dim
     # every rank owns its own ML-20M-shaped user shard (weak scaling); same item space
+    gen_kw = {} if args.item_skew is None else {"item_skew": args.item_skew}  # measurement aid
     data = synthetic.generate_named(args.workload, eval_users=10_000, seed=args.seed + rank,
-                                    scale=args.scale)
+                                    scale=args.scale, **gen_kw)
     U, I = data.num_users, data.num_items
     g = torch.Generator().manual_seed(args.seed)  # same Q on every rank
     Q = ((torch.rand(I, d, generator=g) - 0.5) / d)
@@ -154,6 +160,8 @@ def main():
     src_items = torch.from_numpy(data.items).to(dev)
     users, items = torch.empty_like(src_users), torch.empty_like(src_items)
     e.set_stream_opts(not args.ungrouped, args.run_len)
+    if args.hot_rows is not None:
+        e.set_hot_rows(args.hot_rows, args.hot_replicas)
     sync = ItemSync([Q]) if world > 1 else None
     scalars = torch.zeros(4, device=dev)
     seed = args.seed

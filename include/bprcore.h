@@ -192,6 +192,17 @@ int bpr_train_stream(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int
  * group walks with the user row held in registers. */
 int bpr_set_stream_opts(bpr_ctx* ctx, int32_t grouped_by_user, int32_t run_len);
 
+/* Hot item rows.  On popularity-skewed data the STREAM kernel is limited by fp32 atomics queueing
+ * on the memory channels that happen to hold the most popular item rows (rows are scattered over
+ * the table, the load per channel is uneven).  bpr_plan_epoch therefore counts the training
+ * positives per item (once per training set) and the `hot_rows` most popular rows (default 256)
+ * take their STREAM updates in a compact block of delta rows that spans every channel evenly —
+ * optionally `replicas` (1, 2, 4 or 8; default 1) of them, a wavefront adds to one, every reader
+ * adds them all to the base row — folded into Q right after every STREAM launch.  Same algebra
+ * as updating Q directly, up to the association of fp32 sums.  hot_rows = 0 turns it off.  Takes
+ * effect at the next bpr_plan_epoch. */
+int bpr_set_hot_rows(bpr_ctx* ctx, int32_t hot_rows, int32_t replicas);
+
 /* Epoch order for STREAM mode — replaces DataLoader(shuffle=True, generator=manual_seed(seed))
  * (example.py:307-321; experiments/bpr/exp.py:109-118): a seeded pseudo-random partition of the n
  * training triples into ceil(n/chunk) chunks of `chunk` triples (the last may be shorter); inside a

@@ -55,6 +55,15 @@ struct bpr_ctx {
   void* plan_tmp = nullptr;
   size_t plan_tmp_bytes = 0;
   int64_t plan_cap = 0;
+  // hot item rows (bpr_set_hot_rows): the most popular rows take their STREAM updates in replica
+  // delta rows, folded into Q right after every STREAM launch (all zero in between)
+  int hot_rows_opt = 256, hot_reps_opt = 1;
+  int hot_H = 0, hot_R = 0;
+  int32_t* hot_slot = nullptr;   // [I] slot of an item row, -1 = not hot
+  int32_t* hot_items = nullptr;  // [hot_H]
+  float* hot_delta = nullptr;    // [hot_R, hot_H, d]
+  const int32_t* hot_key_ptr = nullptr;  // training positives the popularity was measured on
+  int64_t hot_key_n = 0;
   // scalar slots
   float* dev_scalars = nullptr;
   // timing of the dominant kernel
@@ -69,6 +78,8 @@ namespace bpr {
 void set_error(const std::string& msg);
 int refresh_impl(bpr_ctx* c);       // bpr_refresh.hip
 void refresh_free(bpr_ctx* c);      // bpr_refresh.hip
+int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n);  // bpr_refresh.hip
+void hot_free(bpr_ctx* c);                                       // bpr_refresh.hip
 int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n,
                     int64_t chunk, uint64_t seed, int32_t* users_out, int32_t* pos_out);
 }  // namespace bpr

@@ -216,6 +216,46 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ 
   if (threadIdx.x < 4) out[threadIdx.x] += (float)red[0][threadIdx.x];
 }
 
+// After a STREAM launch: fold the hot rows' replica deltas into Q and clear them (blocks 1..), and
+// add the launch's loss statistics to the caller's scalars (block 0, when requested).
+__global__ __launch_bounds__(256) void k_stream_epilogue(const float* __restrict__ partials,
+                                                         int n_blocks, float* __restrict__ out,
+                                                         float* __restrict__ Q,
+                                                         float* __restrict__ delta,
+                                                         const int32_t* __restrict__ hot_items,
+                                                         int H, int R, int d) {
+  if (blockIdx.x == 0) {
+    if (out == nullptr) return;
+    __shared__ double red[256][4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < n_blocks; b += 256)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += (double)partials[(int64_t)b * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
+      __syncthreads();
+    }
+    if (threadIdx.x < 4) out[threadIdx.x] += (float)red[0][threadIdx.x];
+    return;
+  }
+  const int64_t n = (int64_t)H * d;
+  for (int64_t k = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x; k < n;
+       k += (int64_t)(gridDim.x - 1) * 256) {
+    const int32_t it = hot_items[k / d];
+    float sum = 0.f;
+    for (int r = 0; r < R; ++r) {
+      sum += delta[(int64_t)r * n + k];
+      delta[(int64_t)r * n + k] = 0.f;
+    }
+    if (it >= 0) Q[(int64_t)it * d + (k % d)] += sum;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // STREAM: the throughput kernel.
 //
@@ -247,7 +287,28 @@ struct StreamArgs {
   int32_t pad_user, pad_item;
   int32_t run_len, grouped, bm_words, dbg;
   float au, ai, an, lr, inv_log1mp;
+  // hot item rows: updates of row i with hot_slot[i] = s >= 0 go to the replica delta row
+  // hot_delta[wave & hot_rmask][s]; its value is Q[i] + the sum of its replicas (NULL = off)
+  const int32_t* hot_slot;
+  float* hot_delta;
+  int32_t hot_H, hot_rmask;
 };
+
+// A hot row's value is its base row plus its replica delta rows; returns the replica this wave
+// adds its update to.
+template <int G, int E>
+__device__ __forceinline__ float* hot_row(float (&q)[E], float* __restrict__ delta, int32_t slot,
+                                          int32_t H, int32_t rmask, int wave, int d, int gl) {
+  for (int32_t r = 0; r <= rmask; ++r) {
+    const float* __restrict__ row = delta + (uint32_t)(r * H + slot) * (uint32_t)d;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int f = e * G + gl;
+      if (f < d) q[e] += row[f];
+    }
+  }
+  return delta + (uint32_t)((wave & rmask) * H + slot) * (uint32_t)d;
+}
 
 // FULL: d == G*E (32, 64, 128, 256, 512, 1024) — every `f < d` predicate folds away.
 template <int G, int E, int SAMPLER, int SEEN, bool FULL>
@@ -287,7 +348,7 @@ void k_stream(const StreamArgs a) {
     // ---- run prologue: ONE coalesced load brings the ids of the whole run (lane k holds triple
     // t0+k; lane L the successor, lane G-1 the predecessor) and one more the users' CSR bounds,
     // so the per-triple dependent chain starts at the row gathers instead of at the ids.
-    int32_t my_u = 0, my_i = 0;
+    int32_t my_u = 0, my_i = 0, my_si = -1;
     int64_t my_lo = 0, my_hi = 0;
     {
       const int tk = (gl == G - 1) ? t0 - 1 : t0 + gl;
@@ -296,6 +357,7 @@ void k_stream(const StreamArgs a) {
       if (in_run || neighbour) my_u = a.users[tk];
       if (in_run) {
         my_i = a.pos[tk];
+        if (a.hot_slot != nullptr) my_si = a.hot_slot[my_i];
         if constexpr (SAMPLER != NEG_GIVEN) {
           my_lo = a.indptr[my_u];
           my_hi = a.indptr[my_u + 1];
@@ -330,6 +392,8 @@ void k_stream(const StreamArgs a) {
       float* __restrict__ irow = a.Q + (uint32_t)i * (uint32_t)d;
       float qi[E];
       load_row<G, E>(qi, irow, d, gl);
+      const int32_t si = group_bcast<G>(my_si, step, lane);
+      if (si >= 0) irow = hot_row<G, E>(qi, a.hot_delta, si, a.hot_H, a.hot_rmask, wave, d, gl);
       if (act && u != cur_u) {
         // ---- user change: write the previous user's row back, fetch the new one
         if (cur_u >= 0 && cur_u != a.pad_user) {
@@ -398,6 +462,10 @@ void k_stream(const StreamArgs a) {
       float* __restrict__ jrow = a.Q + (uint32_t)j * (uint32_t)d;
       float qj[E];
       load_row<G, E>(qj, jrow, d, gl);
+      if (a.hot_slot != nullptr) {
+        const int32_t sj = a.hot_slot[j];
+        if (sj >= 0) jrow = hot_row<G, E>(qj, a.hot_delta, sj, a.hot_H, a.hot_rmask, wave, d, gl);
+      }
 
       // x_uij = <p_u, q_i - q_j> (+ bias difference): one group sum
       float xl = 0.f;

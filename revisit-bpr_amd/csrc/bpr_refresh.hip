@@ -357,6 +357,9 @@ int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
     set_error("bpr_plan_epoch: n must be < 2^31");
     return BPR_ERR_UNSUPPORTED;
   }
+  if (c->hot_key_ptr != pos_in || c->hot_key_n != n) {  // new training set: measure popularity
+    if (int rc = hot_build_impl(c, pos_in, n)) return rc;
+  }
   const int ubits = bits_for((uint64_t)(c->U - 1));
   const int64_t n_chunks = (n + chunk - 1) / chunk;
   const int cbits = bits_for((uint64_t)(n_chunks - 1));
@@ -390,7 +393,94 @@ int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
   return BPR_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Hot item rows: popularity of the training positives -> the H most popular rows get replica
+// delta rows for their STREAM updates (same-line atomic contention on the few
+// hundred hot lines is what sets the kernel's floor on popularity-skewed data).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_item_hist(const int32_t* __restrict__ pos, int64_t n, int64_t I,
+                            uint32_t* __restrict__ counts) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t it = pos[k];
+    if (it >= 0 && it < I) atomicAdd(&counts[it], 1u);
+  }
+}
+__global__ void k_iota32(int32_t* __restrict__ ids, int64_t I) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < I;
+       k += (int64_t)gridDim.x * blockDim.x)
+    ids[k] = (int32_t)k;
+}
+__global__ void k_hot_slots(const int32_t* __restrict__ by_count, const uint32_t* __restrict__ cnt,
+                            int H, int pad_item, int32_t* __restrict__ slot,
+                            int32_t* __restrict__ hot_items) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= H) return;
+  const int32_t it = by_count[s];
+  const bool ok = it != pad_item && cnt[s] > 0u;  // slot s stays unused otherwise
+  hot_items[s] = ok ? it : -1;
+  if (ok) slot[it] = s;
+}
+
+void hot_free(bpr_ctx* c) {
+  hipFree(c->hot_slot);
+  hipFree(c->hot_items);
+  hipFree(c->hot_delta);
+  c->hot_slot = c->hot_items = nullptr;
+  c->hot_delta = nullptr;
+  c->hot_H = c->hot_R = 0;
+  c->hot_key_ptr = nullptr;
+  c->hot_key_n = 0;
+}
+
+int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n) {
+  hot_free(c);
+  const int64_t I = c->I;
+  int H = c->hot_rows_opt, R = c->hot_reps_opt;
+  if (H > I - 1) H = (int)(I - 1);
+  c->hot_key_ptr = pos;
+  c->hot_key_n = n;
+  if (H <= 0 || R <= 0 || n <= 0) return BPR_OK;
+  uint32_t *counts = nullptr, *counts_sorted = nullptr;
+  int32_t *ids = nullptr, *ids_sorted = nullptr;
+  void* tmp = nullptr;
+  size_t bytes = 0;
+  BPR_HIP_CHECK(hipMalloc(&counts, sizeof(uint32_t) * I));
+  BPR_HIP_CHECK(hipMalloc(&counts_sorted, sizeof(uint32_t) * I));
+  BPR_HIP_CHECK(hipMalloc(&ids, sizeof(int32_t) * I));
+  BPR_HIP_CHECK(hipMalloc(&ids_sorted, sizeof(int32_t) * I));
+  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, counts, counts_sorted,
+                                                             ids, ids_sorted, (int)I, 0, 32,
+                                                             c->stream));
+  BPR_HIP_CHECK(hipMalloc(&tmp, bytes > 0 ? bytes : 16));
+  BPR_HIP_CHECK(hipMalloc(&c->hot_slot, sizeof(int32_t) * I));
+  BPR_HIP_CHECK(hipMalloc(&c->hot_items, sizeof(int32_t) * H));
+  BPR_HIP_CHECK(hipMalloc(&c->hot_delta, sizeof(float) * (size_t)R * H * c->d));
+  BPR_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * I, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->hot_slot, 0xff, sizeof(int32_t) * I, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->hot_delta, 0, sizeof(float) * (size_t)R * H * c->d, c->stream));
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_item_hist, dim3(grid), dim3(256), 0, c->stream, pos, n, I, counts);
+  hipLaunchKernelGGL(k_iota32, dim3(64), dim3(256), 0, c->stream, ids, I);
+  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(tmp, bytes, counts, counts_sorted, ids,
+                                                             ids_sorted, (int)I, 0, 32, c->stream));
+  hipLaunchKernelGGL(k_hot_slots, dim3((H + 255) / 256), dim3(256), 0, c->stream, ids_sorted,
+                     counts_sorted, H, c->pad_item, c->hot_slot, c->hot_items);
+  BPR_HIP_CHECK(hipGetLastError());
+  BPR_HIP_CHECK(hipStreamSynchronize(c->stream));  // one-time setup: the scratch is freed below
+  hipFree(counts);
+  hipFree(counts_sorted);
+  hipFree(ids);
+  hipFree(ids_sorted);
+  hipFree(tmp);
+  c->hot_H = H;
+  c->hot_R = R;
+  return BPR_OK;
+}
+
 void refresh_free(bpr_ctx* c) {
+  hot_free(c);
   hipFree(c->plan_keys);
   hipFree(c->plan_keys_sorted);
   hipFree(c->plan_tmp);

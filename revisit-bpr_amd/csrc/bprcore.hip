@@ -292,9 +292,14 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       else if (sampler == NEG_UNIFORM) with_seen(integral_constant<int, NEG_UNIFORM>{});
       else with_seen(integral_constant<int, NEG_ADAPTIVE>{});
     }
-    if (out_scalars != nullptr)
-      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, a.partials, (int)grid,
-                         out_scalars);
+    const bool hot = a.hot_slot != nullptr;
+    if (out_scalars != nullptr || hot) {
+      const unsigned fold_blocks =
+          hot ? (unsigned)std::min<int64_t>(((int64_t)c->hot_H * c->d + 255) / 256, 64) : 0u;
+      hipLaunchKernelGGL(k_stream_epilogue, dim3(1 + fold_blocks), dim3(256), 0, c->stream,
+                         a.partials, (int)grid, out_scalars, c->Q, c->hot_delta, c->hot_items,
+                         hot ? c->hot_H : 0, c->hot_R, c->d);
+    }
     BPR_HIP_CHECK(hipGetLastError());
     return BPR_OK;
   });
@@ -637,6 +642,12 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
   }
   a.au = c->au; a.ai = c->ai; a.an = c->an; a.lr = c->opt.lr;
   a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
+  if (c->hot_H > 0 && a.dbg == 0) {
+    a.hot_slot = c->hot_slot;
+    a.hot_delta = c->hot_delta;
+    a.hot_H = c->hot_H;
+    a.hot_rmask = c->hot_R - 1;
+  }
   return launch_stream(c, a, sampler, max_inflight, out_scalars);
 }
 
@@ -711,6 +722,20 @@ int bpr_item_fold(float* q, float* base, const float* own, const float* tot, flo
   hipLaunchKernelGGL(k_item_fold, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, q, base, own,
                      tot, scale, rebase, n);
   BPR_HIP_CHECK(hipGetLastError());
+  return BPR_OK;
+}
+
+int bpr_set_hot_rows(bpr_ctx* c, int32_t hot_rows, int32_t replicas) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_hot_rows: ctx is NULL");
+  if (hot_rows < 0 || hot_rows > 32768)
+    return fail(BPR_ERR_INVALID, "bpr_set_hot_rows: hot_rows must be in [0, 32768]");
+  if (hot_rows > 0 && replicas != 1 && replicas != 2 && replicas != 4 && replicas != 8)
+    return fail(BPR_ERR_INVALID, "bpr_set_hot_rows: replicas must be 1, 2, 4 or 8");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  hot_free(c);  // rebuilt by the next bpr_plan_epoch
+  c->hot_rows_opt = hot_rows;
+  c->hot_reps_opt = hot_rows > 0 ? replicas : 0;
   return BPR_OK;
 }
 

@@ -268,6 +268,11 @@ class Engine:
     def set_stream_opts(self, grouped_by_user: bool, run_len: int = 8) -> None:
         native.check(self._lib.bpr_set_stream_opts(self._ctx, int(grouped_by_user), run_len))
 
+    def set_hot_rows(self, hot_rows: int = 256, replicas: int = 1) -> None:
+        """Replica delta rows for the most popular item rows in STREAM mode (0 = off); takes
+        effect at the next plan_epoch."""
+        native.check(self._lib.bpr_set_hot_rows(self._ctx, hot_rows, replicas))
+
     def plan_epoch(self, users: torch.Tensor, pos: torch.Tensor, chunk: int, seed: int,
                    out: Optional[tuple[torch.Tensor, torch.Tensor]] = None):
         """Shuffle the training triples into chunks of `chunk`, each grouped by user (on device)."""

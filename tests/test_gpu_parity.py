@@ -619,6 +619,22 @@ def test_atomics_lose_nothing_under_chip_wide_contention():
     dQ = e2.Q.cpu().numpy().astype(np.float64) / -lr
     s0 = np.abs(gQ0).max()
     assert s0 > 3 and np.abs(dQ - gQ0).max() < 0.005 * s0, np.abs(dQ - gQ0).max() / s0
+    # and with the hot-row delta rows in the path (bpr_plan_epoch measures popularity; the 16 most
+    # popular of the 50 rows take their updates in delta rows that are folded after the launch)
+    for hot_rows, replicas in ((16, 1), (50, 4)):
+        e3 = make_engine(P, Q0, None, (0.0, 0.0, 0.0))
+        e3.set_optimizer(kind=0, lr=lr)
+        e3.set_hot_rows(hot_rows, replicas)
+        e3.set_stream_opts(True, 8)
+        pu, pi = e3.plan_epoch(dev(users), dev(pos), n, seed=3)
+        order_back = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(users, pos))}
+        ng = np.asarray([neg[order_back[(int(a), int(b))]] for a, b in
+                         zip(pu.cpu().numpy(), pi.cpu().numpy())], np.int32)
+        e3.train_stream(pu, pi, sampler=0, neg=dev(ng))
+        _, g3, _ = oracle.dense_grad(P, Q0, None, pu.cpu().numpy(), pi.cpu().numpy(), ng,
+                                     (0.0, 0.0, 0.0))
+        dQ3 = e3.Q.cpu().numpy().astype(np.float64) / -lr
+        assert np.abs(dQ3 - g3).max() < 0.005 * s0, (hot_rows, np.abs(dQ3 - g3).max() / s0)
 
 
 @pytest.mark.parametrize("I,d", [(20109, 128), (5001, 32), (12937, 64), (20480, 8), (300, 16)])

@@ -185,6 +185,58 @@ __global__ __launch_bounds__(256) void k(float* P, float* Q, const int* us, cons
   if (acc == 12345.678f) out[0] = acc;
 }
 
+
+// Replica experiment: the H hottest item rows take their updates in R delta replicas (writer picks
+// one by wave id), readers add the replicas to the base row.  Same algebra, R-fold less same-line
+// contention; the deltas are folded into Q after the launch (not timed here: H*R rows).
+__global__ __launch_bounds__(256) void k_rep(float* P, float* Q, float* Dl, const int* slot, int H, int R,
+                                             const int* us, const int* is, const int* js, int64_t n, float lr,
+                                             float* out) {
+  const int lane = threadIdx.x & 63, gl = lane & (G - 1), gw = lane / G;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float acc = 0.f;
+  const int rep = (int)(wave % R);
+  for (int64_t base = wave * 2; base < n; base += nw * 2) {
+    const int64_t t = base + gw;
+    const bool act = t < n;
+    const int64_t tt = act ? t : n - 1;
+    const int u = us[tt], i = is[tt], j = js[tt];
+    const int si = slot[i], sj = slot[j];
+    float* pr = P + (int64_t)u * D;
+    float* ir = Q + (int64_t)i * D;
+    float* jr = Q + (int64_t)j * D;
+    float p[4], qi[4], qj[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[e] = pr[e * G + gl]; qi[e] = ir[e * G + gl]; qj[e] = jr[e * G + gl]; }
+    if (si >= 0)
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qi[e] += Dl[((int64_t)r * H + si) * D + e * G + gl];
+    if (sj >= 0)
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qj[e] += Dl[((int64_t)r * H + sj) * D + e * G + gl];
+    float x = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x += p[e] * (qi[e] - qj[e]);
+    x = gsum(x);
+    const float w = 1.f / (1.f + __expf(x));
+    acc += x;
+    float* iw = si >= 0 ? Dl + ((int64_t)rep * H + si) * D : ir;
+    float* jw = sj >= 0 ? Dl + ((int64_t)rep * H + sj) * D : jr;
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pr[e * G + gl] = p[e] + lr * (w * (qi[e] - qj[e]) - 0.01f * p[e]);
+        aadd(iw + e * G + gl, lr * (w * p[e] - 0.01f * qi[e]));
+        aadd(jw + e * G + gl, lr * (-w * p[e] - 0.01f * qj[e]));
+      }
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
 template <int V>
 double run(const char* name, int blocks, float* P, float* Q, int* us, int* is, int* js, int64_t n, float* out, int iters = 20) {
   hipEvent_t a, b;
@@ -233,6 +285,27 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(is, hi.data(), n * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(js, hj.data(), n * 4, hipMemcpyHostToDevice));
   printf("n=%lld U=%lld I=%lld d=%d hot=%d\n", (long long)n, (long long)U, (long long)I, D, hot);
+  for (int H : {64, 256, 1024, 4096}) {
+    for (int R : {2, 4, 8}) {
+      std::vector<int> hs(I, -1);
+      for (int r = 0; r < H && r < I - 1; ++r) hs[1 + perm[r]] = r;  // rank r -> row 1+perm[r]
+      int* slot; float* Dl;
+      CK(hipMalloc(&slot, I * 4)); CK(hipMalloc(&Dl, (size_t)R * H * D * 4));
+      CK(hipMemcpy(slot, hs.data(), I * 4, hipMemcpyHostToDevice));
+      CK(hipMemset(Dl, 0, (size_t)R * H * D * 4));
+      hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+      std::vector<float> ts;
+      for (int it = 0; it < 23; ++it) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(k_rep, dim3(2048), dim3(256), 0, 0, P, Q, Dl, slot, H, R, us, is, js, n, 1e-6f, out);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); if (it >= 3) ts.push_back(ms);
+      }
+      std::sort(ts.begin(), ts.end());
+      printf("replicas H=%5d R=%d  %8.3f ms  %8.1f Mtriples/s\n", H, R, ts[ts.size() / 2], n / ts[ts.size() / 2] * 1e-3);
+      CK(hipFree(slot)); CK(hipFree(Dl));
+    }
+  }
   for (int blocks : {2048}) {
     run<V_READ>("read-only", blocks, P, Q, us, is, js, n, out);
     run<V_RMW>("rmw-store", blocks, P, Q, us, is, js, n, out);
