@@ -48,7 +48,7 @@ res = {}
 for name in ("pmc_fetch", "pmc_write"):
     for (k, c), (n, v) in sorted(agg(G / name / "bench_counter_collection.csv").items(), key=lambda x: -x[1][1]):
         out.append(f"{k},{c},{n},{v / n:.1f}")
-        if "k_stream" in k:
+        if "k_stream<" in k:
             res[c] = v / n
 rd, wr = 2 * res["FETCH_SIZE"] * 1024, res["WRITE_SIZE"] * 1024
 alg = 199168 * 3080
