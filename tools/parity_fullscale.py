@@ -81,7 +81,7 @@ for sampler in a.samplers.split(","):
                 e.set_optimizer(eng.OPT_SGD, lr=a.lr)
                 e.adaptive_refresh()
                 g = torch.Generator(device=dev).manual_seed(seed)
-            rec = []
+            rec, ep_s = [], []
             for ep in range(a.epochs):
                 torch.cuda.synchronize()
                 s0 = time.perf_counter()
@@ -94,11 +94,12 @@ for sampler in a.samplers.split(","):
                                    offset=ep * data.nnz, refresh_every=every if kind == eng.NEG_ADAPTIVE else 0)
                 torch.cuda.synchronize()
                 secs += time.perf_counter() - s0
+                ep_s.append(round(time.perf_counter() - s0, 4))
                 m = metrics(model)
                 curve.append(m["ndcg@100"])
                 rec.append(m["recall@20"])
             row = {"sampler": sampler, "seed": seed, "mode": mode, "ndcg@100": curve, "recall@20": rec,
-                   "train_s_per_epoch": secs / a.epochs}
+                   "train_s_per_epoch": secs / a.epochs, "epoch_s": ep_s}
             rows.append(row)
             print(json.dumps(row), flush=True)
 print("\nsummary (final epoch, mean over seeds):")
