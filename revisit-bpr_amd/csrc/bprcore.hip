@@ -49,6 +49,14 @@ static int max_blocks() {
   }();
   return v;
 }
+// STREAM grids: ~1.5 runs per group and the hardware dispatcher balances the rest (measured:
+// ML-20M 2,075 blocks 0.233 ms vs 0.24-0.25 for 1 or >= 2 runs per group; Yelp 10,922 blocks
+// 1.22 ms vs 1.31 ms with a persistent 2,048-block grid).  BPR_MAX_BLOCKS caps it (experiments).
+constexpr int64_t STREAM_MAX_GRID = 65536;  // also the size of the per-block partials scratch
+static int64_t stream_grid_cap() {
+  static const bool forced = getenv("BPR_MAX_BLOCKS") != nullptr;
+  return forced ? (int64_t)max_blocks() : STREAM_MAX_GRID;
+}
 
 // grid for n groups of G lanes, 256-thread blocks, capped (grid-stride inside the kernels)
 static unsigned grid_for(int64_t n_groups, int G, int64_t cap_groups) {
@@ -265,7 +273,8 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     if (cap_groups > 0 && want > cap_groups) want = cap_groups;
     const int64_t per_block = block / G;
     int64_t nblk = (want + per_block - 1) / per_block;
-    const int64_t max_blk = (int64_t)max_blocks() * (256 / block);
+    if (cap_groups <= 0 || n_runs <= cap_groups) nblk = (2 * nblk + 2) / 3;  // 1.5 runs per group
+    const int64_t max_blk = std::min<int64_t>(stream_grid_cap() * (256 / block), STREAM_MAX_GRID);
     if (nblk > max_blk) nblk = max_blk;
     const unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
     a.bm_words = lds_words;
@@ -326,7 +335,7 @@ int bpr_ctx_create(bpr_ctx** out, int device_id, void* hip_stream) {
   if (c == nullptr) return fail(BPR_ERR_NOMEM, "bpr_ctx_create: out of host memory");
   c->device = device_id;
   c->stream = (hipStream_t)hip_stream;
-  if (hipMalloc(&c->dev_scalars, sizeof(float) * 4 * (size_t)(max_blocks() + 1)) != hipSuccess) {
+  if (hipMalloc(&c->dev_scalars, sizeof(float) * 4 * (size_t)(STREAM_MAX_GRID + 1)) != hipSuccess) {
     delete c;
     return fail(BPR_ERR_HIP, "bpr_ctx_create: hipMalloc failed");
   }
