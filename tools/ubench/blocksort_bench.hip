@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <rocprim/block/block_radix_sort.hpp>
+#include <rocprim/block/block_sort.hpp>
 #include <stdint.h>
 #include <stdio.h>
 #include <algorithm>
@@ -31,6 +32,40 @@ __global__ __launch_bounds__(BLOCK) void k_sort(const float* __restrict__ T, int
   }
 }
 
+struct Desc { __device__ bool operator()(const float& a, const float& b) const { return a > b; } };
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_msort(const float* __restrict__ T, int cnt, float* __restrict__ ko, uint16_t* __restrict__ vo) {
+  using Sort = rocprim::block_sort<float, BLOCK, ITEMS, uint16_t, rocprim::block_sort_algorithm::stable_merge_sort>;
+  __shared__ typename Sort::storage_type sm;
+  const float* row = T + (int64_t)blockIdx.x * cnt;
+  float keys[ITEMS]; uint16_t vals[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int l = threadIdx.x * ITEMS + k;
+    keys[k] = l < cnt ? row[l] : -__builtin_huge_valf();
+    vals[k] = (uint16_t)l;
+  }
+  Sort().sort(keys, vals, sm, Desc());
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int pos = threadIdx.x * ITEMS + k;
+    if (pos < cnt) { ko[(int64_t)blockIdx.x * cnt + pos] = keys[k]; vo[(int64_t)blockIdx.x * cnt + pos] = vals[k]; }
+  }
+}
+template <int BLOCK, int ITEMS>
+void runm(const float* T, int wgs, int cnt, float* ko, uint16_t* vo) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  std::vector<float> ts;
+  for (int it = 0; it < 13; ++it) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_msort<BLOCK, ITEMS>), dim3(wgs), dim3(BLOCK), 0, 0, T, cnt, ko, vo);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); if (it >= 3) ts.push_back(ms);
+  }
+  std::sort(ts.begin(), ts.end());
+  printf("merge sort block %4d items %2d : %7.1f us\n", BLOCK, ITEMS, ts[ts.size() / 2] * 1e3);
+}
+
 template <int BLOCK, int ITEMS, int RADIX>
 void run(const float* T, int wgs, int cnt, float* ko, uint16_t* vo) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -55,6 +90,9 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(T, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   printf("wgs=%d cnt=%d\n", wgs, cnt);
   if (cnt <= 10240) {
+    runm<1024, 8>(T, wgs, cnt > 8192 ? 8192 : cnt, ko, vo);
+    runm<512, 16>(T, wgs, cnt > 8192 ? 8192 : cnt, ko, vo);
+    runm<1024, 16>(T, wgs, cnt, ko, vo); run<1024, 8, 0>(T, wgs, cnt > 8192 ? 8192 : cnt, ko, vo);
     run<1024, 10, 0>(T, wgs, cnt, ko, vo);
     run<1024, 10, 4>(T, wgs, cnt, ko, vo);
     run<1024, 10, 6>(T, wgs, cnt, ko, vo);
