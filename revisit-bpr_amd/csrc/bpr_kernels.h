@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_stream_epilogue(const float* __restrict
 // accumulated delta added atomically instead.  Item rows are shared by everybody → one full-line
 // fp32 atomic add per 128 B of row.
 // ---------------------------------------------------------------------------------------------
-extern __shared__ uint32_t bpr_smem[];
+extern __shared__ __attribute__((aligned(16))) uint32_t bpr_smem[];
 
 // kernel arguments of k_stream only (kept small: every field costs SGPRs for the whole kernel)
 struct StreamArgs {
@@ -331,7 +331,8 @@ void k_stream(const StreamArgs a) {
   const int W = a.bm_words;
   uint32_t* bm = bpr_smem + (threadIdx.x / G) * W;
   if constexpr (BM) {
-    for (int k = gl; k < W; k += G) bm[k] = 0u;
+    uint4* bm4 = reinterpret_cast<uint4*>(bm);
+    for (int k = gl; k < (W >> 2); k += G) bm4[k] = make_uint4(0u, 0u, 0u, 0u);
   }
   int32_t list_n = -1;
   int64_t cur_lo = 0, cur_hi = 0;  // CSR slice of the current user
@@ -369,6 +370,13 @@ void k_stream(const StreamArgs a) {
     if constexpr (SAMPLER == NEG_ADAPTIVE) {
       my_rnd = adaptive_randoms(a.seed, a.offset + (uint64_t)(t0 + gl), a.inv_log1mp,
                                 (int64_t)(a.I - 1) - (my_hi - my_lo));
+    }
+    // uniform: the first Philox block (candidates 0..3) of every triple of the run, all at once
+    u32x4 my_w = {0u, 0u, 0u, 0u};
+    if constexpr (SAMPLER == NEG_UNIFORM) {
+      const uint64_t tc = a.offset + (uint64_t)(t0 + gl);
+      my_w = philox4x32_10((uint32_t)tc, (uint32_t)(tc >> 32), 0u, PURPOSE_UNIFORM,
+                           (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
     }
     const int32_t prev_u = (run_act && t0 > 0) ? group_bcast<G>(my_u, G - 1, lane) : -1;
     const int32_t next_u = (run_act && t1 < a.n) ? group_bcast<G>(my_u, t1 - t0, lane) : -1;
@@ -408,26 +416,37 @@ void k_stream(const StreamArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e) dp[e] = 0.f;
         if constexpr (SAMPLER != NEG_GIVEN) {
-          if constexpr (BM) {  // wipe the previous user's bits (whichever way is shorter)
-            if (cur_hi - cur_lo < (int64_t)W) {
-              for (int64_t k = cur_lo + gl; k < cur_hi; k += G) bm[a.indices[k] >> 5] = 0u;
-            } else {
-              for (int k = gl; k < W; k += G) bm[k] = 0u;
-            }
+          if constexpr (BM) {
+            // wipe: the whole bitmap with 16-byte LDS stores (W is a multiple of 4: 5 stores per
+            // lane for ML-20M) — cheaper than re-reading the previous user's indices from HBM
+            uint4* bm4 = reinterpret_cast<uint4*>(bm);
+            for (int k = gl; k < (W >> 2); k += G) bm4[k] = make_uint4(0u, 0u, 0u, 0u);
           }
           cur_lo = u_lo;
           cur_hi = u_hi;
-          if constexpr (BM) {
-            for (int64_t k = cur_lo + gl; k < cur_hi; k += G) {
-              const int32_t it = a.indices[k];
-              atomicOr(&bm[it >> 5], 1u << (it & 31));
+          if constexpr (BM) {  // set: 4 index loads in flight per trip
+            for (int64_t k = cur_lo + gl; k < cur_hi; k += 4 * G) {
+              int32_t it[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int64_t kk = k + q * G;
+                it[q] = kk < cur_hi ? a.indices[kk] : 0;  // bit 0 of word 0 = the pad item: harmless
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) atomicOr(&bm[it[q] >> 5], 1u << (it[q] & 31));
             }
           }
           if constexpr (SEEN == SEEN_LIST) {
             const int64_t cnt = cur_hi - cur_lo;
             list_n = cnt <= (int64_t)W ? (int32_t)cnt : -1;
-            if (list_n > 0) {
-              for (int32_t k = gl; k < list_n; k += G) bm[k] = (uint32_t)a.indices[cur_lo + k];
+            for (int32_t k = gl; k < list_n; k += 4 * G) {
+              uint32_t it[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                it[q] = k + q * G < list_n ? (uint32_t)a.indices[cur_lo + k + q * G] : 0u;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (k + q * G < list_n) bm[k + q * G] = it[q];
             }
           }
         }
@@ -451,7 +470,20 @@ void k_stream(const StreamArgs a) {
           seen = SeenCsr{a.indices, cur_lo, cur_hi};
         }
         if constexpr (SAMPLER == NEG_UNIFORM) {
-          j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane);
+          // candidates 0..3 were drawn in the run prologue; lanes 0..3 test them.  All four seen
+          // (probability (n_seen / I)^4) -> the general generator, which starts over and rejects
+          // the same four first.
+          const uint32_t w0 = group_bcast<G>(my_w.x, step, lane), w1 = group_bcast<G>(my_w.y, step, lane);
+          const uint32_t w2 = group_bcast<G>(my_w.z, step, lane), w3 = group_bcast<G>(my_w.w, step, lane);
+          const uint32_t wsel = (gl & 2) ? ((gl & 1) ? w3 : w2) : ((gl & 1) ? w1 : w0);
+          const int32_t c = 1 + (int32_t)__umulhi(wsel, (uint32_t)(a.I - 1));
+          const bool is_seen = seen(c);
+          const Ballot b = wave_ballot(gl < 4 && !is_seen);
+          if (group_first<G>(b, lane) >= 0 && step < t1 - t0) {
+            j = group_pick<G>(b, c, lane);
+          } else {
+            j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane);
+          }
         } else {
           const AdaptiveRandoms rnd = {group_bcast<G>(my_rnd.uf, step, lane),
                                        group_bcast<G>(my_rnd.r, step, lane)};

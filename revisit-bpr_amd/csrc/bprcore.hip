@@ -244,7 +244,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     // 131,072 above); larger item tables stage the user's sorted seen list in LDS instead
     // (LIST_CAP entries per group, heavier users search the CSR in HBM).  BPR_SEEN=csr|bitmap|list
     // forces a structure (tests, measurements); a forced bitmap shrinks the block to fit.
-    const int words = (int)((c->I + 31) / 32);
+    const int words = (int)(((c->I + 31) / 32 + 3) / 4 * 4);  // multiple of 4: 16-byte LDS wipes
     const char* force_env = getenv("BPR_SEEN");
     static const bool no_bm = getenv("BPR_NO_BITMAP") != nullptr;
     const std::string force = force_env ? force_env : (no_bm ? "csr" : "");
