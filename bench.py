@@ -180,8 +180,7 @@ def main():
                        offset=(rank << 40) + k * chunk, max_inflight=args.max_inflight,
                        scalars=scalars)
         if sync is not None and (k + 1) % args.sync_every == 0:
-            sync.finish()
-            sync.start()
+            sync.step()
 
     def barrier():
         torch.cuda.synchronize()

@@ -230,6 +230,11 @@ int bpr_item_delta(const float* q, const float* base, float* own, float* tot, in
  * rebase == 1: q  = base              (blocking reconcile: every replica becomes the same cut) */
 int bpr_item_fold(float* q, float* base, const float* own, const float* tot, float scale,
                   int32_t rebase, int64_t n, void* hip_stream);
+/* bpr_item_fold (rebase = 0) immediately followed by bpr_item_delta, as one pass over the table:
+ * the per-period reconciliation step when nothing trains between folding the previous all-reduce
+ * and cutting the next delta.  tot holds the all-reduced sum on entry and the new delta on exit. */
+int bpr_item_fold_delta(float* q, float* base, float* own, float* tot, float scale, int64_t n,
+                        void* hip_stream);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 /* Average duration (ms) of the dominant kernel over the launches recorded since the last reset,

@@ -887,4 +887,24 @@ __global__ __launch_bounds__(256) void k_item_fold(float* __restrict__ q, float*
   }
 }
 
+// fold of the previous reconciliation and cut of the next delta in one pass (nothing trained in
+// between): q += st - own; base += st; own = tot = q - base
+__global__ __launch_bounds__(256) void k_item_fold_delta(float* __restrict__ q,
+                                                         float* __restrict__ base,
+                                                         float* __restrict__ own,
+                                                         float* __restrict__ tot, float scale,
+                                                         int64_t n) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const float st = scale * tot[k];
+    const float nb = base[k] + st;
+    const float nq = q[k] + (st - own[k]);
+    const float dl = nq - nb;
+    base[k] = nb;
+    q[k] = nq;
+    own[k] = dl;
+    tot[k] = dl;
+  }
+}
+
 }  // namespace bpr

@@ -734,6 +734,18 @@ int bpr_item_fold(float* q, float* base, const float* own, const float* tot, flo
   return BPR_OK;
 }
 
+int bpr_item_fold_delta(float* q, float* base, float* own, float* tot, float scale, int64_t n,
+                        void* hip_stream) {
+  if (n < 0 || (n > 0 && (!q || !base || !own || !tot)))
+    return fail(BPR_ERR_INVALID, "bpr_item_fold_delta: bad argument");
+  if (n == 0) return BPR_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 1023) / 1024, 4096);
+  hipLaunchKernelGGL(k_item_fold_delta, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, q, base,
+                     own, tot, scale, n);
+  BPR_HIP_CHECK(hipGetLastError());
+  return BPR_OK;
+}
+
 int bpr_set_hot_rows(bpr_ctx* c, int32_t hot_rows, int32_t replicas) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_hot_rows: ctx is NULL");
   if (hot_rows < 0 || hot_rows > 32768)

@@ -136,6 +136,25 @@ class ItemSync:
         self._pending = True
 
     @torch.no_grad()
+    def step(self) -> None:
+        """finish() of the reconciliation in flight + start() of the next one, with the two
+        elementwise passes fused into one (nothing trains in between)."""
+        if not self._pending:
+            return self.start()
+        if self._lib is None:
+            self.finish()
+            return self.start()
+        torch.cuda.current_stream().wait_stream(self._side)
+        for t, b, own, tot in zip(self.tensors, self.base, self._own, self._tot):
+            self._check(self._lib.bpr_item_fold_delta(t.data_ptr(), b.data_ptr(), own.data_ptr(),
+                                                      tot.data_ptr(), self.scale, t.numel(),
+                                                      torch.cuda.current_stream().cuda_stream))
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            for tot in self._tot:
+                self._all_reduce(tot)
+
+    @torch.no_grad()
     def finish(self, rebase: bool = False) -> None:
         """Fold the other ranks' contributions into the live replicas (one period late): the
         replica keeps what it learned since start(); the base becomes the reconciled cut.

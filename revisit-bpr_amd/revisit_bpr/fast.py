@@ -72,8 +72,7 @@ class StreamTrainer:
             self.drawn += hi - lo
             k += 1
             if self.item_sync is not None and k % self.sync_every == 0:
-                self.item_sync.finish()
-                self.item_sync.start()
+                self.item_sync.step()
         if self.item_sync is not None:
             self.item_sync.finish()
         self.epoch += 1

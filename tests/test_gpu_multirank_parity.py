@@ -41,3 +41,27 @@ def test_two_rank_training_matches_reference_curves(golden_dir, kind):
             ok &= abs(diff) <= tol
     print("\n".join(report))
     assert ok, "\n".join(report)
+
+
+def test_item_sync_fused_step_equals_finish_then_start():
+    """ItemSync.step() (one fused pass, bpr_item_fold_delta) == finish() + start() bit for bit."""
+    import torch
+
+    from revisit_bpr.distributed import ItemSync
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Q0 = torch.randn(3001, 96, device="cuda", generator=g)
+    Qa, Qb = Q0.clone(), Q0.clone()
+    sa, sb = ItemSync([Qa], scale=0.5), ItemSync([Qb], scale=0.5)
+    for k in range(4):
+        upd = torch.randn(3001, 96, device="cuda", generator=g) * 0.01
+        Qa += upd
+        Qb += upd
+        sa.finish()
+        sa.start()
+        sb.step()
+    sa.finish()
+    sb.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(Qa, Qb) and torch.equal(sa.base[0], sb.base[0])
+    assert not torch.equal(Qa, Q0)
