@@ -376,6 +376,44 @@ def test_stream_sequential_limit_equals_b1_sgd(sampler, seen, monkeypatch):
 
 
 @pytest.mark.parametrize("seen", ["", "list", "csr"])
+@pytest.mark.parametrize("d", [8, 32, 50, 64, 128, 256, 1024])
+def test_stream_picks_match_the_oracle_at_full_concurrency(d, seen, monkeypatch):
+    """lr = 0 freezes the tables, so the negatives a full-width grouped STREAM launch draws are a
+    pure function of (seed, offset, triple index, tables): uniform picks must equal the oracle's
+    exactly, adaptive picks up to the rare fp32 bin-edge flips of the factor / rank draw — for
+    every group width / row width combination and every "seen?" structure."""
+    if seen:
+        monkeypatch.setenv("BPR_SEEN", seen)
+    U, I, n = 500, 700, 20000
+    P, Q, indptr, indices, users, pos, _ = rand_problem(U, I, d, 150, seed=40 + d, B=n)
+    P *= 6
+    Q *= 6
+    e = make_engine(P, Q, None, (0.01, 0.01, 0.01))
+    e.bind_seen_csr(dev(indptr), dev(indices))
+    e.set_optimizer(kind=0, lr=0.0)
+    e.set_stream_opts(True, 8)
+    pu, pi = e.plan_epoch(dev(users), dev(pos), n, seed=1)
+    e.adaptive_refresh()
+    QT, sigma = oracle.adaptive_stats(Q)
+    order = oracle.adaptive_order(QT)
+    pun = pu.cpu().numpy()
+    for sampler in (1, 2):
+        negs = torch.zeros(n, dtype=torch.int32, device="cuda")
+        e.train_stream(pu, pi, sampler=sampler, neg=negs, adaptive_p=0.03, seed=77, offset=1000)
+        got = negs.cpu().numpy()
+        if sampler == 1:
+            want = oracle.sample_uniform(indptr, indices, I, pun, seed=77, offset=1000)
+            assert np.array_equal(got, want)
+        else:
+            want, _, _ = oracle.sample_adaptive(P, sigma, order, indptr, indices, pun, 0.03, seed=77,
+                                                offset=1000)
+            assert (got == want).mean() > 0.995, (got == want).mean()
+        for t in range(0, n, 97):
+            assert got[t] != 0 and got[t] not in indices[indptr[pun[t]]:indptr[pun[t] + 1]]
+    assert np.array_equal(e.P.cpu().numpy(), P) and np.array_equal(e.Q.cpu().numpy(), Q)
+
+
+@pytest.mark.parametrize("seen", ["", "list", "csr"])
 def test_stream_full_chip_learns_and_never_picks_seen(seen, monkeypatch):
     """Full-concurrency STREAM on a small synthetic set: loss falls epoch over epoch, sampled
     negatives are valid, tables stay finite, pad rows stay zero."""
