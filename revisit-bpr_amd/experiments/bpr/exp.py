@@ -44,7 +44,8 @@ class BPRExperiment:
                  early_stopping_metric: Optional[str] = None, early_stopping_patience: int = 200,
                  early_stopping_direction: Literal["min", "max"] = "max",
                  neg_sampling_alpha: float = 0.0,
-                 adaptive_sampling_prob: Optional[float] = None) -> None:
+                 adaptive_sampling_prob: Optional[float] = None,
+                 train_mode: Literal["api", "strict", "stream"] = "api") -> None:
         self._config = exp_config if isinstance(exp_config, dict) else exp_config()
         self._dir = Path(dir) if dir is not None else None
         self._datasets_key = datasets_key
@@ -55,6 +56,13 @@ class BPRExperiment:
         self._skip_seen = skip_seen
         self._early = (early_stopping_metric, early_stopping_patience, early_stopping_direction)
         self._adaptive_p = adaptive_sampling_prob
+        if train_mode not in ("api", "strict", "stream"):
+            raise ValueError("train_mode must be 'api', 'strict' or 'stream'")
+        # "api": the reference's per-batch loop (DataLoader -> sampler -> model -> backward -> step);
+        # "strict": the same mini-batches, whole epochs inside the library (any optimizer);
+        # "stream": the fused throughput path (plain SGD only).  Extension: the reference has only
+        # the first.
+        self._train_mode = train_mode
         if neg_sampling_alpha != 0.0:
             raise NotImplementedError("popularity-weighted negatives (neg_sampling_alpha != 0) are "
                                       "not implemented by the device samplers")
@@ -102,9 +110,12 @@ class BPRExperiment:
         else:
             self._sampler = UniformSampler(num_items, self._neg_gen)
         self.trainer = self._build_trainer()
-        if isinstance(self._adaptive_p, float):
+        loaders = self._datasets
+        if self._train_mode != "api":
+            loaders = self._install_fast_epochs(max_iters)
+        elif isinstance(self._adaptive_p, float):
             self._sampler.update_stats()
-        self._state = self.trainer.run(self._datasets, max_iters=max_iters, epochs=cfg["epochs"])
+        self._state = self.trainer.run(loaders, max_iters=max_iters, epochs=cfg["epochs"])
         if self._dir is not None:
             self._dir.mkdir(parents=True, exist_ok=True)
             (self._dir / "history.json").write_text(json.dumps(self.history, indent=1))
@@ -122,12 +133,13 @@ class BPRExperiment:
         cfg = self._config
         trainer = Trainer(self._model, self._optimizer, self._accelerator,
                           custom_engines=cfg.get("custom_engines", {}))
-        if isinstance(self._adaptive_p, float):
-            batch = self._datasets["train"].batch_size or 1
-            every = max(1, int(cfg["num_items"] * math.log(cfg["num_items"]) / batch))
-            trainer.add_event("train", Events.GET_BATCH_COMPLETED(every=every),
-                              lambda: self._sampler.update_stats())
-        trainer.add_event("train", Events.GET_BATCH_COMPLETED, self._train_batch)
+        if self._train_mode == "api":
+            if isinstance(self._adaptive_p, float):
+                batch = self._datasets["train"].batch_size or 1
+                every = max(1, int(cfg["num_items"] * math.log(cfg["num_items"]) / batch))
+                trainer.add_event("train", Events.GET_BATCH_COMPLETED(every=every),
+                                  lambda: self._sampler.update_stats())
+            trainer.add_event("train", Events.GET_BATCH_COMPLETED, self._train_batch)
         trainer.add_event("eval", Events.GET_BATCH_COMPLETED, self._to_device)
         if self._skip_seen:
             trainer.add_event("eval", ModelEvents.FORWARD_COMPLETED, self._remove_seen_items)
@@ -145,6 +157,76 @@ class BPRExperiment:
                 trainer.add_event(key, event, handler, accelerator=self._accelerator)
         self._best, self._bad_evals = None, 0
         return trainer
+
+    # ---- whole epochs inside the library ------------------------------------------------------
+    def _install_fast_epochs(self, max_iters: dict) -> dict:
+        """train_mode "strict" / "stream": the train engine sees ONE pseudo-batch per epoch and its
+        step runs the epoch through bpr_train_strict (same mini-batches as the per-batch loop) or
+        StreamTrainer; events, eval engine, metrics and early stopping are unchanged."""
+        from revisit_bpr import engine as eng
+
+        model, dev = self._model, self._accelerator.device
+        ds = self._datasets["train"].dataset
+        if not hasattr(ds, "_user_ids") or not hasattr(model, "train_strict"):
+            raise NotImplementedError("train_mode needs SparseSamplingInMemoryWithCollator data and "
+                                      "the fused BPR model")
+        batch = self._datasets["train"].batch_size or 1
+        users = ds._user_ids.to(dev, torch.int32)
+        items = ds._item_ids.to(dev, torch.int32)
+        limit = max_iters.pop("train", None)
+        adaptive = isinstance(self._adaptive_p, float)
+        p = self._adaptive_p if adaptive else 0.01
+        num_items = self._config["num_items"]
+        every = max(1, int(num_items * math.log(num_items) / batch)) if adaptive else 0
+        scalars = torch.zeros(4, device=dev)
+        state = {"epoch": 0, "drawn": 0}
+        gen = torch.Generator(device=dev).manual_seed(self._seed)
+        stream = None
+        if self._train_mode == "stream":
+            from revisit_bpr.fast import StreamTrainer
+
+            opt = self._optimizer
+            group = opt.param_groups[0]
+            if type(opt).__name__ != "SGD" or group.get("momentum", 0) != 0:
+                raise NotImplementedError("train_mode='stream' implements plain SGD; use 'strict'")
+            indptr, indices = ds.seen_csr()
+            stream = StreamTrainer(model, users, items, indptr.to(dev), indices.to(dev),
+                                   lr=group["lr"], sampler="adaptive" if adaptive else "uniform",
+                                   adaptive_p=p, batch_size=batch, seed=self._seed)
+
+        def epoch_step(engine, _batch) -> dict:
+            model.train()
+            if stream is not None:
+                stream.engine.set_optimizer(eng.OPT_SGD, lr=self._optimizer.param_groups[0]["lr"])
+                m = stream.train_epoch()
+                n_batches = max(1, math.ceil(m["triples"] / batch))
+                out = {k: torch.tensor(m[k] * m["triples"] / n_batches, device=dev)
+                       for k in ("bpr_loss", "l2_reg")}
+                out["logits"] = torch.tensor([m["logits_diff"]], device=dev)
+            else:
+                perm = torch.randperm(users.numel(), device=dev, generator=gen)
+                if limit is not None:
+                    perm = perm[:limit * batch]
+                if adaptive:
+                    model.engine().adaptive_refresh()
+                scalars.zero_()
+                steps = model.train_strict(self._optimizer, users[perm].contiguous(),
+                                           items[perm].contiguous(), batch,
+                                           eng.NEG_ADAPTIVE if adaptive else eng.NEG_UNIFORM,
+                                           adaptive_p=p, seed=self._seed, offset=state["drawn"],
+                                           refresh_every=every, scalars=scalars)
+                state["drawn"] += perm.numel()
+                sc = scalars.tolist()
+                out = {"bpr_loss": torch.tensor(sc[0] / steps, device=dev),
+                       "l2_reg": torch.tensor(sc[1] / steps, device=dev),
+                       "logits": torch.tensor([sc[2] / max(sc[3], 1.0)], device=dev)}
+            out["loss"] = out["bpr_loss"] + out["l2_reg"]
+            engine.state.metrics["_loss"] += out["loss"]
+            state["epoch"] += 1
+            return out
+
+        self.trainer.engines["train"]._process = epoch_step
+        return {**self._datasets, "train": [{"epoch": True}]}
 
     # ---- handlers ---------------------------------------------------------------------------
     def _to_device(self, engine) -> None:

@@ -203,6 +203,19 @@ class Model(torch.nn.Module):
             eng.discard_grad()
             self._pending = False
             return
+        kind = self._configure_optimizer(optimizer, group)
+        eng.apply()
+        if kind != 0:
+            for prm in self._fused_params():
+                st = optimizer.state[prm]
+                st["step"] = st.get("step", 0) + 1 if not torch.is_tensor(st.get("step")) \
+                    else st["step"] + 1
+        self._pending = self._armed = False
+
+    def _configure_optimizer(self, optimizer, group) -> int:
+        """Mirror a torch.optim optimizer (kind + hyper-parameters of `group`, read on every call so
+        LR changes are honoured) into the engine and bind its state tensors."""
+        eng = self._engine
         name = type(optimizer).__name__
         if name not in _OPT_KINDS:
             raise NotImplementedError(
@@ -224,13 +237,31 @@ class Model(torch.nn.Module):
                               betas=sig[5], eps=sig[6], alpha=sig[7])
             self._bind_state(optimizer, kind)
             self._opt_sig = sig
-        eng.apply()
+        return kind
+
+    def train_strict(self, optimizer, users: torch.Tensor, items: torch.Tensor, batch_size: int,
+                     sampler: int, adaptive_p: float = 0.0, seed: int = 0, offset: int = 0,
+                     refresh_every: int = 0, scalars: Optional[torch.Tensor] = None) -> int:
+        """The reference's inner loop — for batch: sample negatives, model(batch), backward,
+        optimizer.step() — for ALL batches of `users` / `items` (int32, device) inside the library
+        (`bpr_train_strict`): the same mini-batch semantics as the per-batch API, without the
+        Python round trip per batch.  Returns the number of optimizer steps taken."""
+        eng = self.engine()
+        if self._pending:
+            raise RuntimeError("a forward() is waiting for optimizer.step()")
+        groups = [g for g in optimizer.param_groups
+                  if any(id(p) in _FUSED_PARAMS for p in g["params"])]
+        if len(groups) != 1:
+            raise ValueError("the fused tables must sit in exactly one param group")
+        kind = self._configure_optimizer(optimizer, groups[0])
+        eng.train_strict(users, items, batch_size, sampler=sampler, adaptive_p=adaptive_p, seed=seed,
+                         offset=offset, refresh_every=refresh_every, scalars=scalars)
+        steps = (users.numel() + batch_size - 1) // batch_size
         if kind != 0:
             for prm in self._fused_params():
                 st = optimizer.state[prm]
-                st["step"] = st.get("step", 0) + 1 if not torch.is_tensor(st.get("step")) \
-                    else st["step"] + 1
-        self._pending = self._armed = False
+                st["step"] = st.get("step", 0) + steps
+        return steps
 
     def _fused_params(self):
         lm = self.logits_model

@@ -10,8 +10,10 @@ torch = pytest.importorskip("torch")
 CONFIG = Path(__file__).parent / "configs" / "bpr_small.yaml.j2"
 
 
-@pytest.mark.parametrize("variant", ["uniform-sgd-bias", "adaptive-adam"])
-def test_config_run_learns(tmp_path, variant):
+@pytest.mark.parametrize("variant,mode", [("uniform-sgd-bias", "api"), ("adaptive-adam", "api"),
+                                          ("uniform-sgd-bias", "strict"), ("adaptive-adam", "strict"),
+                                          ("uniform-sgd-bias", "stream"), ("adaptive-sgd", "stream")])
+def test_config_run_learns(tmp_path, variant, mode):
     from click.testing import CliRunner
 
     from experiments import run as run_mod
@@ -23,7 +25,10 @@ def test_config_run_learns(tmp_path, variant):
              "embedding_dim=32;train_batch_size=256;epochs=4")
     if variant == "adaptive-adam":
         extra += ";adaptive=1;optimizer=torch.optim.Adam;lr=0.01;item_bias=false"
-    res = CliRunner().invoke(run_mod.main, [str(CONFIG), "--extra-vars", extra, "-d", str(tmp_path / "exp")],
+    if variant == "adaptive-sgd":
+        extra += ";adaptive=1;item_bias=false"
+    res = CliRunner().invoke(run_mod.main, [str(CONFIG), "--extra-vars", extra, "-d", str(tmp_path / "exp"),
+                                            "--train-mode", mode],
                              catch_exceptions=False, standalone_mode=False)
     assert res.exit_code == 0
     exp = res.return_value
