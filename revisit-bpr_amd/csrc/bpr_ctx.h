@@ -33,7 +33,9 @@ struct bpr_ctx {
   int32_t *flagP = nullptr, *flagQ = nullptr;
   int32_t *lastP = nullptr, *lastQ = nullptr;
   uint32_t* touched = nullptr;
-  uint32_t* touched_cnt = nullptr;
+  uint32_t* touched_cnt = nullptr;  // two counters: [cnt_sel] is live, k_apply clears the other
+  int cnt_sel = 0;
+  bool defer_stats = false;  // bpr_train_strict: k_triples accumulates into the partials scratch
   int64_t pending = 0;  // upper bound of entries in `touched`
   int64_t step = 0;     // optimizer steps applied so far
   int64_t flushed_at = 0;

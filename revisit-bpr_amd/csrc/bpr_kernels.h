@@ -49,6 +49,7 @@ struct ApplyArgs {
   int32_t* flagQ;
   const uint32_t* touched;
   const uint32_t* touched_cnt;
+  uint32_t* next_cnt;  // the other half of the double-buffered counter: cleared for the next step
   int64_t U, I;
   int d;
   int pad_user, pad_item;
@@ -146,6 +147,7 @@ struct TripleArgs {
   float* lneg;
   float* scalars;   // caller's 4 floats (non-NULL = statistics wanted)
   float* partials;  // [gridDim.x, 4] per-block partial sums (ctx scratch)
+  int32_t acc_partials;  // 1: add to the block's slot (bpr_train_strict sums once per call)
   // STRICT accumulators
   float* GP;
   float* GQ;
@@ -173,7 +175,8 @@ __device__ __forceinline__ void mark_touched(int32_t* flag, uint32_t row, uint32
 // to the caller's 4 floats with atomics from every wave serialises ~10^4 same-line atomics per
 // launch — measured 0.3 ms — so the final sum is a separate one-block kernel, k_sum_partials.)
 __device__ __forceinline__ void reduce_scalars(float* partials, float s_loss, float s_reg,
-                                               float s_abs, float s_cnt, int lane) {
+                                               float s_abs, float s_cnt, int lane,
+                                               bool accumulate = false) {
   __shared__ float red[4][4];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -193,7 +196,8 @@ __device__ __forceinline__ void reduce_scalars(float* partials, float s_loss, fl
   if (threadIdx.x < 4) {
     float v = 0.f;
     for (int k = 0; k < nw; ++k) v += red[k][threadIdx.x];
-    partials[(int64_t)blockIdx.x * 4 + threadIdx.x] = v;
+    float* slot = partials + (int64_t)blockIdx.x * 4 + threadIdx.x;
+    *slot = accumulate ? *slot + v : v;
   }
 }
 
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(256) void k_triples(const TripleArgs a) {
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int d = a.d;
-  const bool stats = a.scalars != nullptr;
+  const bool stats = a.scalars != nullptr || a.acc_partials != 0;
   float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
 
   for (int64_t base = wave * GPW; base < a.n; base += n_waves * GPW) {
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(256) void k_triples(const TripleArgs a) {
       }
     }
   }
-  if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);
+  if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane, a.acc_partials != 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -738,6 +742,7 @@ __global__ __launch_bounds__(256) void k_apply(const ApplyArgs a) {
   const int gl = lane & (G - 1);
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const uint32_t cnt = *a.touched_cnt;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_cnt = 0u;  // saves a memset launch per step
   if (grp >= (int64_t)cnt) return;
   const uint32_t en = a.touched[grp];
   const bool is_item = (en & 1u) != 0u;
@@ -798,6 +803,7 @@ __global__ __launch_bounds__(256) void k_discard(const ApplyArgs a) {
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_cnt = 0u;
   if (grp >= (int64_t)*a.touched_cnt) return;
   const uint32_t en = a.touched[grp];
   const bool is_item = (en & 1u) != 0u;

@@ -86,7 +86,7 @@ static int ensure_strict_scratch(bpr_ctx* c) {
   BPR_HIP_CHECK(hipMalloc(&c->lastP, sizeof(int32_t) * c->U));
   BPR_HIP_CHECK(hipMalloc(&c->lastQ, sizeof(int32_t) * c->I));
   BPR_HIP_CHECK(hipMalloc(&c->touched, sizeof(uint32_t) * (size_t)(c->U + c->I)));
-  BPR_HIP_CHECK(hipMalloc(&c->touched_cnt, sizeof(uint32_t)));
+  BPR_HIP_CHECK(hipMalloc(&c->touched_cnt, 2 * sizeof(uint32_t)));
   BPR_HIP_CHECK(hipMemsetAsync(c->GP, 0, sizeof(float) * nP, c->stream));
   BPR_HIP_CHECK(hipMemsetAsync(c->GQ, 0, sizeof(float) * nQ, c->stream));
   BPR_HIP_CHECK(hipMemsetAsync(c->Gb, 0, sizeof(float) * c->I, c->stream));
@@ -94,7 +94,8 @@ static int ensure_strict_scratch(bpr_ctx* c) {
   BPR_HIP_CHECK(hipMemsetAsync(c->flagQ, 0, sizeof(int32_t) * c->I, c->stream));
   BPR_HIP_CHECK(hipMemsetAsync(c->lastP, 0, sizeof(int32_t) * c->U, c->stream));
   BPR_HIP_CHECK(hipMemsetAsync(c->lastQ, 0, sizeof(int32_t) * c->I, c->stream));
-  BPR_HIP_CHECK(hipMemsetAsync(c->touched_cnt, 0, sizeof(uint32_t), c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->touched_cnt, 0, 2 * sizeof(uint32_t), c->stream));
+  c->cnt_sel = 0;
   c->pending = 0;
   return BPR_OK;
 }
@@ -120,8 +121,9 @@ static TripleArgs triple_args(const bpr_ctx* c) {
   a.au = c->au; a.ai = c->ai; a.an = c->an;
   a.GP = c->GP; a.GQ = c->GQ; a.Gb = c->Gb;
   a.flagP = c->flagP; a.flagQ = c->flagQ;
-  a.touched = c->touched; a.touched_cnt = c->touched_cnt;
+  a.touched = c->touched; a.touched_cnt = c->touched_cnt + c->cnt_sel;
   a.partials = c->dev_scalars;
+  a.acc_partials = c->defer_stats ? 1 : 0;
   a.mP = c->mP; a.vP = c->vP; a.mQ = c->mQ; a.vQ = c->vQ; a.mb = c->mb; a.vb = c->vb;
   a.lastP = c->lastP; a.lastQ = c->lastQ;
   a.o = opt_dev(c, c->step + 1);
@@ -158,7 +160,8 @@ static ApplyArgs apply_args(const bpr_ctx* c, int64_t t) {
   a.mP = c->mP; a.vP = c->vP; a.mQ = c->mQ; a.vQ = c->vQ; a.mb = c->mb; a.vb = c->vb;
   a.lastP = c->lastP; a.lastQ = c->lastQ;
   a.flagP = c->flagP; a.flagQ = c->flagQ;
-  a.touched = c->touched; a.touched_cnt = c->touched_cnt;
+  a.touched = c->touched; a.touched_cnt = c->touched_cnt + c->cnt_sel;
+  a.next_cnt = c->touched_cnt + (c->cnt_sel ^ 1);
   a.U = c->U; a.I = c->I; a.d = c->d;
   a.pad_user = c->pad_user; a.pad_item = c->pad_item;
   a.o = opt_dev(c, t);
@@ -560,7 +563,7 @@ int bpr_apply(bpr_ctx* c) {
       return BPR_OK;
     });
     if (rc) return rc;
-    BPR_HIP_CHECK(hipMemsetAsync(c->touched_cnt, 0, sizeof(uint32_t), c->stream));
+    c->cnt_sel ^= 1;  // the kernel cleared the other counter
     c->pending = 0;
   }
   return BPR_OK;
@@ -578,7 +581,7 @@ int bpr_discard_grad(bpr_ctx* c) {
     return BPR_OK;
   });
   if (rc) return rc;
-  BPR_HIP_CHECK(hipMemsetAsync(c->touched_cnt, 0, sizeof(uint32_t), c->stream));
+  c->cnt_sel ^= 1;  // the kernel cleared the other counter
   c->pending = 0;
   return BPR_OK;
 }
@@ -695,17 +698,33 @@ int bpr_train_strict(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
   if (int rc = check_sampler(c, "bpr_train_strict", sampler, adaptive_p, neg_scratch, n)) return rc;
   if (sampler != BPR_NEG_GIVEN && neg_scratch == nullptr && n > 0)
     return fail(BPR_ERR_INVALID, "bpr_train_strict: neg_scratch is NULL");
+  // loss statistics: k_triples adds each batch's partial sums to the per-block scratch and ONE
+  // k_sum_partials at the end adds them to out_scalars (instead of one extra launch per batch)
+  const bool defer = out_scalars != nullptr && n > 0;
+  const unsigned stat_blocks = grid_for(B < n ? B : n, c->G, 0);
+  if (defer) {
+    BPR_HIP_CHECK(hipSetDevice(c->device));
+    BPR_HIP_CHECK(hipMemsetAsync(c->dev_scalars, 0, sizeof(float) * 4 * stat_blocks, c->stream));
+    c->defer_stats = true;
+  }
+  int rc = BPR_OK;
   int64_t batch = 0;
-  for (int64_t lo = 0; lo < n; lo += B, ++batch) {
+  for (int64_t lo = 0; lo < n && rc == BPR_OK; lo += B, ++batch) {
     const int64_t b = n - lo < B ? n - lo : B;
     int32_t* neg = sampler == BPR_NEG_GIVEN ? neg_scratch + lo : neg_scratch;
-    if (int rc = bpr_step(c, users + lo, pos + lo, neg, b, BPR_MODE_STRICT, sampler, adaptive_p,
-                          seed, offset + (uint64_t)lo, nullptr, nullptr, out_scalars))
-      return rc;
-    if (refresh_every > 0 && (batch + 1) % refresh_every == 0) {
-      if (int rc = bpr_flush_lazy(c)) return rc;
-      if (int rc = bpr_adaptive_refresh(c)) return rc;
+    rc = bpr_step(c, users + lo, pos + lo, neg, b, BPR_MODE_STRICT, sampler, adaptive_p, seed,
+                  offset + (uint64_t)lo, nullptr, nullptr, nullptr);
+    if (rc == BPR_OK && refresh_every > 0 && (batch + 1) % refresh_every == 0) {
+      rc = bpr_flush_lazy(c);
+      if (rc == BPR_OK) rc = bpr_adaptive_refresh(c);
     }
+  }
+  c->defer_stats = false;
+  if (rc != BPR_OK) return rc;
+  if (defer) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->dev_scalars,
+                       (int)stat_blocks, out_scalars);
+    BPR_HIP_CHECK(hipGetLastError());
   }
   return BPR_OK;
 }
