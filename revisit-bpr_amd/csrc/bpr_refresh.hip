@@ -174,10 +174,13 @@ __global__ __launch_bounds__(1024) void k_sort_sub(const float* __restrict__ T, 
 // search in LDS and merges serially out of LDS; results go back through LDS so the stores are
 // coalesced as well.  LDS indices are padded by one word per 16 so the threads' serial walks spread
 // over the banks.  HBM traffic: keys + ids read once, written once (ids only on the last level).
-constexpr int MERGE_PER_THREAD = 16;
+#ifndef BPR_MERGE_PER_THREAD
+#define BPR_MERGE_PER_THREAD 16
+#endif
+constexpr int MERGE_PER_THREAD = BPR_MERGE_PER_THREAD;
 constexpr int MERGE_THREADS = 256;
 constexpr int MERGE_TILE = MERGE_THREADS * MERGE_PER_THREAD;
-__device__ __forceinline__ int merge_pad(int k) { return k + (k >> 4); }
+__device__ __forceinline__ int merge_pad(int k) { return k + k / MERGE_PER_THREAD; }
 
 // number of elements the first `k` merged outputs take from run A (lenA) — B (lenB) gets k - that
 template <typename KeyA, typename KeyB>
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_runs(
     const float* __restrict__ keys_in, const int32_t* __restrict__ ids_in, int64_t I, int64_t run,
     int tiles_per_pair, float* __restrict__ keys_out, int32_t* __restrict__ ids_out, int last,
     float* __restrict__ sigma, const double* __restrict__ sig_acc) {
-  __shared__ float lk[MERGE_TILE + MERGE_TILE / 16 + 1];
-  __shared__ int32_t lv[MERGE_TILE + MERGE_TILE / 16 + 1];
+  __shared__ float lk[MERGE_TILE + MERGE_THREADS + 1];
+  __shared__ int32_t lv[MERGE_TILE + MERGE_THREADS + 1];
   __shared__ int64_t cut[2];
   const int f = blockIdx.y;
   const int t = threadIdx.x;
@@ -216,10 +219,31 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_runs(
   const int64_t k1 = min(k0 + MERGE_TILE, lenA + lenB);
   const float* K = keys_in + (int64_t)f * I;
   const int32_t* V = ids_in + (int64_t)f * I;
-  if (t == 0 || t == 64) {
-    const int64_t k = t == 0 ? k0 : k1;
-    cut[t >> 6] = merge_split(k, lenA, lenB, [&](int64_t x) { return K[a0 + x]; },
-                              [&](int64_t x) { return K[b0 + x]; });
+  if (t < 128) {
+    // 64-ary diagonal search in HBM: wave 0 finds the start of the tile, wave 1 its end.  The
+    // predicate "A(x) >= B(k-x-1)" is true on a prefix of [lo, hi); every lane probes one point per
+    // step, so the interval shrinks 65-fold per round trip (3 instead of 17 dependent loads).
+    const int l = t & 63;
+    const int64_t k = t < 64 ? k0 : k1;
+    int64_t lo = max((int64_t)0, k - lenB), hi = min(k, lenA);
+    while (lo < hi) {
+      const int64_t span = hi - lo;
+      const bool fine = span <= 64;  // last step: one lane per remaining position
+      const int64_t x = fine ? lo + l : lo + (int64_t)(l + 1) * span / 65;
+      const bool in = x < hi;
+      const bool pred = in && K[a0 + x] >= K[b0 + (k - x - 1)];
+      const int c = __popcll(__ballot(pred));  // trues form a prefix of the probes
+      if (fine) {
+        lo += c;
+        hi = lo;
+      } else {
+        const int64_t below = c == 0 ? lo : lo + (int64_t)c * span / 65 + 1;
+        const int64_t above = c == 64 ? hi : lo + (int64_t)(c + 1) * span / 65;
+        lo = below;
+        hi = above;
+      }
+    }
+    if (l == 0) cut[t >> 6] = lo;
   }
   __syncthreads();
   const int64_t a_lo = cut[0], a_hi = cut[1];
@@ -554,7 +578,7 @@ int refresh_impl(bpr_ctx* c) {
   while (sub < 4 && d * sub < 256 && I / (2 * sub) >= 5000) sub *= 2;
   if (force_sub == 1 || force_sub == 2 || force_sub == 4) sub = force_sub;
   int64_t len = (I + sub - 1) / sub;
-  len = (len + MERGE_PER_THREAD - 1) / MERGE_PER_THREAD * MERGE_PER_THREAD;
+  len = (len + 15) / 16 * 16;
   if (len <= 1024 * 36 && !no_fast) {
     float* keysA = reinterpret_cast<float*>(c->keys_sorted);
     int32_t* idsA = reinterpret_cast<int32_t*>(keysA + n);
