@@ -93,8 +93,6 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("BPR_DIST_BACKEND", "nccl")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-        if mode != "stream":
-            raise SystemExit("multi-GPU training uses --mode stream")
     if synthetic_name:
         data = synthetic.generate_named(synthetic_name, eval_users=10_000, seed=seed)
         num_users, num_items = data.num_users, data.num_items
@@ -126,6 +124,20 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
         trainer = StreamTrainer(model, users_t, items_t, t["indptr"], t["indices"], lr=lr,
                                 sampler="adaptive", adaptive_p=sampling_prob,
                                 batch_size=batch_size, seed=seed, rank=rank, item_sync=sync)
+        run_epoch = trainer.train_epoch
+    elif world > 1:  # reference mini-batches per user shard, item table reconciled by ItemSync
+        from revisit_bpr.distributed import ItemSync, balanced_user_shards, owner_of
+        from revisit_bpr.fast import StrictTrainer
+
+        bounds = balanced_user_shards(data.indptr, world)
+        mine = torch.from_numpy(owner_of(data.users, bounds) == rank).to(dev)
+        f = model.logits_model.get_features()
+        sync = ItemSync([f["item"].data] + ([f["item_bias"].data] if f["item_bias"] is not None else []))
+        optimizer = torch.optim.SGD(model.parameters(), lr=lr)
+        trainer = StrictTrainer(model, optimizer, t["users"][mine].contiguous(),
+                                t["items"][mine].contiguous(), t["indptr"], t["indices"],
+                                sampler="adaptive", adaptive_p=sampling_prob, batch_size=batch_size,
+                                seed=seed, rank=rank, item_sync=sync)
         run_epoch = trainer.train_epoch
     else:
         model.bind_seen_csr(t["indptr"], t["indices"])

@@ -80,3 +80,72 @@ class StreamTrainer:
         cnt = max(sc[3], 1.0)
         return {"bpr_loss": sc[0] / cnt, "l2_reg": sc[1] / cnt, "logits_diff": sc[2] / cnt,
                 "loss": (sc[0] + sc[1]) / cnt, "triples": int(sc[3])}
+
+
+class StrictTrainer:
+    """Epochs of the reference's exact mini-batch loop (sample → model(batch) → backward →
+    optimizer.step()) inside the library, for every optimizer the engine mirrors (SGD, momentum /
+    Nesterov, Adam, RMSprop — the dense torch.optim semantics, see Model.train_strict).
+
+    One GPU: one `bpr_train_strict` call per epoch.  Several: every rank runs the mini-batches of
+    its own user shard and the replicated item table is reconciled by `item_sync` every
+    refresh period / world batches (the STREAM cadence); optimizer state of the item table stays
+    local to the rank, rows are brought to "now" (lazy replay flushed) before every reconciliation."""
+
+    def __init__(self, model, optimizer, users: torch.Tensor, items: torch.Tensor,
+                 seen_indptr: torch.Tensor, seen_indices: torch.Tensor, sampler: str = "adaptive",
+                 adaptive_p: float = 0.01, batch_size: int = 256, seed: int = 13, rank: int = 0,
+                 item_sync=None, world: Optional[int] = None) -> None:
+        if users.dtype != torch.int32 or items.dtype != torch.int32:
+            raise ValueError("users / items must be int32 device tensors")
+        self.model, self.optimizer = model, optimizer
+        self.engine = model.engine()
+        self.users, self.items = users.contiguous(), items.contiguous()
+        self.n = users.numel()
+        model.bind_seen_csr(seen_indptr, seen_indices)
+        self.sampler = {"adaptive": eng.NEG_ADAPTIVE, "uniform": eng.NEG_UNIFORM}[sampler]
+        self.adaptive_p, self.batch = adaptive_p, batch_size
+        I = self.engine.I
+        self.every = max(1, int(I * math.log(I) / batch_size))
+        if world is None:
+            world = item_sync.world if item_sync is not None else 1
+        self.item_sync = item_sync
+        self.chunk_batches = max(1, self.every // max(world, 1))
+        self.seed, self.rank = seed, rank
+        self.gen = torch.Generator(device=users.device).manual_seed(seed * 1000003 + rank)
+        self.drawn = 0
+        self._scalars = torch.zeros(4, dtype=torch.float32, device=users.device)
+        self._fresh = False
+
+    def train_epoch(self) -> dict:
+        model, e, B = self.model, self.engine, self.batch
+        model.train()
+        perm = torch.randperm(self.n, device=self.users.device, generator=self.gen)
+        u, i = self.users[perm].contiguous(), self.items[perm].contiguous()
+        adaptive = self.sampler == eng.NEG_ADAPTIVE
+        self._scalars.zero_()
+        if adaptive and not self._fresh:
+            e.adaptive_refresh()
+            self._fresh = True
+        if self.item_sync is None:
+            model.train_strict(self.optimizer, u, i, B, self.sampler, adaptive_p=self.adaptive_p,
+                               seed=self.seed, offset=(self.rank << 40) + self.drawn,
+                               refresh_every=self.every if adaptive else 0, scalars=self._scalars)
+        else:
+            step = self.chunk_batches * B
+            for lo in range(0, self.n, step):
+                hi = min(lo + step, self.n)
+                model.train_strict(self.optimizer, u[lo:hi], i[lo:hi], B, self.sampler,
+                                   adaptive_p=self.adaptive_p, seed=self.seed,
+                                   offset=(self.rank << 40) + self.drawn + lo, refresh_every=0,
+                                   scalars=self._scalars)
+                e.flush_lazy()
+                self.item_sync.step()
+                if adaptive:
+                    e.adaptive_refresh()
+            self.item_sync.finish()
+        self.drawn += self.n
+        sc = self._scalars.tolist()
+        cnt = max(sc[3], 1.0)
+        return {"bpr_loss": sc[0] / cnt, "l2_reg": sc[1] / cnt, "logits_diff": sc[2] / cnt,
+                "loss": (sc[0] + sc[1]) / cnt, "triples": int(sc[3])}

@@ -34,7 +34,8 @@ def test_example_cli_runs_and_learns(tmp_path, mode, caplog):
     assert len(nd) == 4 and nd[-1] > nd[0] and nd[-1] > 0.08, nd
 
 
-def test_example_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("mode", ["stream", "strict"])
+def test_example_two_ranks_on_one_gpu(tmp_path, mode):
     """The multi-GPU path of example.py (user shards + ItemSync) with two ranks sharing cuda:0 over
     gloo — a functional check of sharding, delta all-reduce and the user-row gather; RCCL needs one
     device per rank, the protocol is the same."""
@@ -50,9 +51,10 @@ def test_example_two_ranks_on_one_gpu(tmp_path):
     root = Path(__file__).resolve().parents[1]
     env = dict(os.environ, BPR_DIST_BACKEND="gloo", PYTHONPATH=str(root / "revisit-bpr_amd"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29611", str(root / "revisit-bpr_amd" / "example.py"),
+           "--master-addr", "127.0.0.1", "--master-port", {"stream": "29611", "strict": "29612"}[mode], str(root / "revisit-bpr_amd" / "example.py"),
            str(tmp_path), "--num-users", str(data.num_users), "--num-items", str(data.num_items),
-           "--embedding-dim", "32", "--epochs", "4", "--lr", "0.05", "--sampling-prob", "0.05"]
+           "--embedding-dim", "32", "--epochs", "4", "--lr", "0.05", "--sampling-prob", "0.05",
+           "--mode", mode]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     nd = [float(line.rsplit("|", 1)[1]) for line in res.stderr.splitlines() if "ndcg@100" in line]

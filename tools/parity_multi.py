@@ -16,7 +16,7 @@ import torch.distributed as dist  # noqa: E402
 
 from revisit_bpr.distributed import ItemSync, balanced_user_shards, owner_of  # noqa: E402
 from revisit_bpr.evaluation import evaluate_topk  # noqa: E402
-from revisit_bpr.fast import StreamTrainer  # noqa: E402
+from revisit_bpr.fast import StreamTrainer, StrictTrainer  # noqa: E402
 from revisit_bpr.models import BPR  # noqa: E402
 from revisit_bpr.models.bpr import MF  # noqa: E402
 
@@ -24,6 +24,7 @@ from revisit_bpr.models.bpr import MF  # noqa: E402
 def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "uniform"
     seeds = [int(s) for s in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2", "3"])]
+    mode = sys.argv[3] if len(sys.argv) > 3 else "stream"  # "stream" (SGD) | "adam" (STRICT, Adam)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -33,7 +34,19 @@ def main():
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     ref = json.loads((ROOT / "tests/golden/e2e_reference.json").read_text())
     cfg = ref["config"]
-    d = np.load(ROOT / "tests/golden/e2e_data.npz")
+    if len(sys.argv) > 4 and sys.argv[4] == "full":  # ML-20M-shaped latent-structure set, d=128
+        from revisit_bpr.datasets import synthetic
+
+        data = synthetic.generate_latent(136677, 20108, 9_700_000, factors=16, strength=1.2,
+                                         median_per_user=37, min_per_user=5, seed=13,
+                                         eval_users=10_000, item_skew=1.2, item_shift=60.0)
+        d = {k: getattr(data, k) for k in ("users", "items", "indptr", "indices", "eval_users",
+                                           "eval_indptr", "eval_items")}
+        d["num_users"], d["num_items"] = data.num_users, data.num_items
+        cfg = dict(cfg, d=128, B=256, epochs=int(os.environ.get("BPR_EPOCHS", "4")), lr=0.05,
+                   adaptive_p=0.01, reg={"user": 0.0016, "item": 0.0001, "neg": 0.00375})
+    else:
+        d = np.load(ROOT / "tests/golden/e2e_data.npz")
     U, I = int(d["num_users"]), int(d["num_items"])
     t = {k: torch.from_numpy(d[k]).to(dev) for k in ("users", "items", "indptr", "indices", "eval_users",
                                                      "eval_indptr", "eval_items")}
@@ -46,10 +59,17 @@ def main():
                                     torch.nn.Embedding(I, cfg["d"], padding_idx=0))).to(dev)
         f = model.logits_model.get_features()
         sync = ItemSync([f["item"].data]) if world > 1 else None
-        tr = StreamTrainer(model, t["users"][mine].contiguous(), t["items"][mine].contiguous(),
-                           t["indptr"], t["indices"], lr=cfg["lr"], sampler=kind,
-                           adaptive_p=cfg["adaptive_p"], batch_size=cfg["B"], seed=seed, rank=rank,
-                           item_sync=sync)
+        if mode in ("adam", "sgd"):
+            opt = (torch.optim.Adam(model.parameters(), lr=float(os.environ.get("BPR_ADAM_LR", "0.002")))
+                   if mode == "adam" else torch.optim.SGD(model.parameters(), lr=cfg["lr"]))
+            tr = StrictTrainer(model, opt, t["users"][mine].contiguous(), t["items"][mine].contiguous(),
+                               t["indptr"], t["indices"], sampler=kind, adaptive_p=cfg["adaptive_p"],
+                               batch_size=cfg["B"], seed=seed, rank=rank, item_sync=sync)
+        else:
+            tr = StreamTrainer(model, t["users"][mine].contiguous(), t["items"][mine].contiguous(),
+                               t["indptr"], t["indices"], lr=cfg["lr"], sampler=kind,
+                               adaptive_p=cfg["adaptive_p"], batch_size=cfg["B"], seed=seed, rank=rank,
+                               item_sync=sync)
         curve = []
         for _ in range(cfg["epochs"]):
             tr.train_epoch()
@@ -58,12 +78,14 @@ def main():
                     lo, hi = int(bounds[r]), int(bounds[r + 1])
                     if hi > lo:
                         dist.broadcast(f["user"].data[lo:hi], src=r)
+            if mode in ("adam", "sgd"):
+                model.sync()  # bring lazily-updated rows to "now" before reading the tables
             if rank == 0:
                 m = evaluate_topk(f["user"].data, f["item"].data, None, t["eval_users"], t["eval_indptr"],
                                   t["eval_items"], t["indptr"], t["indices"], ks=(20, 100))
                 curve.append((m["ndcg@100"], m["recall@20"]))
         if rank == 0:
-            print(json.dumps({"kind": kind, "seed": seed, "world": world,
+            print(json.dumps({"kind": kind, "seed": seed, "world": world, "mode": mode,
                               "ndcg@100": [c[0] for c in curve], "recall@20": [c[1] for c in curve]}),
                   flush=True)
     if world > 1:
