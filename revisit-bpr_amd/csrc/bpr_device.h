@@ -86,17 +86,6 @@ template <int G>
 __device__ __forceinline__ float group_sum(float v, int lane) {
   return group_last<G>(group_scan_incl<G>(v), lane);
 }
-// ballot restricted to the caller's group, bit k = lane k of the group
-template <int G>
-__device__ __forceinline__ uint64_t group_ballot(bool pred, int lane) {
-  const uint64_t full = __ballot(pred);
-  if constexpr (G == 64) {
-    return full;
-  } else {
-    static_assert(G == 32, "groups are half or whole waves");
-    return (lane & 32) ? (uint64_t)(uint32_t)(full >> 32) : (uint64_t)(uint32_t)full;
-  }
-}
 // value held by lane `src` of the caller's group
 template <int G, typename T>
 __device__ __forceinline__ T group_bcast(T v, int src, int lane) {
