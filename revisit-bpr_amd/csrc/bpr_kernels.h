@@ -87,6 +87,60 @@ __device__ __forceinline__ void opt_replay(float& w, float& m, float& v, int64_t
   }
 }
 
+// The same k zero-gradient steps for the E elements a lane holds of ONE row: the per-step scalars
+// (bias corrections — double-precision exp / divide / sqrt) are computed once per step instead of
+// once per element and step; element arithmetic is identical to opt_replay, bit for bit.
+template <int E>
+__device__ __forceinline__ void opt_replay_row(float (&w)[E], float (&m)[E], float (&v)[E],
+                                               int64_t s0, int64_t k, const OptDev& o) {
+  if (k <= 0) return;
+  if (o.kind == OPT_MOMENTUM) {
+    const float muk = (float)exp((double)k * o.log_mu);
+    const float c = o.nesterov ? o.mu : 1.0f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      w[e] -= o.lr * c * m[e] * o.mu * (1.0f - muk) / (1.0f - o.mu);
+      m[e] *= muk;
+    }
+  } else if (o.kind == OPT_ADAM) {
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < E; ++e) any |= m[e] != 0.f;
+    if (any) {
+      double b1p = exp((double)s0 * o.log_b1), b2p = exp((double)s0 * o.log_b2);
+      float ms[E], vs[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        ms[e] = m[e];
+        vs[e] = v[e];
+      }
+      const int64_t kk = k < (int64_t)o.kmax ? k : (int64_t)o.kmax;
+      for (int64_t s = 0; s < kk; ++s) {
+        b1p *= (double)o.b1;
+        b2p *= (double)o.b2;
+        const float step = (float)((double)o.lr / (1.0 - b1p));
+        const float bc2 = (float)sqrt(1.0 - b2p);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          ms[e] *= o.b1;
+          vs[e] *= o.b2;
+          if (m[e] != 0.f) w[e] -= step * (ms[e] / (sqrtf(vs[e]) / bc2 + o.eps));
+        }
+      }
+    }
+    const float mk = (float)exp((double)k * o.log_b1), vk = (float)exp((double)k * o.log_b2);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      m[e] *= mk;
+      v[e] *= vk;
+    }
+  } else if (o.kind == OPT_RMSPROP) {
+    const float ak = (float)exp((double)k * o.log_alpha);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] *= ak;
+  }
+}
+
 // the step with gradient g (torch.optim single-tensor formulas, pinned via the oracle)
 __device__ __forceinline__ void opt_update(float& w, float g, float& m, float& v, const OptDev& o,
                                            float adam_step, float adam_bc2_sqrt) {
@@ -119,14 +173,14 @@ __device__ __forceinline__ void catch_up_row(float (&r)[E], const float* __restr
                                              const float* __restrict__ V, int64_t row, int d,
                                              int gl, int64_t s0, int64_t k, const OptDev& o) {
   if (k <= 0) return;
+  float m[E], v[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int f = e * G + gl;
-    if (f >= d) continue;
-    float m = M != nullptr ? M[row * d + f] : 0.f;
-    float v = V != nullptr ? V[row * d + f] : 0.f;
-    opt_replay(r[e], m, v, s0, k, o);
+    m[e] = (M != nullptr && f < d) ? M[row * d + f] : 0.f;
+    v[e] = (V != nullptr && f < d) ? V[row * d + f] : 0.f;
   }
+  opt_replay_row<E>(r, m, v, s0, k, o);
 }
 
 struct TripleArgs {
@@ -765,20 +819,26 @@ __global__ __launch_bounds__(256) void k_apply(const ApplyArgs a) {
     adam_bc2_sqrt = (float)sqrt(1.0 - exp((double)o.t * o.log_b2));
   }
   if (row != pad) {
+    float w[E], g[E], m[E], v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int f = e * G + gl;
+      const bool in = f < d;
+      w[e] = in ? W[f] : 0.f;
+      g[e] = in ? Gr[f] : 0.f;
+      m[e] = (in && M != nullptr) ? M[row * d + f] : 0.f;
+      v[e] = (in && V != nullptr) ? V[row * d + f] : 0.f;
+    }
+    opt_replay_row<E>(w, m, v, s0, k, o);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int f = e * G + gl;
       if (f >= d) continue;
-      float w = W[f];
-      const float g = Gr[f];
-      float m = M != nullptr ? M[row * d + f] : 0.f;
-      float v = V != nullptr ? V[row * d + f] : 0.f;
-      opt_replay(w, m, v, s0, k, o);
-      opt_update(w, g, m, v, o, adam_step, adam_bc2_sqrt);
-      W[f] = w;
+      opt_update(w[e], g[e], m[e], v[e], o, adam_step, adam_bc2_sqrt);
+      W[f] = w[e];
       Gr[f] = 0.f;
-      if (M != nullptr) M[row * d + f] = m;
-      if (V != nullptr) V[row * d + f] = v;
+      if (M != nullptr) M[row * d + f] = m[e];
+      if (V != nullptr) V[row * d + f] = v[e];
     }
   }
   if (gl == 0) {
@@ -838,17 +898,23 @@ __global__ __launch_bounds__(256) void k_flush_lazy(const ApplyArgs a, const int
     const int64_t s0 = last[row];
     const int64_t k = o.t - s0;
     if (k <= 0) continue;
+    float w[E], m[E], v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int f = e * G + gl;
+      const bool in = f < d;
+      w[e] = in ? Wt[row * d + f] : 0.f;
+      m[e] = (in && M != nullptr) ? M[row * d + f] : 0.f;
+      v[e] = (in && V != nullptr) ? V[row * d + f] : 0.f;
+    }
+    opt_replay_row<E>(w, m, v, s0, k, o);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int f = e * G + gl;
       if (f >= d) continue;
-      float w = Wt[row * d + f];
-      float m = M != nullptr ? M[row * d + f] : 0.f;
-      float v = V != nullptr ? V[row * d + f] : 0.f;
-      opt_replay(w, m, v, s0, k, o);
-      Wt[row * d + f] = w;
-      if (M != nullptr) M[row * d + f] = m;
-      if (V != nullptr) V[row * d + f] = v;
+      Wt[row * d + f] = w[e];
+      if (M != nullptr) M[row * d + f] = m[e];
+      if (V != nullptr) V[row * d + f] = v[e];
     }
     if (gl == 0) {
       if (is_item && a.bias != nullptr) {
