@@ -745,11 +745,16 @@ struct SampleArgs {
   const float *mP, *vP;
   const int32_t* lastP;
   OptDev o;
+  int32_t bm_words;  // words per group of the LDS seen-bitmap (k_sample<..., BM = true>)
 };
 
 enum { SAMPLE_UNIFORM = 0, SAMPLE_ADAPTIVE = 1, SAMPLE_PICK = 2 };
 
-template <int G, int E, int WHAT>
+// BM: the walk's "seen?" tests go to a per-group LDS bitmap of the user's seen items (dynamic LDS,
+// a.bm_words words per group) built once per pick with 8 index loads in flight — a launch lasts
+// as long as its slowest pick, and that is a user with thousands of seen items whose candidates
+// would otherwise each cost a binary search of dependent HBM loads.
+template <int G, int E, int WHAT, bool BM>
 __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
   constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -763,7 +768,23 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
     const int64_t tt = act ? t : a.n - 1;
     const int32_t u = a.users[tt];
     const int64_t lo = a.indptr[u], hi = a.indptr[u + 1];
-    const SeenCsr seen{a.indices, lo, hi};
+    using Seen = typename std::conditional<BM, SeenBitmap, SeenCsr>::type;
+    Seen seen;
+    if constexpr (BM) {
+      uint32_t* bm = bpr_smem + (threadIdx.x / G) * a.bm_words;
+      uint4* bm4 = reinterpret_cast<uint4*>(bm);
+      for (int k = gl; k < (a.bm_words >> 2); k += G) bm4[k] = make_uint4(0u, 0u, 0u, 0u);
+      for (int64_t k = lo + gl; k < hi; k += 8 * G) {
+        int32_t it[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) it[q] = k + q * G < hi ? a.indices[k + q * G] : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) atomicOr(&bm[it[q] >> 5], 1u << (it[q] & 31));
+      }
+      seen = SeenBitmap{bm};
+    } else {
+      seen = SeenCsr{a.indices, lo, hi};
+    }
     if constexpr (WHAT == SAMPLE_UNIFORM) {
       const int32_t j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane);
       if (act && gl == 0) a.neg[t] = j;

@@ -431,13 +431,42 @@ static int launch_sample(bpr_ctx* c, int what, SampleArgs a) {
     using T = decltype(tag);
     constexpr int G = T::G, E = T::E;
     const unsigned grid = grid_for(a.n, G, 0);
+    // adaptive picks walk hundreds of candidates: an LDS seen-bitmap per group when the block's
+    // bitmaps fit 64 KiB; the uniform sampler tests a handful and searches the CSR directly
+    const int words = (int)(((c->I + 31) / 32 + 3) / 4 * 4);
+    const size_t lds = (size_t)(256 / G) * words * sizeof(uint32_t);
+    static const bool no_bm = getenv("BPR_NO_BITMAP") != nullptr;
+    // (one block per CU is plenty for a single batch, so the bitmaps may take most of the 160 KB)
+    constexpr size_t SAMPLE_LDS_MAX = 144 * 1024;
+    const bool bm = what != SAMPLE_UNIFORM && lds <= SAMPLE_LDS_MAX && !no_bm;
+    a.bm_words = bm ? words : 0;
+    if (bm && lds > 64 * 1024) {
+      static bool raised = false;  // per (G, E) instantiation of this lambda
+      if (!raised) {
+        BPR_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&k_sample<G, E, SAMPLE_ADAPTIVE, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLE_LDS_MAX));
+        BPR_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&k_sample<G, E, SAMPLE_PICK, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMPLE_LDS_MAX));
+        raised = true;
+      }
+    }
     if (what == SAMPLE_UNIFORM)
-      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_UNIFORM>), dim3(grid), dim3(256), 0, c->stream, a);
+      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_UNIFORM, false>), dim3(grid), dim3(256), 0,
+                         c->stream, a);
+    else if (what == SAMPLE_ADAPTIVE && bm)
+      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_ADAPTIVE, true>), dim3(grid), dim3(256), lds,
+                         c->stream, a);
     else if (what == SAMPLE_ADAPTIVE)
-      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_ADAPTIVE>), dim3(grid), dim3(256), 0, c->stream,
+      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_ADAPTIVE, false>), dim3(grid), dim3(256), 0,
+                         c->stream, a);
+    else if (bm)
+      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_PICK, true>), dim3(grid), dim3(256), lds, c->stream,
                          a);
     else
-      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_PICK>), dim3(grid), dim3(256), 0, c->stream, a);
+      hipLaunchKernelGGL((k_sample<G, E, SAMPLE_PICK, false>), dim3(grid), dim3(256), 0, c->stream,
+                         a);
     BPR_HIP_CHECK(hipGetLastError());
     return BPR_OK;
   });

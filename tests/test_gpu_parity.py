@@ -302,6 +302,25 @@ def test_samplers_with_heavy_users(d):
                                               int(rnk[b]))
 
 
+@pytest.mark.parametrize("I,d", [(100_003, 8), (150_001, 200), (150_001, 8)])
+def test_adaptive_sampler_large_item_tables(I, d):
+    """Item tables whose per-group seen-bitmaps need more than the default 64 KiB of dynamic LDS
+    (8 groups x 100 k bits = 100 KB; 4 groups x 150 k bits = 75 KB at d > 128) or do not fit at all
+    (8 groups x 150 k bits: binary search in the CSR)."""
+    U, B = 60, 1500
+    P, Q, indptr, indices, users, _, _ = rand_problem(U, I, d, 3000, seed=7 + d, B=B)
+    e = make_engine(P, Q)
+    e.bind_seen_csr(dev(indptr), dev(indices))
+    e.adaptive_refresh()
+    neg, fac, rnk = (t.cpu().numpy() for t in
+                     e.sample_adaptive(dev(users), 0.01, seed=3, offset=9, return_draws=True))
+    QT, _ = oracle.adaptive_stats(Q)
+    order = oracle.adaptive_order(QT)
+    for b in range(0, B, 5):
+        assert neg[b] == oracle.adaptive_pick(order, indptr, indices, int(users[b]), int(fac[b]),
+                                              int(rnk[b]))
+
+
 # ------------------------------------------------------------------------------------------------
 # STREAM mode
 # ------------------------------------------------------------------------------------------------
