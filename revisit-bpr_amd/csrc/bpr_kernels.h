@@ -108,21 +108,26 @@ __device__ __forceinline__ void opt_replay_row(float (&w)[E], float (&m)[E], flo
     for (int e = 0; e < E; ++e) any |= m[e] != 0.f;
     if (any) {
       double b1p = exp((double)s0 * o.log_b1), b2p = exp((double)s0 * o.log_b2);
-      float ms[E], vs[E];
+      // ms = m b1^s and sv = sqrt(v b2^s) = sqrt(v) sqrt(b2)^s are carried as float products
+      float ms[E], sv[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         ms[e] = m[e];
-        vs[e] = v[e];
+        sv[e] = sqrtf(v[e]);
       }
+      const float sqrt_b2 = (float)sqrt((double)o.b2);
       const int kk = (int)(k < (int64_t)o.kmax ? k : (int64_t)o.kmax);
       // With the default beta1 = 0.9 a row untouched for a while replays 176 steps, and these
-      // single-batch kernels run one wave per SIMD: the loop is bound by its instruction count.
-      // The powers are carried in double (a float product drifts over hundreds of steps) and
-      // 1 - beta^t is formed in double (it cancels for small t); everything after that uses the
-      // hardware's 1-ulp v_rcp / v_sqrt instead of correctly rounded divide / sqrt sequences
-      // (7 instead of ~45 instructions per element and step).  The terms are independent given
-      // (m, v), so the error does not compound: ~1e-7 of the replayed movement, far inside the
-      // 2e-6 parity tolerance; the optimizer step itself (opt_update) stays exactly rounded.
+      // single-batch kernels run one wave per SIMD: the loop is bound by its instruction count and
+      // by the quarter-rate transcendental unit.  The bias-correction powers are carried in double
+      // (1 - beta^t cancels for small t); everything after that uses the hardware's 1-ulp v_rcp /
+      // v_rsq instead of correctly rounded divide / sqrt sequences, and one multiply replaces the
+      // square root per element and step (6 instead of ~45 instructions per element and step, one
+      // transcendental instead of three).  The terms are independent given (m, v), so the error
+      // does not compound beyond the float products' drift (~1e-6 of the replayed movement, itself
+      // ~1e-2 of a weight: far inside the 2e-6 parity tolerance); the optimizer step itself
+      // (opt_update) stays exactly rounded.
+#pragma unroll 4
       for (int s = 0; s < kk; ++s) {
         b1p *= (double)o.b1;
         b2p *= (double)o.b2;
@@ -131,8 +136,8 @@ __device__ __forceinline__ void opt_replay_row(float (&w)[E], float (&m)[E], flo
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           ms[e] *= o.b1;
-          vs[e] *= o.b2;
-          const float denom = fmaf(__builtin_amdgcn_sqrtf(vs[e]), inv_bc2, o.eps);
+          sv[e] *= sqrt_b2;
+          const float denom = fmaf(sv[e], inv_bc2, o.eps);
           if (m[e] != 0.f) w[e] -= step * (ms[e] * __builtin_amdgcn_rcpf(denom));
         }
       }
