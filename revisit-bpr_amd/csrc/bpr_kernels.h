@@ -25,6 +25,8 @@ enum { MODE_FORWARD = 0, MODE_GRAD = 1 };
 enum { NEG_GIVEN = 0, NEG_UNIFORM = 1, NEG_ADAPTIVE = 2 };
 enum { OPT_SGD = 0, OPT_MOMENTUM = 1, OPT_ADAM = 2, OPT_RMSPROP = 3 };
 
+constexpr int ADAM_SERIES = 6;
+
 struct OptDev {
   int kind;
   float lr, mu, damp;
@@ -33,6 +35,12 @@ struct OptDev {
   int64_t t;  // 1-based number of the step being applied (flush: steps applied so far)
   double log_b1, log_b2, log_mu, log_alpha;
   int kmax;   // Adam replay truncation (terms beyond are < 1e-8 of the first)
+  // Adam replay in closed form: from step t_sat on both bias corrections are exactly 1 in fp32
+  // (-1 = never / disabled); G = the geometric series of the eps expansion, for kk = kmax
+  int64_t t_sat;
+  float G[ADAM_SERIES];  // G(z_j) = z_j (1 - z_j^kmax) / (1 - z_j), z_j = b1 / b2^((j+1)/2)
+  float sv_min;          // closed form needs sqrt(v) >= eps * r^-kmax / 0.033 (series argument)
+  float log2_z[ADAM_SERIES], zc[ADAM_SERIES];  // log2(z_j), z_j / (1 - z_j): G_j(k) for k < kmax
 };
 
 struct ApplyArgs {
@@ -106,7 +114,40 @@ __device__ __forceinline__ void opt_replay_row(float (&w)[E], float (&m)[E], flo
     bool any = false;
 #pragma unroll
     for (int e = 0; e < E; ++e) any |= m[e] != 0.f;
-    if (any) {
+    // Closed form for gaps of 16 steps and more once the bias corrections have saturated (1 - b^t == 1 in fp32 for every
+    // replayed step).  The replayed movement is then
+    //   lr * sum_{s=1..kmax} m b1^s / (sqrt(v) r^s + eps),  r = sqrt(b2)
+    //   = lr (m / sqrt(v)) * sum q^s / (1 + e r^-s),         q = b1 / r,  e = eps / sqrt(v)
+    //   = lr (m / sqrt(v)) * sum_j (-e)^j G(q / r^j),        G(z) = z (1 - z^kmax) / (1 - z)
+    // with host-side constants G_j; six terms, e r^-kmax <= 0.033 required (truncation < 2e-9).
+    // Lanes holding an element with a larger e, shorter gaps and the warm-up take the loop.
+    bool closed = any && o.t_sat >= 0 && s0 >= o.t_sat && k >= 16;
+    if (closed) {
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (m[e] != 0.f) closed = closed && (sqrtf(v[e]) >= o.sv_min);
+    }
+    if (closed) {
+      // G_j for this gap: the host's constants for k >= kmax, else z_j (1 - z_j^k) / (1 - z_j) with
+      // z^k = 2^(k log2 z) in fp32 (|k log2 z| < 30: relative error ~1e-6, of the replayed movement)
+      float G[ADAM_SERIES];
+#pragma unroll
+      for (int jj = 0; jj < ADAM_SERIES; ++jj)
+        G[jj] = k >= (int64_t)o.kmax
+                    ? o.G[jj]
+                    : o.zc[jj] * (1.0f - __builtin_amdgcn_exp2f((float)k * o.log2_z[jj]));
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (m[e] != 0.f) {
+          const float isv = 1.0f / sqrtf(v[e]);
+          const float ne = -o.eps * isv;
+          float acc = G[ADAM_SERIES - 1];
+#pragma unroll
+          for (int jj = ADAM_SERIES - 2; jj >= 0; --jj) acc = fmaf(acc, ne, G[jj]);
+          w[e] -= o.lr * (m[e] * isv) * acc;
+        }
+      }
+    } else if (any) {
       double b1p = exp((double)s0 * o.log_b1), b2p = exp((double)s0 * o.log_b2);
       // ms = m b1^s and sv = sqrt(v b2^s) = sqrt(v) sqrt(b2)^s are carried as float products
       float ms[E], sv[E];

@@ -145,9 +145,26 @@ static OptDev opt_dev(const bpr_ctx* c, int64_t t) {
   o.log_alpha = safe_log((double)o.alpha);
   // Adam replay: terms decay like (b1/sqrt(b2))^s; stop once below 1e-8 of the first
   o.kmax = 0;
+  o.t_sat = -1;
   if (o.kind == OPT_ADAM && o.b1 > 0.f) {
     const double ratio = (double)o.b1 / sqrt((double)o.b2);
     o.kmax = ratio < 1.0 ? (int)ceil(log(1e-8) / log(ratio)) : 1 << 20;
+    // closed-form replay (bpr_kernels.h: opt_replay_row): needs 1 - b^t to round to 1.0f for every
+    // replayed t (b^t < 2^-25) and all three series ratios b1 / b2^((j+1)/2) below 1
+    const bool no_closed = getenv("BPR_NO_ADAM_CLOSED") != nullptr;  // tests compare both routes
+    const double zmax = (double)o.b1 / pow((double)o.b2, 0.5 * ADAM_SERIES);
+    if (!no_closed && zmax < 0.999 && o.b1 < 1.f && o.b2 > 0.f && o.b2 < 1.f) {
+      const double lim = log(ldexp(1.0, -25));
+      const double t1 = ceil(lim / log((double)o.b1)), t2 = ceil(lim / log((double)o.b2));
+      o.t_sat = (int64_t)(t1 > t2 ? t1 : t2);  // replayed steps are s0+1 .. : s0 >= t_sat suffices
+      o.sv_min = (float)((double)o.eps * pow((double)o.b2, -0.5 * o.kmax) / 0.033);
+      for (int j = 0; j < ADAM_SERIES; ++j) {
+        const double lz = log((double)o.b1) - 0.5 * (j + 1) * log((double)o.b2), z = exp(lz);
+        o.G[j] = (float)(z * (1.0 - exp((double)o.kmax * lz)) / (1.0 - z));
+        o.log2_z[j] = (float)(lz / log(2.0));
+        o.zc[j] = (float)(z / (1.0 - z));
+      }
+    }
   }
   return o;
 }

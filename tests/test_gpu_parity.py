@@ -158,6 +158,51 @@ def test_lazy_replay_without_intermediate_flush(golden_dir, opt_name):
     assert close(e.item_bias.cpu().numpy(), g[f"{opt_name}_b5"], 1e-5)
 
 
+@pytest.mark.parametrize("route", ["closed-form", "loop"])
+@pytest.mark.parametrize("d", [50, 128, 256])
+def test_adam_lazy_replay_long_gaps_after_warmup(d, route, monkeypatch):
+    """Dense torch.optim.Adam (default betas) emulated lazily, 40,000 steps into training: small
+    batches leave rows untouched for hundreds of steps, so every read / update replays up to 176
+    zero-gradient steps — in closed form once the bias corrections have saturated (geometric series
+    with the eps expansion), or by the step loop (BPR_NO_ADAM_CLOSED).  Both must follow the oracle's
+    dense Adam, which really moves every row on every step."""
+    if route == "loop":
+        monkeypatch.setenv("BPR_NO_ADAM_CLOSED", "1")
+    U, I, B, T0, steps = 300, 200, 24, 40_000, 260
+    P, Q, _, _, _, _, _ = rand_problem(U, I, d, 10, seed=d, B=8)
+    P *= 4
+    Q *= 4
+    reg = (0.002, 0.001, 0.003)
+    cfg = dict(kind=2, lr=0.003, betas=(0.9, 0.999))
+    e = make_engine(P, Q, None, reg)
+    e.set_optimizer(**cfg)
+    e.alloc_opt_state()
+    Po, Qo = P.copy(), Q.copy()
+    st = {k: np.zeros_like(Po if k.endswith("P") else Qo) for k in ("mP", "vP", "mQ", "vQ")}
+    opt = oracle.make_opt(2, 0.003, betas=(0.9, 0.999))
+    rng = np.random.default_rng(d)
+
+    def batch(n):
+        return (rng.integers(1, U, n).astype(np.int32), rng.integers(1, I, n).astype(np.int32),
+                rng.integers(1, I, n).astype(np.int32))
+
+    for t in range(1, 4):  # give every row some momentum first
+        u, i, j = batch(2000)
+        e.step(dev(u), dev(i), dev(j))
+        oracle.step(Po, Qo, None, u, i, j, opt, t, st, reg)
+    e.flush_lazy()
+    e.set_step(T0)  # as if resumed from a checkpoint written at step T0
+    for s in range(steps):
+        u, i, j = batch(B)
+        e.step(dev(u), dev(i), dev(j))
+        oracle.step(Po, Qo, None, u, i, j, opt, T0 + 1 + s, st, reg)
+    e.flush_lazy()
+    Pg, Qg = e.P.cpu().numpy(), e.Q.cpu().numpy()
+    assert np.abs(Po - P).max() > 0.01  # the tables really moved
+    assert close(Pg, Po, 2e-5), maxerr(Pg, Po)
+    assert close(Qg, Qo, 2e-5), maxerr(Qg, Qo)
+
+
 # ------------------------------------------------------------------------------------------------
 # against the oracle at the dims the kernels are specialised for
 # ------------------------------------------------------------------------------------------------

@@ -23,6 +23,7 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--sampler", default="adaptive")
 ap.add_argument("--triples", type=int, default=1_000_000)
 ap.add_argument("--beta1", type=float, default=0.1)
+ap.add_argument("--start-step", type=int, default=0, help="pretend this many optimizer steps were taken")
 a = ap.parse_args()
 data = synthetic.generate_named(a.workload, seed=13)
 dev = torch.device("cuda")
@@ -34,6 +35,8 @@ e.set_reg(0.0025, 0.0025, 0.00025)
 kind = {"sgd": eng.OPT_SGD, "adam": eng.OPT_ADAM, "rmsprop": eng.OPT_RMSPROP, "momentum": eng.OPT_MOMENTUM}[a.opt]
 e.set_optimizer(kind, lr=0.001, betas=(a.beta1, 0.999), momentum=0.9, nesterov=True, alpha=0.9)
 e.alloc_opt_state()
+if a.start_step:
+    e.set_step(a.start_step)
 e.bind_seen_csr(torch.from_numpy(data.indptr).to(dev), torch.from_numpy(data.indices).to(dev))
 e.adaptive_refresh()
 n = min(a.triples, data.nnz)
