@@ -39,6 +39,7 @@ struct OptDev {
   // (-1 = never / disabled); G = the geometric series of the eps expansion, for kk = kmax
   int64_t t_sat;
   float G[ADAM_SERIES];  // G(z_j) = z_j (1 - z_j^kmax) / (1 - z_j), z_j = b1 / b2^((j+1)/2)
+  float adam_step, adam_bc2;  // lr / (1 - b1^t), sqrt(1 - b2^t) of the step being applied (host)
   float sv_min;          // closed form needs sqrt(v) >= eps * r^-kmax / 0.033 (series argument)
   float log2_z[ADAM_SERIES], zc[ADAM_SERIES];  // log2(z_j), z_j / (1 - z_j): G_j(k) for k < kmax
 };
@@ -98,7 +99,9 @@ __device__ __forceinline__ void opt_replay(float& w, float& m, float& v, int64_t
 // The same k zero-gradient steps for the E elements a lane holds of ONE row: the per-step scalars
 // (bias corrections — double-precision exp / divide / sqrt) are computed once per step instead of
 // once per element and step; element arithmetic is identical to opt_replay, bit for bit.
-template <int E>
+// STATE = false: only w is wanted (a forward pass reading the row "as of now"): the decayed
+// moments — two double-precision exps per row — are not computed.
+template <int E, bool STATE = true>
 __device__ __forceinline__ void opt_replay_row(float (&w)[E], float (&m)[E], float (&v)[E],
                                                int64_t s0, int64_t k, const OptDev& o) {
   if (k <= 0) return;
@@ -183,16 +186,20 @@ __device__ __forceinline__ void opt_replay_row(float (&w)[E], float (&m)[E], flo
         }
       }
     }
-    const float mk = (float)exp((double)k * o.log_b1), vk = (float)exp((double)k * o.log_b2);
+    if constexpr (STATE) {
+      const float mk = (float)exp((double)k * o.log_b1), vk = (float)exp((double)k * o.log_b2);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      m[e] *= mk;
-      v[e] *= vk;
+      for (int e = 0; e < E; ++e) {
+        m[e] *= mk;
+        v[e] *= vk;
+      }
     }
   } else if (o.kind == OPT_RMSPROP) {
-    const float ak = (float)exp((double)k * o.log_alpha);
+    if constexpr (STATE) {
+      const float ak = (float)exp((double)k * o.log_alpha);
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] *= ak;
+      for (int e = 0; e < E; ++e) v[e] *= ak;
+    }
   }
 }
 
@@ -235,7 +242,7 @@ __device__ __forceinline__ void catch_up_row(float (&r)[E], const float* __restr
     m[e] = (M != nullptr && f < d) ? M[row * d + f] : 0.f;
     v[e] = (V != nullptr && f < d) ? V[row * d + f] : 0.f;
   }
-  opt_replay_row<E>(r, m, v, s0, k, o);
+  opt_replay_row<E, false>(r, m, v, s0, k, o);
 }
 
 struct TripleArgs {
@@ -889,11 +896,7 @@ __global__ __launch_bounds__(256) void k_apply(const ApplyArgs a) {
   const bool stateful = o.kind != OPT_SGD;
   const int64_t s0 = stateful ? (int64_t)last[row] : 0;
   const int64_t k = stateful ? (o.t - 1) - s0 : 0;
-  float adam_step = 0.f, adam_bc2_sqrt = 1.f;
-  if (o.kind == OPT_ADAM) {
-    adam_step = (float)((double)o.lr / (1.0 - exp((double)o.t * o.log_b1)));
-    adam_bc2_sqrt = (float)sqrt(1.0 - exp((double)o.t * o.log_b2));
-  }
+  const float adam_step = o.adam_step, adam_bc2_sqrt = o.adam_bc2;
   if (row != pad) {
     float w[E], g[E], m[E], v[E];
 #pragma unroll

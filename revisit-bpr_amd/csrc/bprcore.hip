@@ -146,6 +146,12 @@ static OptDev opt_dev(const bpr_ctx* c, int64_t t) {
   // Adam replay: terms decay like (b1/sqrt(b2))^s; stop once below 1e-8 of the first
   o.kmax = 0;
   o.t_sat = -1;
+  o.adam_step = 0.f;
+  o.adam_bc2 = 1.f;
+  if (o.kind == OPT_ADAM) {
+    o.adam_step = (float)((double)o.lr / (1.0 - exp((double)t * o.log_b1)));
+    o.adam_bc2 = (float)sqrt(1.0 - exp((double)t * o.log_b2));
+  }
   if (o.kind == OPT_ADAM && o.b1 > 0.f) {
     const double ratio = (double)o.b1 / sqrt((double)o.b2);
     o.kmax = ratio < 1.0 ? (int)ceil(log(1e-8) / log(ratio)) : 1 << 20;
