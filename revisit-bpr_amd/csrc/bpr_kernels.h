@@ -25,7 +25,7 @@ enum { MODE_FORWARD = 0, MODE_GRAD = 1 };
 enum { NEG_GIVEN = 0, NEG_UNIFORM = 1, NEG_ADAPTIVE = 2 };
 enum { OPT_SGD = 0, OPT_MOMENTUM = 1, OPT_ADAM = 2, OPT_RMSPROP = 3 };
 
-constexpr int ADAM_SERIES = 6;
+constexpr int ADAM_SERIES = 12;
 
 struct OptDev {
   int kind;
@@ -40,7 +40,7 @@ struct OptDev {
   int64_t t_sat;
   float G[ADAM_SERIES];  // G(z_j) = z_j (1 - z_j^kmax) / (1 - z_j), z_j = b1 / b2^((j+1)/2)
   float adam_step, adam_bc2;  // lr / (1 - b1^t), sqrt(1 - b2^t) of the step being applied (host)
-  float sv_min;          // closed form needs sqrt(v) >= eps * r^-kmax / 0.033 (series argument)
+  float sv_min;          // closed form needs sqrt(v) >= eps * r^-kmax / 0.2 (series argument)
   float log2_z[ADAM_SERIES], zc[ADAM_SERIES];  // log2(z_j), z_j / (1 - z_j): G_j(k) for k < kmax
 };
 
@@ -122,7 +122,7 @@ __device__ __forceinline__ void opt_replay_row(float (&w)[E], float (&m)[E], flo
     //   lr * sum_{s=1..kmax} m b1^s / (sqrt(v) r^s + eps),  r = sqrt(b2)
     //   = lr (m / sqrt(v)) * sum q^s / (1 + e r^-s),         q = b1 / r,  e = eps / sqrt(v)
     //   = lr (m / sqrt(v)) * sum_j (-e)^j G(q / r^j),        G(z) = z (1 - z^kmax) / (1 - z)
-    // with host-side constants G_j; six terms, e r^-kmax <= 0.033 required (truncation < 2e-9).
+    // with host-side constants G_j; twelve terms, e r^-kmax <= 0.2 required (truncation < 5e-9).
     // Lanes holding an element with a larger e, shorter gaps and the warm-up take the loop.
     bool closed = any && o.t_sat >= 0 && s0 >= o.t_sat && k >= 16;
     if (closed) {

@@ -163,7 +163,7 @@ static OptDev opt_dev(const bpr_ctx* c, int64_t t) {
       const double lim = log(ldexp(1.0, -25));
       const double t1 = ceil(lim / log((double)o.b1)), t2 = ceil(lim / log((double)o.b2));
       o.t_sat = (int64_t)(t1 > t2 ? t1 : t2);  // replayed steps are s0+1 .. : s0 >= t_sat suffices
-      o.sv_min = (float)((double)o.eps * pow((double)o.b2, -0.5 * o.kmax) / 0.033);
+      o.sv_min = (float)((double)o.eps * pow((double)o.b2, -0.5 * o.kmax) / 0.2);
       for (int j = 0; j < ADAM_SERIES; ++j) {
         const double lz = log((double)o.b1) - 0.5 * (j + 1) * log((double)o.b2), z = exp(lz);
         o.G[j] = (float)(z * (1.0 - exp((double)o.kmax * lz)) / (1.0 - z));
