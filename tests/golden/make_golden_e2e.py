@@ -70,12 +70,16 @@ def evaluate(model, data, seen_all):
     return float(nd.get_metric()), float(rc.get_metric())
 
 
-def run(data, seen_all, sampler_kind, sampler_seed):
+ADAM_LR = 0.0005  # torch.optim.Adam, default betas: the optimizer of 14 of the 22 reference configs
+
+
+def run(data, seen_all, sampler_kind, sampler_seed, optimizer="sgd"):
     set_seed(INIT_SEED)
     model = BPR(fuse_forward=True, reg_alphas=REG,
                 logits_model=MF(torch.nn.Embedding(data.num_users, D, padding_idx=0),
                                 torch.nn.Embedding(data.num_items, D, padding_idx=0)))
-    opt = torch.optim.SGD(model.parameters(), lr=LR)
+    opt = (torch.optim.Adam(model.parameters(), lr=ADAM_LR) if optimizer == "adam"
+           else torch.optim.SGD(model.parameters(), lr=LR))
     gen = torch.Generator().manual_seed(sampler_seed)
     if sampler_kind == "uniform":
         sampler = UniformSampler(data.num_items, gen)
@@ -103,7 +107,32 @@ def run(data, seen_all, sampler_kind, sampler_seed):
     return curve
 
 
+def main_adam(only):
+    """`make_golden_e2e.py adam [adaptive_1 ...]`: the same protocol with torch.optim.Adam ->
+    tests/golden/e2e_reference_adam_<run>.json (one file per run, so seeds can run in parallel);
+    the dataset file is not rewritten."""
+    torch.set_num_threads(1)
+    data = synthetic.generate_latent(USERS, ITEMS, ACTIONS, factors=8, strength=1.5,
+                                     median_per_user=20, min_per_user=5, seed=7)
+    saved = np.load(OUT / "e2e_data.npz")
+    assert np.array_equal(saved["users"], data.users) and np.array_equal(saved["items"], data.items)
+    seen_all = padded_seen(data, np.arange(data.num_users))
+    for kind in ("uniform", "adaptive"):
+        for s in SAMPLER_SEEDS:
+            if only and f"{kind}_{s}" not in only:
+                continue
+            t0 = time.time()
+            curve = run(data, seen_all, kind, s, optimizer="adam")
+            out = {"optimizer": "torch.optim.Adam", "lr": ADAM_LR, "betas": [0.9, 0.999],
+                   "ndcg@100": [c[0] for c in curve], "recall@20": [c[1] for c in curve]}
+            (OUT / f"e2e_reference_adam_{kind}_{s}.json").write_text(json.dumps(out, indent=1))
+            print("adam", kind, s, f"{time.time() - t0:.0f}s", [round(c[0], 4) for c in curve],
+                  flush=True)
+
+
 def main():
+    if sys.argv[1:2] == ["adam"]:
+        return main_adam(sys.argv[2:] or None)
     torch.set_num_threads(8)
     only = sys.argv[1:] or None
     data = synthetic.generate_latent(USERS, ITEMS, ACTIONS, factors=8, strength=1.5,
