@@ -71,6 +71,15 @@ def evaluate(model, data, seen_all):
 
 
 ADAM_LR = 0.0005  # torch.optim.Adam, default betas: the optimizer of 14 of the 22 reference configs
+OPT_KW = {"adam": {"lr": ADAM_LR, "betas": [0.9, 0.999]},
+          "rmsprop": {"lr": 0.0005, "alpha": 0.9},  # alpha as in configs/RQ2/optimizers/rmsprop-*.yaml.j2
+          "nesterov": {"lr": 0.01, "momentum": 0.9, "nesterov": True}}
+OPTIMIZERS = {
+    "sgd": lambda p: torch.optim.SGD(p, lr=LR),
+    "adam": lambda p: torch.optim.Adam(p, lr=ADAM_LR),
+    "rmsprop": lambda p: torch.optim.RMSprop(p, **OPT_KW["rmsprop"]),
+    "nesterov": lambda p: torch.optim.SGD(p, **OPT_KW["nesterov"]),
+}
 
 
 def run(data, seen_all, sampler_kind, sampler_seed, optimizer="sgd"):
@@ -78,8 +87,7 @@ def run(data, seen_all, sampler_kind, sampler_seed, optimizer="sgd"):
     model = BPR(fuse_forward=True, reg_alphas=REG,
                 logits_model=MF(torch.nn.Embedding(data.num_users, D, padding_idx=0),
                                 torch.nn.Embedding(data.num_items, D, padding_idx=0)))
-    opt = (torch.optim.Adam(model.parameters(), lr=ADAM_LR) if optimizer == "adam"
-           else torch.optim.SGD(model.parameters(), lr=LR))
+    opt = OPTIMIZERS[optimizer](model.parameters())
     gen = torch.Generator().manual_seed(sampler_seed)
     if sampler_kind == "uniform":
         sampler = UniformSampler(data.num_items, gen)
@@ -107,9 +115,9 @@ def run(data, seen_all, sampler_kind, sampler_seed, optimizer="sgd"):
     return curve
 
 
-def main_adam(only):
-    """`make_golden_e2e.py adam [adaptive_1 ...]`: the same protocol with torch.optim.Adam ->
-    tests/golden/e2e_reference_adam_<run>.json (one file per run, so seeds can run in parallel);
+def main_opt(name, only):
+    """`make_golden_e2e.py adam|rmsprop|nesterov [adaptive_1 ...]`: the same protocol with another
+    torch.optim optimizer -> tests/golden/e2e_reference_<optimizer>_<run>.json (one file per run, so seeds can run in parallel);
     the dataset file is not rewritten."""
     torch.set_num_threads(1)
     data = synthetic.generate_latent(USERS, ITEMS, ACTIONS, factors=8, strength=1.5,
@@ -122,17 +130,17 @@ def main_adam(only):
             if only and f"{kind}_{s}" not in only:
                 continue
             t0 = time.time()
-            curve = run(data, seen_all, kind, s, optimizer="adam")
-            out = {"optimizer": "torch.optim.Adam", "lr": ADAM_LR, "betas": [0.9, 0.999],
+            curve = run(data, seen_all, kind, s, optimizer=name)
+            out = {"optimizer": name, **OPT_KW[name],
                    "ndcg@100": [c[0] for c in curve], "recall@20": [c[1] for c in curve]}
-            (OUT / f"e2e_reference_adam_{kind}_{s}.json").write_text(json.dumps(out, indent=1))
-            print("adam", kind, s, f"{time.time() - t0:.0f}s", [round(c[0], 4) for c in curve],
+            (OUT / f"e2e_reference_{name}_{kind}_{s}.json").write_text(json.dumps(out, indent=1))
+            print(name, kind, s, f"{time.time() - t0:.0f}s", [round(c[0], 4) for c in curve],
                   flush=True)
 
 
 def main():
-    if sys.argv[1:2] == ["adam"]:
-        return main_adam(sys.argv[2:] or None)
+    if sys.argv[1:2] and sys.argv[1] in OPT_KW:
+        return main_opt(sys.argv[1], sys.argv[2:] or None)
     torch.set_num_threads(8)
     only = sys.argv[1:] or None
     data = synthetic.generate_latent(USERS, ITEMS, ACTIONS, factors=8, strength=1.5,
