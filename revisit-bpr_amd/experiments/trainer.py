@@ -91,35 +91,37 @@ class Trainer:
         return self.engines["eval" if "eval" in loaders else "train"].state
 
     # ---- steps --------------------------------------------------------------------------------
+    def _forward(self, engine: Engine, batch: dict) -> dict:
+        """model(batch) between the two FORWARD events; the running loss sum feeds `_mean_loss`."""
+        st = engine.state
+        st.forward_iteration += 1
+        engine.fire_event(ModelEvents.FORWARD_STARTED)
+        st.output = result = self.model(batch)
+        engine.fire_event(ModelEvents.FORWARD_COMPLETED)
+        return result
+
     def _train_step(self, engine: Engine, batch: dict) -> dict:
         self.model.train()
-        state = engine.state
         with self._accelerator.accumulate(self.model):
-            state.forward_iteration += 1
-            engine.fire_event(ModelEvents.FORWARD_STARTED)
-            output = state.output = self.model(batch)
-            engine.fire_event(ModelEvents.FORWARD_COMPLETED)
-            if "loss" in output:
-                self._accelerator.backward(output["loss"])
-                state.optimizer_iteration += 1
+            result = self._forward(engine, batch)
+            loss = result.get("loss")
+            if loss is not None:
+                self._accelerator.backward(loss)
+                engine.state.optimizer_iteration += 1
                 engine.fire_event(ModelEvents.OPTIMIZER_STARTED)
                 self.optimizer.step()
                 engine.fire_event(ModelEvents.OPTIMIZER_COMPLETED)
                 self.optimizer.zero_grad()
-                state.metrics["_loss"] += output["loss"].detach()
-        return output
+                engine.state.metrics["_loss"] += loss.detach()
+        return result
 
+    @torch.no_grad()
     def _eval_step(self, engine: Engine, batch: dict) -> dict:
         self.model.eval()
-        state = engine.state
-        with torch.no_grad():
-            state.forward_iteration += 1
-            engine.fire_event(ModelEvents.FORWARD_STARTED)
-            output = state.output = self.model(batch)
-            engine.fire_event(ModelEvents.FORWARD_COMPLETED)
-            if "loss" in output:
-                state.metrics["_loss"] += output["loss"].detach()
-        return output
+        result = self._forward(engine, batch)
+        if "loss" in result:
+            engine.state.metrics["_loss"] += result["loss"].detach()
+        return result
 
     # ---- built-in handlers ----------------------------------------------------------------------
     def _run_eval(self) -> None:
