@@ -51,6 +51,15 @@ def parse_args():
     ap.add_argument("--workload", default="ml-20m")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--sampler", choices=["adaptive", "uniform", "given"], default="adaptive")
+    ap.add_argument("--optimizer", choices=["sgd", "adam", "momentum", "rmsprop"], default="sgd",
+                    help="sgd: the fused SGD STREAM kernel (BASELINE configs[2], the default); the "
+                         "others run the batched STREAM kernel (virtual mini-batches of "
+                         "--batch-size, one dense torch.optim step each; BASELINE configs[4] is "
+                         "--workload yelp --optimizer adam)")
+    ap.add_argument("--batched", action="store_true",
+                    help="run plain SGD through the batched STREAM kernel too (measurement aid)")
+    ap.add_argument("--betas", type=float, nargs=2, default=(0.1, 0.999),
+                    help="Adam betas (configs/RQ3/time-split/ada-sampling-adam.yaml.j2:175)")
     ap.add_argument("--adaptive-p", type=float, default=0.01)
     ap.add_argument("--lr", type=float, default=0.001)
     ap.add_argument("--batch-size", type=int, default=256,
@@ -147,7 +156,11 @@ def main():
     e = eng.Engine(P, Q)
     reg = (0.0016, 0.0001, 0.00375)  # configs/RQ2/neg-sampling/ada-sampling-ml-20m.yaml.j2:144-147
     e.set_reg(*reg)
-    e.set_optimizer(eng.OPT_SGD, lr=args.lr)
+    batched = args.batched or args.optimizer != "sgd"
+    kind = {"sgd": eng.OPT_SGD, "momentum": eng.OPT_MOMENTUM, "adam": eng.OPT_ADAM,
+            "rmsprop": eng.OPT_RMSPROP}[args.optimizer]
+    e.set_optimizer(kind, lr=args.lr, momentum=0.9, betas=tuple(args.betas), alpha=0.99)
+    opt_state = e.alloc_opt_state()  # noqa: F841  (keeps the state tensors alive)
     e.bind_seen_csr(torch.from_numpy(data.indptr).to(dev), torch.from_numpy(data.indices).to(dev))
     sampler = {"adaptive": eng.NEG_ADAPTIVE, "uniform": eng.NEG_UNIFORM, "given": eng.NEG_GIVEN}[args.sampler]
 
@@ -172,14 +185,25 @@ def main():
         c = k % n_chunks
         lo = c * chunk
         if c == 0:  # new epoch: re-plan (inside the timed region — it is part of the job)
-            e.plan_epoch(src_users, src_items, chunk, seed + k // n_chunks, out=(users, items))
+            if batched:
+                e.shuffle_epoch(src_users, src_items, seed + k // n_chunks, out=(users, items))
+            else:
+                e.plan_epoch(src_users, src_items, chunk, seed + k // n_chunks, out=(users, items))
         if sampler == eng.NEG_ADAPTIVE:
-            e.adaptive_refresh()
-        e.train_stream(users[lo:lo + chunk], items[lo:lo + chunk], sampler=sampler,
-                       neg=given_neg, adaptive_p=args.adaptive_p, seed=seed,
-                       offset=(rank << 40) + k * chunk, max_inflight=args.max_inflight,
-                       scalars=scalars)
+            e.adaptive_refresh()  # batched: brings the item rows to "now" first
+        if batched:
+            e.train_stream_batched(users[lo:lo + chunk], items[lo:lo + chunk], args.batch_size,
+                                   sampler=sampler, neg=given_neg, adaptive_p=args.adaptive_p,
+                                   seed=seed, offset=(rank << 40) + k * chunk,
+                                   max_inflight=args.max_inflight, scalars=scalars)
+        else:
+            e.train_stream(users[lo:lo + chunk], items[lo:lo + chunk], sampler=sampler,
+                           neg=given_neg, adaptive_p=args.adaptive_p, seed=seed,
+                           offset=(rank << 40) + k * chunk, max_inflight=args.max_inflight,
+                           scalars=scalars)
         if sync is not None and (k + 1) % args.sync_every == 0:
+            if batched:
+                e.flush_lazy()
             sync.step()
 
     def barrier():
@@ -210,17 +234,23 @@ def main():
         dt = float(t.item())
     sc = scalars.cpu().numpy()
 
+    opt_desc = {"sgd": f"SGD lr={args.lr}", "momentum": f"SGD(momentum 0.9) lr={args.lr}",
+                "adam": f"Adam lr={args.lr} betas={tuple(args.betas)}",
+                "rmsprop": f"RMSprop lr={args.lr} alpha=0.99"}[args.optimizer]
     if rank == 0:
         triples = args.steps * chunk * world
         value = triples / dt
-        bytes_per_triple = 24 * d + 8  # read 3 rows + write 3 rows (fp32) + 2 int32 ids
+        # SGD reads and writes 3 rows (+ 2 int32 ids); Adam reads and writes w, m, v of 3
+        # rows (+ ids + 24 B of per-row step marks); momentum / RMSprop carry one state table
+        bytes_per_triple = {"sgd": 24 * d + 8, "adam": 72 * d + 32, "momentum": 48 * d + 32,
+                            "rmsprop": 48 * d + 32}[args.optimizer]
         # HBM-side bytes per k_stream launch from the rocprofv3 PMC passes of this same command
         # (profiles/r01_pmc_traffic.md: FETCH_SIZE x2 correction + WRITE_SIZE); null when the run
         # is not the profiled configuration
         traffic = None
         tfile = ROOT / "profiles" / "traffic_r01.json"
         if tfile.exists() and args.workload == "ml-20m" and d == 128 and args.sampler == "adaptive" \
-                and args.scale == 1.0:
+                and args.scale == 1.0 and not batched:
             tj = json.loads(tfile.read_text())
             if tj.get("triples_per_launch") == chunk:
                 traffic = tj["traffic_bytes_per_launch"]
@@ -240,10 +270,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}-shaped synthetic user-split ({U - 1} users x {I - 1} "
-                            f"items, {data.nnz} train triples per GPU), d={d}, SGD lr={args.lr} + L2 "
+                            f"items, {data.nnz} train triples per GPU), d={d}, {opt_desc} + L2 "
                             f"reg {reg}, {args.sampler} negative sampling"
                             + (f" p={args.adaptive_p}" if args.sampler == "adaptive" else "")
-                            + f", STREAM mode, step = refresh + {chunk} triples",
+                            + (f", batched STREAM mode (virtual mini-batches of {args.batch_size})" if batched
+                               else ", STREAM mode") + f", step = refresh + {chunk} triples",
                 "triples_per_step_per_gpu": chunk,
                 "parallelism": f"user-sharded x{world}, item table replicated, async delta "
                                f"all-reduce every {args.sync_every} step(s)" if world > 1 else "single GPU",
@@ -251,7 +282,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_stream<G=%d,E=%d,%s>" % (32 if d <= 128 else 64, max(1, -(-d // (32 if d <= 128 else 64))), args.sampler.upper()),
+                "kernel": ("k_vstream" if batched else "k_stream") + "<G=%d,E=%d,%s>" % (32 if d <= 128 else 64, max(1, -(-d // (32 if d <= 128 else 64))), args.sampler.upper()),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -70,7 +70,8 @@ typedef enum bpr_mode {
   BPR_MODE_STRICT = 0,
   /* Throughput path: one launch consumes a whole chunk of triples; every triple reads the latest
    * rows it can see and applies its update immediately with per-element fp32 atomics
-   * (asynchronous SGD, bounded staleness).  SGD only. */
+   * (asynchronous SGD, bounded staleness).  SGD only; the other optimizers have their own
+   * single-launch path, bpr_train_stream_batched. */
   BPR_MODE_STREAM = 1
 } bpr_mode;
 
@@ -171,8 +172,11 @@ int bpr_step(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* ne
  * time.  users/pos [n] are the epoch's triple stream (already shuffled); batches of B consecutive
  * triples; neg_scratch [>= B] int32 receives each batch's negatives (sampler != GIVEN) or, for
  * BPR_NEG_GIVEN, is the full [n] negative stream.  refresh_every > 0 calls bpr_adaptive_refresh
- * after every refresh_every-th batch (AdaptiveSampler: neg_samplers.py:122-123) — with lazy
- * optimizers it flushes first.  out_scalars accumulates over the epoch. */
+ * at every refresh_every-th batch exactly where AdaptiveSampler.sample does
+ * (neg_samplers.py:75,122-123): after that batch's negatives are drawn and before its optimizer
+ * step; the batch counter belongs to the ctx and keeps counting across calls (epochs), as the
+ * sampler's _iteration_cnt does (bpr_set_sampler_iter rewinds it).  With lazy optimizers the
+ * refresh flushes first.  out_scalars accumulates over the epoch. */
 int bpr_train_strict(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg_scratch,
                      int64_t n, int64_t B, int32_t sampler, float adaptive_p, uint64_t seed,
                      uint64_t offset, int64_t refresh_every, float* out_scalars);
@@ -183,6 +187,30 @@ int bpr_train_strict(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int
 int bpr_train_stream(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
                      int64_t n, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
                      int64_t max_inflight, float* out_scalars);
+
+/* BATCHED STREAM — the single-launch throughput path for every optimizer kind (SGD, momentum /
+ * Nesterov, Adam, RMSprop; configs/RQ3/time-split/ada-sampling-adam.yaml.j2:169-175 and 14 of the
+ * 22 BPR configs step torch.optim.Adam at experiments/trainer.py:79-81).  users/pos [n] are the
+ * shuffled triple stream (bpr_shuffle_epoch; NOT grouped by user); triple k belongs to virtual
+ * mini-batch k / B, i.e. optimizer step (steps so far) + 1 + k / B.  Per row the gradients of one
+ * virtual batch are summed and applied as ONE torch.optim step (dense semantics: untouched rows
+ * catch up lazily), every gradient being evaluated on the rows as of the previous step.  Executed
+ * by one group (max_inflight = 1) this IS the reference's mini-batch loop; with the chip full,
+ * triples of up to max_inflight (0 = fill the chip) consecutive stream positions run concurrently
+ * and see rows that may be a few steps stale.  Advances the step counter by
+ * ceil(n / B); bpr_flush_lazy / bpr_adaptive_refresh bring rows to "now" (call bpr_flush_lazy
+ * before reading the tables: eval, checkpoint, item all-reduce).  sampler / seed / offset / neg /
+ * out_scalars as bpr_train_stream. */
+int bpr_train_stream_batched(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
+                             int64_t n, int64_t B, int32_t sampler, float adaptive_p,
+                             uint64_t seed, uint64_t offset, int64_t max_inflight,
+                             float* out_scalars);
+/* DataLoader(shuffle=True, generator=manual_seed(seed)) stand-in (example.py:307-321,
+ * experiments/bpr/exp.py:109-118) without the by-user grouping of bpr_plan_epoch: a seeded
+ * pseudo-random permutation of the n training triples, computed on device.  Outputs must not alias
+ * the inputs. */
+int bpr_shuffle_epoch(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_in, int64_t n,
+                      uint64_t seed, int32_t* users_out, int32_t* pos_out);
 
 /* STREAM options.  grouped_by_user = 1 promises that inside every chunk handed to
  * bpr_train_stream the triples of a user are contiguous (the output of bpr_plan_epoch): a user
@@ -217,6 +245,9 @@ int bpr_flush_lazy(bpr_ctx* ctx);
 /* Global optimizer step counter t (number of bpr_apply calls); settable for checkpoint resume. */
 int bpr_get_step_host(bpr_ctx* ctx, int64_t* step_host);
 int bpr_set_step(bpr_ctx* ctx, int64_t step);
+/* AdaptiveSampler._iteration_cnt of the bpr_train_strict loop (neg_samplers.py:75): batches drawn so
+ * far; 0 at ctx creation.  Settable so a resumed run refreshes at the same iterations. */
+int bpr_set_sampler_iter(bpr_ctx* ctx, int64_t iteration);
 
 /* ---- multi-GPU item-table reconciliation (no reference counterpart: the reference's DDP path is
  * never enabled by a config, experiments/launcher.py:35-73).  The all-reduce itself is RCCL via

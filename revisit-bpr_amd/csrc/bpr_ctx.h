@@ -39,6 +39,13 @@ struct bpr_ctx {
   int64_t pending = 0;  // upper bound of entries in `touched`
   int64_t step = 0;     // optimizer steps applied so far
   int64_t flushed_at = 0;
+  int64_t strict_iter = 0;  // batches drawn by bpr_train_strict so far (AdaptiveSampler._iteration_cnt)
+  // private scratch — batched STREAM (bpr_vstream.hip): per-row headers (last | gstep | slot | lock)
+  // and double-buffered gradient accumulators [2, rows, d]; while vs_active the headers — not
+  // lastP / lastQ — say how far each row has been advanced
+  float *vGP = nullptr, *vGQ = nullptr, *vGb = nullptr;
+  uint64_t *vHP = nullptr, *vHQ = nullptr;
+  bool vs_active = false;
   // private scratch — adaptive sampler snapshot
   int32_t* order = nullptr;  // [d, I], inside order_alloc with BPR_ORDER_PAD entries of slack on
   int32_t* order_alloc = nullptr;  // both ends (the sampler's walk reads 16-byte vectors)

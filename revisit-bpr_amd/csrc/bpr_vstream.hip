@@ -1,0 +1,241 @@
+// bpr_vstream.hip — host side of the batched STREAM path (kernels: bpr_vstream.h).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+
+#include "bpr_host.h"
+#include "bpr_vstream.h"
+
+namespace bpr {
+
+static VTable table_P(const bpr_ctx* c) {
+  VTable t;
+  memset(&t, 0, sizeof(t));
+  t.W = c->P; t.M = c->mP; t.V = c->vP; t.Gacc = c->vGP; t.H = c->vHP; t.rows = c->U;
+  return t;
+}
+static VTable table_Q(const bpr_ctx* c) {
+  VTable t;
+  memset(&t, 0, sizeof(t));
+  t.W = c->Q; t.M = c->mQ; t.V = c->vQ; t.Gacc = c->vGQ; t.H = c->vHQ; t.rows = c->I;
+  if (c->bias != nullptr) {
+    t.b = c->bias; t.mb = c->mb; t.vb = c->vb; t.Gb = c->vGb;
+  }
+  return t;
+}
+
+void vs_free(bpr_ctx* c) {
+  hipFree(c->vGP); hipFree(c->vGQ); hipFree(c->vGb); hipFree(c->vHP); hipFree(c->vHQ);
+  c->vGP = c->vGQ = c->vGb = nullptr;
+  c->vHP = c->vHQ = nullptr;
+  c->vs_active = false;
+}
+
+static int vs_ensure(bpr_ctx* c) {
+  if (c->vHP != nullptr) return BPR_OK;
+  const size_t nP = (size_t)c->U * c->d, nQ = (size_t)c->I * c->d;
+  BPR_HIP_CHECK(hipMalloc(&c->vGP, sizeof(float) * 2 * nP));
+  BPR_HIP_CHECK(hipMalloc(&c->vGQ, sizeof(float) * 2 * nQ));
+  BPR_HIP_CHECK(hipMalloc(&c->vGb, sizeof(float) * 2 * (size_t)c->I));
+  BPR_HIP_CHECK(hipMalloc(&c->vHP, sizeof(uint64_t) * (size_t)c->U));
+  BPR_HIP_CHECK(hipMalloc(&c->vHQ, sizeof(uint64_t) * (size_t)c->I));
+  BPR_HIP_CHECK(hipMemsetAsync(c->vGP, 0, sizeof(float) * 2 * nP, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->vGQ, 0, sizeof(float) * 2 * nQ, c->stream));
+  BPR_HIP_CHECK(hipMemsetAsync(c->vGb, 0, sizeof(float) * 2 * (size_t)c->I, c->stream));
+  return BPR_OK;
+}
+
+// rows tracked by lastP / lastQ (STRICT) -> rows tracked by the headers
+static int vs_enter(bpr_ctx* c) {
+  if (c->vs_active) return BPR_OK;
+  if (int rc = vs_ensure(c)) return rc;
+  if (int rc = strict_flush_impl(c)) return rc;  // every row current as of c->step
+  const uint64_t h = vhdr_pack(c->step, c->step, 0, 0);
+  hipLaunchKernelGGL(k_vfill_hdr, dim3(256), dim3(256), 0, c->stream, c->vHP, c->U, h);
+  hipLaunchKernelGGL(k_vfill_hdr, dim3(256), dim3(256), 0, c->stream, c->vHQ, c->I, h);
+  BPR_HIP_CHECK(hipGetLastError());
+  c->vs_active = true;
+  return BPR_OK;
+}
+
+int vs_flush(bpr_ctx* c, bool users, bool items) {
+  if (!c->vs_active) return BPR_OK;
+  const bool stateful = c->opt_kind != BPR_OPT_SGD;
+  if (stateful)
+    if (int rc = check_opt_state(c, "bpr_flush_lazy")) return rc;
+  VFlushArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d = c->d;
+  a.now = c->step;
+  a.o = opt_dev(c, c->step);
+  return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
+    using T = decltype(tag);
+    constexpr int G = T::G, E = T::E;
+    auto go = [&](const VTable& t, int pad) {
+      a.T = t;
+      a.pad = pad;
+      const int64_t per_block = 256 / G;
+      const unsigned grid = (unsigned)std::min<int64_t>((t.rows + per_block - 1) / per_block, 8192);
+      if (stateful)
+        hipLaunchKernelGGL((k_vflush<G, E, true>), dim3(grid), dim3(256), 0, c->stream, a);
+      else
+        hipLaunchKernelGGL((k_vflush<G, E, false>), dim3(grid), dim3(256), 0, c->stream, a);
+    };
+    if (users) go(table_P(c), c->pad_user);
+    if (items) go(table_Q(c), c->pad_item);
+    BPR_HIP_CHECK(hipGetLastError());
+    return BPR_OK;
+  });
+}
+
+// headers -> lastP / lastQ: everything applied, every row current as of c->step
+int vs_leave(bpr_ctx* c) {
+  if (!c->vs_active) return BPR_OK;
+  if (int rc = vs_flush(c, true, true)) return rc;
+  if (c->lastP != nullptr) {
+    BPR_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->lastP, (int)c->step, (size_t)c->U, c->stream));
+    BPR_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->lastQ, (int)c->step, (size_t)c->I, c->stream));
+  }
+  c->vs_active = false;
+  return BPR_OK;
+}
+
+static int launch_vstream(bpr_ctx* c, VStreamArgs a, int sampler, int64_t cap_groups,
+                          float* out_scalars) {
+  return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
+    using T = decltype(tag);
+    constexpr int G = T::G, E = T::E;
+    constexpr int GPW = 64 / G;
+    unsigned block = 256;
+    a.gpw_active = GPW;
+    if (cap_groups > 0 && cap_groups * G < 256) {
+      block = (unsigned)(((cap_groups * G + 63) / 64) * 64);
+      if (cap_groups < GPW) a.gpw_active = (int)cap_groups;  // one wave, fewer groups at work
+    }
+    // "seen?" structure in LDS, rebuilt per triple (bpr_device.h): the I-bit bitmap while a
+    // block's bitmaps fit 64 KiB, else the user's sorted list (LIST_CAP entries, longer lists
+    // fall back to the CSR in HBM).  BPR_SEEN=csr|bitmap|list forces one (tests).
+    const int words = (int)(((c->I + 31) / 32 + 3) / 4 * 4);
+    const char* force_env = getenv("BPR_SEEN");
+    const std::string force = force_env ? force_env : "";
+    constexpr int LIST_CAP = 512;
+    int seen = SEEN_CSR, lds_words = 0;
+    if (sampler != NEG_GIVEN && force != "csr") {
+      const bool bm_fits = (size_t)(block / G) * words * sizeof(uint32_t) <= 64 * 1024;
+      if (force == "list" || (force != "bitmap" && !bm_fits)) {
+        seen = SEEN_LIST;
+        lds_words = LIST_CAP;
+      } else if (bm_fits) {
+        seen = SEEN_BITMAP;
+        lds_words = words;
+      } else {
+        return fail(BPR_ERR_UNSUPPORTED, "BPR_SEEN=bitmap: item table too large for LDS bitmaps");
+      }
+    }
+    const size_t shmem = (size_t)(block / G) * (size_t)lds_words * sizeof(uint32_t);
+    const int64_t per_block = (int64_t)(block / 64) * a.gpw_active;
+    int64_t want = a.n;
+    if (cap_groups > 0 && want > cap_groups) want = cap_groups;
+    int64_t nblk = (want + per_block - 1) / per_block;
+    const int64_t resident = 256 * 8;  // 256 CUs x up to 8 blocks: more only queues
+    if (nblk > resident) nblk = resident;
+    const unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
+    a.bm_words = lds_words;
+    const bool stateful = c->opt_kind != BPR_OPT_SGD;
+    {
+      Timer tm(c, true);
+      (void)tm;
+      auto go = [&](auto smp, auto sn) {
+        constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
+        if (stateful)
+          hipLaunchKernelGGL((k_vstream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
+                             c->stream, a);
+        else
+          hipLaunchKernelGGL((k_vstream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
+                             c->stream, a);
+      };
+      using std::integral_constant;
+      auto with_seen = [&](auto smp) {
+        if (seen == SEEN_BITMAP) go(smp, integral_constant<int, SEEN_BITMAP>{});
+        else if (seen == SEEN_LIST) go(smp, integral_constant<int, SEEN_LIST>{});
+        else go(smp, integral_constant<int, SEEN_CSR>{});
+      };
+      if (sampler == NEG_GIVEN)
+        go(integral_constant<int, NEG_GIVEN>{}, integral_constant<int, SEEN_CSR>{});
+      else if (sampler == NEG_UNIFORM) with_seen(integral_constant<int, NEG_UNIFORM>{});
+      else with_seen(integral_constant<int, NEG_ADAPTIVE>{});
+    }
+    if (out_scalars != nullptr)
+      hipLaunchKernelGGL(k_vsum_partials, dim3(1), dim3(256), 0, c->stream, a.partials, (int)grid,
+                         out_scalars);
+    BPR_HIP_CHECK(hipGetLastError());
+    return BPR_OK;
+  });
+}
+
+}  // namespace bpr
+
+using namespace bpr;
+
+extern "C" {
+
+int bpr_train_stream_batched(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg,
+                             int64_t n, int64_t B, int32_t sampler, float adaptive_p,
+                             uint64_t seed, uint64_t offset, int64_t max_inflight,
+                             float* out_scalars) {
+  if (int rc = check_triples(c, "bpr_train_stream_batched", users, pos, n)) return rc;
+  if (int rc = check_sampler(c, "bpr_train_stream_batched", sampler, adaptive_p, neg, n)) return rc;
+  if (B < 1) return fail(BPR_ERR_INVALID, "bpr_train_stream_batched: B must be >= 1");
+  if (int rc = check_opt_state(c, "bpr_train_stream_batched")) return rc;
+  if (c->pending != 0)
+    return fail(BPR_ERR_INVALID, "bpr_train_stream_batched: unapplied STRICT gradients pending");
+  if (n == 0) return BPR_OK;
+  const int64_t steps = (n + B - 1) / B;
+  if (n >= ((int64_t)1 << 31) || B >= ((int64_t)1 << 31) || c->step + steps >= VSTEP_MAX)
+    return fail(BPR_ERR_UNSUPPORTED,
+                "bpr_train_stream_batched: n, B and the optimizer step count must be < 2^31");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = vs_enter(c)) return rc;
+  VStreamArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = table_P(c);
+  a.Q = table_Q(c);
+  a.indptr = c->indptr; a.indices = c->indices;
+  a.order = c->order; a.sigma = c->sigma;
+  a.users = users; a.pos = pos; a.neg = neg;
+  a.partials = out_scalars != nullptr ? c->dev_scalars : nullptr;
+  a.seed = seed; a.offset = offset;
+  a.t_base = c->step + 1;
+  a.n = (int32_t)n; a.I = (int32_t)c->I; a.d = c->d; a.B = (int32_t)B;
+  a.pad_user = c->pad_user; a.pad_item = c->pad_item;
+  a.au = c->au; a.ai = c->ai; a.an = c->an;
+  a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
+  a.o = opt_dev(c, c->step + 1);
+  if (int rc = launch_vstream(c, a, sampler, max_inflight, out_scalars)) return rc;
+  c->step += steps;
+  return BPR_OK;
+}
+
+int bpr_shuffle_epoch(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n,
+                      uint64_t seed, int32_t* users_out, int32_t* pos_out) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_shuffle_epoch: ctx is NULL");
+  if (n < 0 || (n > 0 && (!users_in || !pos_in || !users_out || !pos_out)))
+    return fail(BPR_ERR_INVALID, "bpr_shuffle_epoch: bad argument");
+  if (users_in == users_out || pos_in == pos_out)
+    return fail(BPR_ERR_INVALID, "bpr_shuffle_epoch: outputs must not alias the inputs");
+  if (n == 0) return BPR_OK;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  int bits = 1;
+  while ((((uint64_t)(n - 1)) >> bits) != 0) ++bits;
+  const int half_bits = std::max(1, (bits + 1) / 2);
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_shuffle_scatter, dim3(grid), dim3(256), 0, c->stream, users_in, pos_in, n,
+                     half_bits, seed, users_out, pos_out);
+  BPR_HIP_CHECK(hipGetLastError());
+  return BPR_OK;
+}
+
+}  // extern "C"

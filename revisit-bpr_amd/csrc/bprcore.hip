@@ -9,6 +9,7 @@
 
 #include "bpr_ctx.h"
 #include "bpr_kernels.h"
+#include "bpr_host.h"
 
 namespace bpr {
 static_assert(ORDER_PAD == BPR_ORDER_PAD, "walk vector width vs snapshot padding");
@@ -16,29 +17,9 @@ static_assert(ORDER_PAD == BPR_ORDER_PAD, "walk vector width vs snapshot padding
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
-static int fail(int code, const std::string& msg) {
+int fail(int code, const std::string& msg) {
   set_error(msg);
   return code;
-}
-
-// ---- (G, E) dispatch: G lanes per triple, E elements per lane (bpr_device.h) --------------------
-template <int A, int B>
-struct GE {
-  static constexpr int G = A;
-  static constexpr int E = B;
-};
-
-template <typename F>
-static int dispatch_ge(int G, int E, F&& f) {
-  switch (G * 32 + E) {
-    case 32 * 32 + 1: return f(GE<32, 1>{});
-    case 32 * 32 + 2: return f(GE<32, 2>{});
-    case 32 * 32 + 4: return f(GE<32, 4>{});
-    case 64 * 32 + 4: return f(GE<64, 4>{});
-    case 64 * 32 + 8: return f(GE<64, 8>{});
-    case 64 * 32 + 16: return f(GE<64, 16>{});
-    default: return fail(BPR_ERR_UNSUPPORTED, "unsupported embedding dim");
-  }
 }
 
 static int max_blocks() {
@@ -68,7 +49,7 @@ static unsigned grid_for(int64_t n_groups, int G, int64_t cap_groups) {
   return (unsigned)blocks;
 }
 
-static int check_bound(const bpr_ctx* c, const char* who) {
+int check_bound(const bpr_ctx* c, const char* who) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, std::string(who) + ": ctx is NULL");
   if (c->P == nullptr || c->Q == nullptr)
     return fail(BPR_ERR_INVALID, std::string(who) + ": tables not bound (bpr_bind_tables)");
@@ -92,8 +73,9 @@ static int ensure_strict_scratch(bpr_ctx* c) {
   BPR_HIP_CHECK(hipMemsetAsync(c->Gb, 0, sizeof(float) * c->I, c->stream));
   BPR_HIP_CHECK(hipMemsetAsync(c->flagP, 0, sizeof(int32_t) * c->U, c->stream));
   BPR_HIP_CHECK(hipMemsetAsync(c->flagQ, 0, sizeof(int32_t) * c->I, c->stream));
-  BPR_HIP_CHECK(hipMemsetAsync(c->lastP, 0, sizeof(int32_t) * c->U, c->stream));
-  BPR_HIP_CHECK(hipMemsetAsync(c->lastQ, 0, sizeof(int32_t) * c->I, c->stream));
+  // rows are current as of the step counter (0, or a resumed checkpoint's: bpr_set_step)
+  BPR_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->lastP, (int)c->step, (size_t)c->U, c->stream));
+  BPR_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->lastQ, (int)c->step, (size_t)c->I, c->stream));
   BPR_HIP_CHECK(hipMemsetAsync(c->touched_cnt, 0, 2 * sizeof(uint32_t), c->stream));
   c->cnt_sel = 0;
   c->pending = 0;
@@ -110,7 +92,6 @@ static void free_strict_scratch(bpr_ctx* c) {
   c->pending = 0;
 }
 
-static OptDev opt_dev(const bpr_ctx* c, int64_t t);
 
 static TripleArgs triple_args(const bpr_ctx* c) {
   TripleArgs a;
@@ -130,7 +111,7 @@ static TripleArgs triple_args(const bpr_ctx* c) {
   return a;
 }
 
-static OptDev opt_dev(const bpr_ctx* c, int64_t t) {
+OptDev opt_dev(const bpr_ctx* c, int64_t t) {
   OptDev o;
   memset(&o, 0, sizeof(o));
   o.kind = c->opt_kind;
@@ -191,7 +172,7 @@ static ApplyArgs apply_args(const bpr_ctx* c, int64_t t) {
   return a;
 }
 
-static int check_opt_state(const bpr_ctx* c, const char* who) {
+int check_opt_state(const bpr_ctx* c, const char* who) {
   const bool need_m = c->opt_kind == BPR_OPT_MOMENTUM || c->opt_kind == BPR_OPT_ADAM;
   const bool need_v = c->opt_kind == BPR_OPT_ADAM || c->opt_kind == BPR_OPT_RMSPROP;
   if ((need_m && (!c->mP || !c->mQ || (c->bias && !c->mb))) ||
@@ -200,27 +181,6 @@ static int check_opt_state(const bpr_ctx* c, const char* who) {
                 std::string(who) + ": optimizer state not bound (bpr_bind_opt_state)");
   return BPR_OK;
 }
-
-struct Timer {
-  bpr_ctx* c;
-  size_t slot = 0;
-  bool on = false;
-  Timer(bpr_ctx* ctx, bool enabled) : c(ctx) {
-    if (!enabled || !c->timing) return;
-    if (c->ev_used == c->ev_start.size()) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-      c->ev_start.push_back(a);
-      c->ev_stop.push_back(b);
-    }
-    slot = c->ev_used++;
-    on = true;
-    hipEventRecord(c->ev_start[slot], c->stream);
-  }
-  ~Timer() {
-    if (on) hipEventRecord(c->ev_stop[slot], c->stream);
-  }
-};
 
 static int drain_timing(bpr_ctx* c) {
   if (c->ev_used == 0) return BPR_OK;
@@ -340,6 +300,53 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
   });
 }
 
+float inv_log1mp(float p) { return (float)(1.0 / log1p(-(double)p)); }
+
+
+int check_triples(const bpr_ctx* c, const char* who, const int32_t* users,
+                         const int32_t* pos, int64_t B) {
+  if (int rc = check_bound(c, who)) return rc;
+  if (B < 0 || (B > 0 && (users == nullptr || pos == nullptr)))
+    return fail(BPR_ERR_INVALID, std::string(who) + ": bad argument");
+  return BPR_OK;
+}
+
+int check_sampler(const bpr_ctx* c, const char* who, int32_t sampler, float adaptive_p,
+                         const int32_t* neg, int64_t B) {
+  if (sampler == BPR_NEG_GIVEN) {
+    if (neg == nullptr && B > 0) return fail(BPR_ERR_INVALID, std::string(who) + ": neg is NULL");
+    return BPR_OK;
+  }
+  if (sampler != BPR_NEG_UNIFORM && sampler != BPR_NEG_ADAPTIVE)
+    return fail(BPR_ERR_INVALID, std::string(who) + ": unknown sampler");
+  if (c->indptr == nullptr) return fail(BPR_ERR_INVALID, std::string(who) + ": seen CSR not bound");
+  if (sampler == BPR_NEG_ADAPTIVE) {
+    if (!c->have_snapshot)
+      return fail(BPR_ERR_INVALID, std::string(who) + ": call bpr_adaptive_refresh first");
+    if (!(adaptive_p > 0.f && adaptive_p < 1.f))
+      return fail(BPR_ERR_INVALID, std::string(who) + ": adaptive_p not in (0,1)");
+  }
+  return BPR_OK;
+}
+
+// STRICT lazy replay: bring every row to step c->step (rows tracked by lastP / lastQ)
+int strict_flush_impl(bpr_ctx* c) {
+  if (c->opt_kind == BPR_OPT_SGD || c->GP == nullptr || c->step == 0) return BPR_OK;
+  if (int rc = check_opt_state(c, "bpr_flush_lazy")) return rc;
+  // (accumulated gradients of a batch in flight are left alone: the flush only advances w / m / v
+  // and the rows' last-step marks, bpr_apply then finds nothing left to replay)
+  ApplyArgs a = apply_args(c, c->step);
+  return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_flush_lazy<T::G, T::E>), dim3(grid_for(c->U, T::G, 0)), dim3(256), 0,
+                       c->stream, a, 0);
+    hipLaunchKernelGGL((k_flush_lazy<T::G, T::E>), dim3(grid_for(c->I, T::G, 0)), dim3(256), 0,
+                       c->stream, a, 1);
+    BPR_HIP_CHECK(hipGetLastError());
+    return BPR_OK;
+  });
+}
+
 }  // namespace bpr
 
 using namespace bpr;
@@ -375,6 +382,7 @@ int bpr_ctx_destroy(bpr_ctx* c) {
   hipStreamSynchronize(c->stream);
   free_strict_scratch(c);
   refresh_free(c);
+  vs_free(c);
   hipFree(c->dev_scalars);
   for (auto e : c->ev_start) hipEventDestroy(e);
   for (auto e : c->ev_stop) hipEventDestroy(e);
@@ -403,6 +411,9 @@ int bpr_bind_tables(bpr_ctx* c, float* P, int64_t U, float* Q, int64_t I, int32_
     BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
     free_strict_scratch(c);
     refresh_free(c);
+    vs_free(c);
+  } else if (c->vs_active && (c->P != P || c->Q != Q || c->bias != item_bias)) {
+    if (int rc = vs_leave(c)) return rc;  // pending steps belong to the tables bound so far
   }
   c->P = P; c->Q = Q; c->bias = item_bias;
   c->U = U; c->I = I; c->d = d;
@@ -435,6 +446,12 @@ int bpr_set_optimizer(bpr_ctx* c, int32_t kind, const bpr_opt_params* params) {
     return fail(BPR_ERR_INVALID, "bpr_set_optimizer: unknown optimizer kind");
   if (kind == BPR_OPT_MOMENTUM && !(params->momentum >= 0.f && params->momentum < 1.f))
     return fail(BPR_ERR_INVALID, "bpr_set_optimizer: momentum must be in [0, 1)");
+  if (c->vs_active && (kind != c->opt_kind || memcmp(&c->opt, params, sizeof(*params)) != 0)) {
+    // batched STREAM: pending steps and the replay of missed ones use the hyper-parameters in
+    // force when they were taken — bring every row to "now" before those change
+    BPR_HIP_CHECK(hipSetDevice(c->device));
+    if (int rc = vs_leave(c)) return rc;
+  }
   c->opt_kind = kind;
   c->opt = *params;
   return BPR_OK;
@@ -443,6 +460,10 @@ int bpr_set_optimizer(bpr_ctx* c, int32_t kind, const bpr_opt_params* params) {
 int bpr_bind_opt_state(bpr_ctx* c, float* m_P, float* v_P, float* m_Q, float* v_Q, float* m_bias,
                        float* v_bias) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_bind_opt_state: ctx is NULL");
+  if (c->vs_active && (c->mP != m_P || c->vP != v_P || c->mQ != m_Q || c->vQ != v_Q)) {
+    BPR_HIP_CHECK(hipSetDevice(c->device));
+    if (int rc = vs_leave(c)) return rc;  // finish with the state tensors bound so far
+  }
   c->mP = m_P; c->vP = v_P; c->mQ = m_Q; c->vQ = v_Q; c->mb = m_bias; c->vb = v_bias;
   return BPR_OK;
 }
@@ -506,8 +527,6 @@ static SampleArgs sample_args(const bpr_ctx* c) {
   return a;
 }
 
-static float inv_log1mp(float p) { return (float)(1.0 / log1p(-(double)p)); }
-
 int bpr_sample_uniform(bpr_ctx* c, const int32_t* users, int64_t B, uint64_t seed, uint64_t offset,
                        int32_t* neg_out) {
   if (int rc = check_bound(c, "bpr_sample_uniform")) return rc;
@@ -522,6 +541,8 @@ int bpr_sample_uniform(bpr_ctx* c, const int32_t* users, int64_t B, uint64_t see
 int bpr_adaptive_refresh(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_adaptive_refresh")) return rc;
   BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (c->vs_active)  // batched STREAM: the snapshot must see the item rows as of "now"
+    if (int rc = vs_flush(c, false, true)) return rc;
   return refresh_impl(c);
 }
 
@@ -535,6 +556,7 @@ int bpr_sample_adaptive(bpr_ctx* c, const int32_t* users, int64_t B, float p, ui
   if (!(p > 0.f && p < 1.f)) return fail(BPR_ERR_INVALID, "bpr_sample_adaptive: p not in (0,1)");
   if (users == nullptr || neg_out == nullptr || B < 0)
     return fail(BPR_ERR_INVALID, "bpr_sample_adaptive: bad argument");
+  if (int rc = vs_leave(c)) return rc;  // reads the live user rows
   SampleArgs a = sample_args(c);
   a.users = users; a.n = B; a.seed = seed; a.offset = offset;
   a.neg = neg_out; a.factor_out = factor_out; a.rank_out = rank_out;
@@ -567,18 +589,11 @@ int bpr_adaptive_get_snapshot(bpr_ctx* c, int32_t* order_out, float* sigma_out) 
 }
 
 // ---- hot path -----------------------------------------------------------------------------------
-static int check_triples(const bpr_ctx* c, const char* who, const int32_t* users,
-                         const int32_t* pos, int64_t B) {
-  if (int rc = check_bound(c, who)) return rc;
-  if (B < 0 || (B > 0 && (users == nullptr || pos == nullptr)))
-    return fail(BPR_ERR_INVALID, std::string(who) + ": bad argument");
-  return BPR_OK;
-}
-
 int bpr_forward(bpr_ctx* c, const int32_t* users, const int32_t* pos, const int32_t* neg,
                 int64_t B, float* out_logits_pos, float* out_logits_neg, float* out_scalars) {
   if (int rc = check_triples(c, "bpr_forward", users, pos, B)) return rc;
   if (neg == nullptr && B > 0) return fail(BPR_ERR_INVALID, "bpr_forward: neg is NULL");
+  if (int rc = vs_leave(c)) return rc;
   TripleArgs a = triple_args(c);
   a.users = users; a.pos = pos; a.neg = neg; a.n = B;
   a.lpos = out_logits_pos; a.lneg = out_logits_neg; a.scalars = out_scalars;
@@ -590,6 +605,7 @@ int bpr_forward_grad(bpr_ctx* c, const int32_t* users, const int32_t* pos, const
   if (int rc = check_triples(c, "bpr_forward_grad", users, pos, B)) return rc;
   if (neg == nullptr && B > 0) return fail(BPR_ERR_INVALID, "bpr_forward_grad: neg is NULL");
   BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = vs_leave(c)) return rc;
   if (int rc = ensure_strict_scratch(c)) return rc;
   TripleArgs a = triple_args(c);
   a.users = users; a.pos = pos; a.neg = neg; a.n = B;
@@ -654,24 +670,6 @@ int bpr_get_grad(bpr_ctx* c, float* gP, float* gQ, float* gbias) {
   return BPR_OK;
 }
 
-static int check_sampler(const bpr_ctx* c, const char* who, int32_t sampler, float adaptive_p,
-                         const int32_t* neg, int64_t B) {
-  if (sampler == BPR_NEG_GIVEN) {
-    if (neg == nullptr && B > 0) return fail(BPR_ERR_INVALID, std::string(who) + ": neg is NULL");
-    return BPR_OK;
-  }
-  if (sampler != BPR_NEG_UNIFORM && sampler != BPR_NEG_ADAPTIVE)
-    return fail(BPR_ERR_INVALID, std::string(who) + ": unknown sampler");
-  if (c->indptr == nullptr) return fail(BPR_ERR_INVALID, std::string(who) + ": seen CSR not bound");
-  if (sampler == BPR_NEG_ADAPTIVE) {
-    if (!c->have_snapshot)
-      return fail(BPR_ERR_INVALID, std::string(who) + ": call bpr_adaptive_refresh first");
-    if (!(adaptive_p > 0.f && adaptive_p < 1.f))
-      return fail(BPR_ERR_INVALID, std::string(who) + ": adaptive_p not in (0,1)");
-  }
-  return BPR_OK;
-}
-
 int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t n,
                      int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
                      int64_t max_inflight, float* out_scalars) {
@@ -684,6 +682,7 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
   if (c->pending != 0)
     return fail(BPR_ERR_INVALID, "bpr_train_stream: unapplied STRICT gradients pending");
   BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = vs_leave(c)) return rc;
   if (n >= ((int64_t)1 << 31) || c->U * c->d >= ((int64_t)1 << 31) ||
       c->I * c->d >= ((int64_t)1 << 31))
     return fail(BPR_ERR_UNSUPPORTED,
@@ -759,17 +758,27 @@ int bpr_train_strict(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
     BPR_HIP_CHECK(hipMemsetAsync(c->dev_scalars, 0, sizeof(float) * 4 * stat_blocks, c->stream));
     c->defer_stats = true;
   }
+  // AdaptiveSampler.sample (neg_samplers.py:74-124): _iteration_cnt += 1; draw with the CURRENT
+  // snapshot; if _iteration_cnt % every == 0: update_stats() — i.e. the snapshot is retaken after
+  // the draws of that batch and BEFORE its optimizer step, and the counter lives as long as the
+  // sampler (it is not reset at epoch boundaries): c->strict_iter carries it across calls.
   int rc = BPR_OK;
-  int64_t batch = 0;
-  for (int64_t lo = 0; lo < n && rc == BPR_OK; lo += B, ++batch) {
+  for (int64_t lo = 0; lo < n && rc == BPR_OK; lo += B) {
     const int64_t b = n - lo < B ? n - lo : B;
     int32_t* neg = sampler == BPR_NEG_GIVEN ? neg_scratch + lo : neg_scratch;
-    rc = bpr_step(c, users + lo, pos + lo, neg, b, BPR_MODE_STRICT, sampler, adaptive_p, seed,
-                  offset + (uint64_t)lo, nullptr, nullptr, nullptr);
-    if (rc == BPR_OK && refresh_every > 0 && (batch + 1) % refresh_every == 0) {
+    if (sampler == BPR_NEG_UNIFORM)
+      rc = bpr_sample_uniform(c, users + lo, b, seed, offset + (uint64_t)lo, neg);
+    else if (sampler == BPR_NEG_ADAPTIVE)
+      rc = bpr_sample_adaptive(c, users + lo, b, adaptive_p, seed, offset + (uint64_t)lo, neg,
+                               nullptr, nullptr);
+    c->strict_iter += 1;
+    if (rc == BPR_OK && refresh_every > 0 && c->strict_iter % refresh_every == 0) {
       rc = bpr_flush_lazy(c);
       if (rc == BPR_OK) rc = bpr_adaptive_refresh(c);
     }
+    if (rc == BPR_OK)
+      rc = bpr_forward_grad(c, users + lo, pos + lo, neg, b, nullptr, nullptr, nullptr);
+    if (rc == BPR_OK) rc = bpr_apply(c);
   }
   c->defer_stats = false;
   if (rc != BPR_OK) return rc;
@@ -852,20 +861,9 @@ int bpr_plan_epoch(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, i
 
 int bpr_flush_lazy(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_flush_lazy")) return rc;
-  if (c->opt_kind == BPR_OPT_SGD || c->GP == nullptr || c->step == 0) return BPR_OK;
-  if (int rc = check_opt_state(c, "bpr_flush_lazy")) return rc;
-  if (c->pending != 0)
-    return fail(BPR_ERR_INVALID, "bpr_flush_lazy: unapplied gradients pending");
-  ApplyArgs a = apply_args(c, c->step);
-  return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
-    using T = decltype(tag);
-    hipLaunchKernelGGL((k_flush_lazy<T::G, T::E>), dim3(grid_for(c->U, T::G, 0)), dim3(256), 0,
-                       c->stream, a, 0);
-    hipLaunchKernelGGL((k_flush_lazy<T::G, T::E>), dim3(grid_for(c->I, T::G, 0)), dim3(256), 0,
-                       c->stream, a, 1);
-    BPR_HIP_CHECK(hipGetLastError());
-    return BPR_OK;
-  });
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (c->vs_active) return vs_flush(c, true, true);  // batched STREAM bookkeeping is live
+  return strict_flush_impl(c);
 }
 
 int bpr_get_step_host(bpr_ctx* c, int64_t* step_host) {
@@ -877,14 +875,24 @@ int bpr_get_step_host(bpr_ctx* c, int64_t* step_host) {
 
 int bpr_set_step(bpr_ctx* c, int64_t step) {
   if (c == nullptr || step < 0) return fail(BPR_ERR_INVALID, "bpr_set_step: bad argument");
+  if (c->vs_active) {
+    BPR_HIP_CHECK(hipSetDevice(c->device));
+    if (int rc = vs_leave(c)) return rc;
+  }
   // rows are assumed flushed at `step` (a checkpoint is written after bpr_flush_lazy)
   c->step = step;
   if (c->lastP != nullptr) {
-    BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
-    std::vector<int32_t> h((size_t)(c->U > c->I ? c->U : c->I), (int32_t)step);
-    BPR_HIP_CHECK(hipMemcpy(c->lastP, h.data(), sizeof(int32_t) * c->U, hipMemcpyHostToDevice));
-    BPR_HIP_CHECK(hipMemcpy(c->lastQ, h.data(), sizeof(int32_t) * c->I, hipMemcpyHostToDevice));
+    BPR_HIP_CHECK(hipSetDevice(c->device));
+    BPR_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->lastP, (int)step, (size_t)c->U, c->stream));
+    BPR_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->lastQ, (int)step, (size_t)c->I, c->stream));
   }
+  return BPR_OK;
+}
+
+int bpr_set_sampler_iter(bpr_ctx* c, int64_t iteration) {
+  if (c == nullptr || iteration < 0)
+    return fail(BPR_ERR_INVALID, "bpr_set_sampler_iter: bad argument");
+  c->strict_iter = iteration;
   return BPR_OK;
 }
 

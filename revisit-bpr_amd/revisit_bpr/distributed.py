@@ -82,6 +82,17 @@ class ItemSync:
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    def max_over_ranks(self, value: int) -> int:
+        """MAX of a host integer over the group (e.g. chunks per epoch: ranks whose shard holds
+        fewer chunks must still take part in every reconciliation, or the collectives of different
+        ranks stop matching up)."""
+        if self.world == 1:
+            return int(value)
+        dev = self.tensors[0].device if self.tensors else torch.device("cpu")
+        t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
     # ---- the two elementwise passes ---------------------------------------------------------
     def _delta(self, t, b, own, tot) -> None:
         if self._lib is not None:

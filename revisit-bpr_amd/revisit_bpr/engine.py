@@ -265,6 +265,33 @@ class Engine:
                                                 adaptive_p, seed, offset, refresh_every,
                                                 _ptr(scalars)))
 
+    def train_stream_batched(self, users, pos, batch_size: int, sampler: int = NEG_UNIFORM,
+                             neg: Optional[torch.Tensor] = None, adaptive_p: float = 0.01,
+                             seed: int = 0, offset: int = 0, max_inflight: int = 0,
+                             scalars: Optional[torch.Tensor] = None) -> None:
+        """BATCHED STREAM over users/pos (int32, on device, shuffled — not grouped by user) in one
+        launch, any optimizer: virtual mini-batches of `batch_size` consecutive triples, one
+        torch.optim step per row and batch (see include/bprcore.h)."""
+        self._sync_stream()
+        if users.dtype != torch.int32 or pos.dtype != torch.int32:
+            raise ValueError("train_stream_batched takes int32 id tensors")
+        if sampler == NEG_GIVEN and neg is None:
+            raise ValueError("sampler NEG_GIVEN needs `neg`")
+        native.check(self._lib.bpr_train_stream_batched(
+            self._ctx, users.data_ptr(), pos.data_ptr(), _ptr(neg), users.numel(), batch_size,
+            sampler, adaptive_p, seed, offset, max_inflight, _ptr(scalars)))
+
+    def shuffle_epoch(self, users: torch.Tensor, pos: torch.Tensor, seed: int,
+                      out: Optional[tuple[torch.Tensor, torch.Tensor]] = None):
+        """Seeded pseudo-random permutation of the training triples (on device)."""
+        self._sync_stream()
+        if users.dtype != torch.int32 or pos.dtype != torch.int32:
+            raise ValueError("shuffle_epoch takes int32 id tensors")
+        uo, po = out if out is not None else (torch.empty_like(users), torch.empty_like(pos))
+        native.check(self._lib.bpr_shuffle_epoch(self._ctx, users.data_ptr(), pos.data_ptr(),
+                                                 users.numel(), seed, uo.data_ptr(), po.data_ptr()))
+        return uo, po
+
     def set_stream_opts(self, grouped_by_user: bool, run_len: int = 8) -> None:
         native.check(self._lib.bpr_set_stream_opts(self._ctx, int(grouped_by_user), run_len))
 
@@ -297,6 +324,10 @@ class Engine:
 
     def set_step(self, step: int) -> None:
         native.check(self._lib.bpr_set_step(self._ctx, step))
+
+    def set_sampler_iter(self, iteration: int) -> None:
+        """Batch counter of the train_strict loop (AdaptiveSampler._iteration_cnt)."""
+        native.check(self._lib.bpr_set_sampler_iter(self._ctx, iteration))
 
     # ---- measurement ------------------------------------------------------------------------
     def timing_enable(self, on: bool = True) -> None:

@@ -10,6 +10,7 @@ from __future__ import annotations
 import math
 from typing import Optional
 
+import numpy as np
 import torch
 
 from revisit_bpr import engine as eng
@@ -54,24 +55,29 @@ class StreamTrainer:
         self._pi = torch.empty_like(self.items)
         self._scalars = torch.zeros(4, dtype=torch.float32, device=users.device)
         self.item_sync, self.sync_every = item_sync, sync_every
+        # shards are balanced by interactions, not equal: every rank runs the same number of
+        # rounds per epoch (a rank out of triples still joins the item reconciliations)
+        self.rounds = -(-self.n // self.chunk)
+        if item_sync is not None:
+            self.rounds = item_sync.max_over_ranks(self.rounds)
 
     def train_epoch(self) -> dict:
         e = self.engine
         e.plan_epoch(self.users, self.items, self.chunk, self.seed + self.epoch,
                      out=(self._pu, self._pi))
         self._scalars.zero_()
-        k = 0
-        for lo in range(0, self.n, self.chunk):
+        for k in range(self.rounds):
+            lo = k * self.chunk
             hi = min(lo + self.chunk, self.n)
-            if self.sampler == eng.NEG_ADAPTIVE:
-                e.adaptive_refresh()
-            e.train_stream(self._pu[lo:hi], self._pi[lo:hi], sampler=self.sampler,
-                           adaptive_p=self.adaptive_p, seed=self.seed,
-                           offset=(self.rank << 40) + self.drawn, max_inflight=self.max_inflight,
-                           scalars=self._scalars)
-            self.drawn += hi - lo
-            k += 1
-            if self.item_sync is not None and k % self.sync_every == 0:
+            if lo < hi:
+                if self.sampler == eng.NEG_ADAPTIVE:
+                    e.adaptive_refresh()
+                e.train_stream(self._pu[lo:hi], self._pi[lo:hi], sampler=self.sampler,
+                               adaptive_p=self.adaptive_p, seed=self.seed,
+                               offset=(self.rank << 40) + self.drawn,
+                               max_inflight=self.max_inflight, scalars=self._scalars)
+                self.drawn += hi - lo
+            if self.item_sync is not None and (k + 1) % self.sync_every == 0:
                 self.item_sync.step()
         if self.item_sync is not None:
             self.item_sync.finish()
@@ -95,7 +101,12 @@ class StrictTrainer:
     def __init__(self, model, optimizer, users: torch.Tensor, items: torch.Tensor,
                  seen_indptr: torch.Tensor, seen_indices: torch.Tensor, sampler: str = "adaptive",
                  adaptive_p: float = 0.01, batch_size: int = 256, seed: int = 13, rank: int = 0,
-                 item_sync=None, world: Optional[int] = None) -> None:
+                 item_sync=None, world: Optional[int] = None,
+                 order_seed: Optional[int] = None) -> None:
+        """order_seed: the epoch permutations come from ``np.random.default_rng(order_seed)`` (one
+        ``permutation(n)`` per epoch, the DataLoader(shuffle=True) stand-in of
+        tests/golden/make_golden_e2e.py) instead of a device randperm seeded by `seed` — parity
+        runs feed the reference's own epoch order."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
             raise ValueError("users / items must be int32 device tensors")
         self.model, self.optimizer = model, optimizer
@@ -113,14 +124,21 @@ class StrictTrainer:
         self.chunk_batches = max(1, self.every // max(world, 1))
         self.seed, self.rank = seed, rank
         self.gen = torch.Generator(device=users.device).manual_seed(seed * 1000003 + rank)
+        self._order_rng = None if order_seed is None else np.random.default_rng(order_seed)
         self.drawn = 0
         self._scalars = torch.zeros(4, dtype=torch.float32, device=users.device)
         self._fresh = False
+        self.rounds = -(-self.n // (self.chunk_batches * batch_size))
+        if item_sync is not None:  # same number of reconciliations on every rank (see StreamTrainer)
+            self.rounds = item_sync.max_over_ranks(self.rounds)
 
     def train_epoch(self) -> dict:
         model, e, B = self.model, self.engine, self.batch
         model.train()
-        perm = torch.randperm(self.n, device=self.users.device, generator=self.gen)
+        if self._order_rng is not None:
+            perm = torch.from_numpy(self._order_rng.permutation(self.n)).to(self.users.device)
+        else:
+            perm = torch.randperm(self.n, device=self.users.device, generator=self.gen)
         u, i = self.users[perm].contiguous(), self.items[perm].contiguous()
         adaptive = self.sampler == eng.NEG_ADAPTIVE
         self._scalars.zero_()
@@ -133,18 +151,94 @@ class StrictTrainer:
                                refresh_every=self.every if adaptive else 0, scalars=self._scalars)
         else:
             step = self.chunk_batches * B
-            for lo in range(0, self.n, step):
+            for k in range(self.rounds):
+                lo = k * step
                 hi = min(lo + step, self.n)
-                model.train_strict(self.optimizer, u[lo:hi], i[lo:hi], B, self.sampler,
-                                   adaptive_p=self.adaptive_p, seed=self.seed,
-                                   offset=(self.rank << 40) + self.drawn + lo, refresh_every=0,
-                                   scalars=self._scalars)
+                if lo < hi:
+                    model.train_strict(self.optimizer, u[lo:hi], i[lo:hi], B, self.sampler,
+                                       adaptive_p=self.adaptive_p, seed=self.seed,
+                                       offset=(self.rank << 40) + self.drawn + lo, refresh_every=0,
+                                       scalars=self._scalars)
                 e.flush_lazy()
                 self.item_sync.step()
                 if adaptive:
                     e.adaptive_refresh()
             self.item_sync.finish()
         self.drawn += self.n
+        sc = self._scalars.tolist()
+        cnt = max(sc[3], 1.0)
+        return {"bpr_loss": sc[0] / cnt, "l2_reg": sc[1] / cnt, "logits_diff": sc[2] / cnt,
+                "loss": (sc[0] + sc[1]) / cnt, "triples": int(sc[3])}
+
+
+class BatchedStreamTrainer:
+    """Epochs of the reference's mini-batch loop with ANY torch.optim optimizer the engine mirrors
+    (SGD, momentum / Nesterov, Adam, RMSprop) as fused launches: per epoch a seeded device shuffle
+    (`bpr_shuffle_epoch`), then per sampler-refresh period `bpr_adaptive_refresh` + ONE
+    `bpr_train_stream_batched` launch whose virtual mini-batches of `batch_size` triples take one
+    dense optimizer step each (lazy replay for the rows a batch does not touch).  This is the
+    throughput path of the Adam configs (configs/RQ3/time-split/ada-sampling-adam.yaml.j2);
+    `StrictTrainer` is the same loop with a launch triple per batch and no asynchrony.
+
+    Several GPUs: users sharded, item table (+ bias) reconciled by `item_sync` every refresh period
+    of the whole job, optimizer state of the item table local to the rank (as StrictTrainer)."""
+
+    def __init__(self, model, optimizer, users: torch.Tensor, items: torch.Tensor,
+                 seen_indptr: torch.Tensor, seen_indices: torch.Tensor, sampler: str = "adaptive",
+                 adaptive_p: float = 0.01, batch_size: int = 256, seed: int = 13,
+                 max_inflight: Optional[int] = None, rank: int = 0, item_sync=None,
+                 world: Optional[int] = None) -> None:
+        if users.dtype != torch.int32 or items.dtype != torch.int32:
+            raise ValueError("users / items must be int32 device tensors")
+        self.model, self.optimizer = model, optimizer
+        self.engine = model.engine()
+        self.users, self.items = users.contiguous(), items.contiguous()
+        self.n = users.numel()
+        model.bind_seen_csr(seen_indptr, seen_indices)
+        self.sampler = {"adaptive": eng.NEG_ADAPTIVE, "uniform": eng.NEG_UNIFORM}[sampler]
+        self.adaptive_p, self.batch = adaptive_p, batch_size
+        I, U = self.engine.I, self.engine.U
+        every = max(1, int(I * math.log(I) / batch_size))  # example.py:302
+        if world is None:
+            world = item_sync.world if item_sync is not None else 1
+        self.chunk = max(batch_size, every // max(world, 1) * batch_size)
+        # staleness budget (DESIGN.md §5): at most ~U/4 triples against one parameter cut
+        self.max_inflight = max(64, U // 4) if max_inflight is None else max_inflight
+        self.seed, self.rank = seed, rank
+        self.epoch = 0
+        self.drawn = 0
+        self.item_sync = item_sync
+        self._pu = torch.empty_like(self.users)
+        self._pi = torch.empty_like(self.items)
+        self._scalars = torch.zeros(4, dtype=torch.float32, device=users.device)
+        self.rounds = -(-self.n // self.chunk)
+        if item_sync is not None:
+            self.rounds = item_sync.max_over_ranks(self.rounds)
+
+    def train_epoch(self) -> dict:
+        model, e = self.model, self.engine
+        model.train()
+        e.shuffle_epoch(self.users, self.items, (self.seed << 20) + (self.rank << 12) + self.epoch,
+                        out=(self._pu, self._pi))
+        self._scalars.zero_()
+        adaptive = self.sampler == eng.NEG_ADAPTIVE
+        for k in range(self.rounds):
+            lo = k * self.chunk
+            hi = min(lo + self.chunk, self.n)
+            if lo < hi:
+                if adaptive:
+                    e.adaptive_refresh()  # brings the item rows to "now" first
+                model.train_stream_batched(self.optimizer, self._pu[lo:hi], self._pi[lo:hi],
+                                           self.batch, self.sampler, adaptive_p=self.adaptive_p,
+                                           seed=self.seed, offset=(self.rank << 40) + self.drawn,
+                                           max_inflight=self.max_inflight, scalars=self._scalars)
+                self.drawn += hi - lo
+            if self.item_sync is not None:
+                e.flush_lazy()
+                self.item_sync.step()
+        if self.item_sync is not None:
+            self.item_sync.finish()
+        self.epoch += 1
         sc = self._scalars.tolist()
         cnt = max(sc[3], 1.0)
         return {"bpr_loss": sc[0] / cnt, "l2_reg": sc[1] / cnt, "logits_diff": sc[2] / cnt,

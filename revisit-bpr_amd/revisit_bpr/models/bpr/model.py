@@ -121,8 +121,17 @@ def _optimizer_pre_hook(optimizer, args, kwargs):
             ref = _FUSED_PARAMS.get(id(prm))
             model = ref() if ref is not None else None
             if model is not None and model._engine is not None:
-                models[id(model)] = (model, group)
-    for model, group in models.values():
+                seen = models.setdefault(id(model), (model, group, []))
+                if seen[1] is not group:
+                    raise NotImplementedError(
+                        "the fused BPR update applies ONE set of hyper-parameters to the user, item "
+                        "and bias tables: keep them in a single param group (or use "
+                        "set_backend('torch'))")
+                seen[2].append(prm)
+    for model, group, prms in models.values():
+        if model._pending and len(prms) != len(model._fused_params()):
+            raise NotImplementedError(
+                "the fused BPR tables must all belong to the optimizer that steps them")
         model._apply_pending(optimizer, group)
     return None
 
@@ -156,6 +165,7 @@ class Model(torch.nn.Module):
         self._armed = False
         self._pending = False
         self._opt_sig = None
+        self._state_sig = None
         self._anchor = None
 
     # ---- fused engine plumbing ------------------------------------------------------------
@@ -182,6 +192,7 @@ class Model(torch.nn.Module):
             self._engine.set_reg(*resolve_reg_alphas(self._reg_alphas))
             self._engine_key = key
             self._opt_sig = None
+            self._state_sig = None
             self._pending = self._armed = False
             for prm in (P, Q, b):
                 if prm is not None:
@@ -229,14 +240,22 @@ class Model(torch.nn.Module):
             kind = 1
         if name == "RMSprop" and group.get("momentum", 0) != 0:
             raise NotImplementedError("RMSprop with momentum is not fused")
-        sig = (kind, group["lr"], group.get("momentum", 0.0), group.get("dampening", 0.0),
+        sig = (kind, float(group["lr"]), group.get("momentum", 0.0), group.get("dampening", 0.0),
                bool(group.get("nesterov", False)), tuple(group.get("betas", (0.9, 0.999))),
                group.get("eps", 1e-8), group.get("alpha", 0.99))
         if sig != self._opt_sig:
+            # rows are brought to "now" lazily with the CURRENT hyper-parameters: a changed lr /
+            # betas / momentum (LR scheduler, manual edit) must not be applied to the zero-gradient
+            # steps a row missed under the old ones — replay those first
+            if self._opt_sig is not None and self._opt_sig[0] != 0 and eng.step_count > 0:
+                eng.flush_lazy()
             eng.set_optimizer(kind, lr=sig[1], momentum=sig[2], dampening=sig[3], nesterov=sig[4],
                               betas=sig[5], eps=sig[6], alpha=sig[7])
-            self._bind_state(optimizer, kind)
             self._opt_sig = sig
+            self._state_sig = None
+        # the state tensors are looked up on every call: optimizer.load_state_dict() (checkpoint
+        # resume) replaces them, and the engine must follow
+        self._bind_state(optimizer, kind)
         return kind
 
     def train_strict(self, optimizer, users: torch.Tensor, items: torch.Tensor, batch_size: int,
@@ -263,16 +282,46 @@ class Model(torch.nn.Module):
                 st["step"] = st.get("step", 0) + steps
         return steps
 
+    def train_stream_batched(self, optimizer, users: torch.Tensor, items: torch.Tensor,
+                             batch_size: int, sampler: int, adaptive_p: float = 0.0, seed: int = 0,
+                             offset: int = 0, max_inflight: int = 0,
+                             scalars: Optional[torch.Tensor] = None) -> int:
+        """The same loop as train_strict — virtual mini-batches of `batch_size` consecutive
+        triples, one torch.optim step per batch — as ONE fused launch (`bpr_train_stream_batched`,
+        any optimizer): triples of neighbouring batches run concurrently, so a gradient may see
+        rows that are a few steps stale (bounded by `max_inflight`).  Returns the steps taken."""
+        eng = self.engine()
+        if self._pending:
+            raise RuntimeError("a forward() is waiting for optimizer.step()")
+        groups = [g for g in optimizer.param_groups
+                  if any(id(p) in _FUSED_PARAMS for p in g["params"])]
+        if len(groups) != 1:
+            raise ValueError("the fused tables must sit in exactly one param group")
+        kind = self._configure_optimizer(optimizer, groups[0])
+        eng.train_stream_batched(users, items, batch_size, sampler=sampler, adaptive_p=adaptive_p,
+                                 seed=seed, offset=offset, max_inflight=max_inflight,
+                                 scalars=scalars)
+        steps = (users.numel() + batch_size - 1) // batch_size
+        if kind != 0:
+            for prm in self._fused_params():
+                st = optimizer.state[prm]
+                st["step"] = st.get("step", 0) + steps
+        return steps
+
     def _fused_params(self):
         lm = self.logits_model
         return [t for t in (lm._user_emb.weight, lm._item_emb.weight, lm._item_bias) if t is not None]
 
     def _bind_state(self, optimizer, kind: int) -> None:
-        """Create torch-compatible optimizer state tensors and hand their storage to the engine."""
+        """Create torch-compatible optimizer state tensors and hand their storage to the engine.
+        Re-binds whenever the tensors in ``optimizer.state`` are not the bound ones any more
+        (``load_state_dict``), and then also restores the engine's step counter from
+        ``state["step"]`` — the loaded rows are "as of that step" (checkpoints are written after
+        ``Model.sync()``), so bias corrections and the lazy replay continue where they stopped."""
         if kind == 0:
             return
         keys = {1: ("momentum_buffer", None), 2: ("exp_avg", "exp_avg_sq"), 3: (None, "square_avg")}[kind]
-        bufs = []
+        bufs, created = [], False
         for prm in self._fused_params():
             st = optimizer.state[prm]
             pair = []
@@ -282,18 +331,43 @@ class Model(torch.nn.Module):
                     continue
                 if k not in st or st[k] is None:
                     st[k] = torch.zeros_like(prm, memory_format=torch.preserve_format)
+                    created = True
                 pair.append(st[k])
             st.setdefault("step", 0)
             bufs.append(pair)
+        sig = tuple(None if t is None else t.data_ptr() for pair in bufs for t in pair)
+        if sig == self._state_sig:
+            return
+        for pair in bufs:
+            for t in pair:
+                if t is not None and (not t.is_contiguous() or t.dtype != torch.float32):
+                    raise ValueError("optimizer state tensors must be contiguous float32")
         (mP, vP), (mQ, vQ) = bufs[0], bufs[1]
         mb, vb = bufs[2] if len(bufs) > 2 else (None, None)
-        self._engine.bind_opt_state(mP, vP, mQ, vQ, mb, vb)
+        eng = self._engine
+        if self._state_sig is not None or not created:
+            # foreign tensors (a loaded checkpoint): rows in them are current as of `step`
+            step = max(int(optimizer.state[prm]["step"]) for prm in self._fused_params())
+            if kind == 1 and step == 0 and not created:
+                step = 1  # torch's SGD keeps no step: a present momentum_buffer means "not the first"
+            if step != eng.step_count:
+                eng.set_step(step)
+        eng.bind_opt_state(mP, vP, mQ, vQ, mb, vb)
+        self._state_sig = sig
 
     def sync(self) -> None:
         """Bring every row to the current optimizer step (lazy dense-optimizer replay): called
         automatically before eval and state_dict."""
-        if self._engine is not None and not self._pending:
-            self._engine.flush_lazy()
+        if self._engine is None:
+            return
+        if self._pending:
+            if self._armed:
+                raise RuntimeError("loss.backward() was called but optimizer.step() was not: step "
+                                   "(or zero the gradients by a new forward) before eval / state_dict")
+            # forward without backward: torch would hold no gradient either
+            self._engine.discard_grad()
+            self._pending = False
+        self._engine.flush_lazy()
 
     def train(self, mode: bool = True):
         if not mode:

@@ -74,6 +74,10 @@ SIGNATURES = {
                          c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "bpr_train_stream": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
                                  c_uint64, c_uint64, c_int64, c_void_p]),
+    "bpr_train_stream_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                         c_int32, c_float, c_uint64, c_uint64, c_int64, c_void_p]),
+    "bpr_shuffle_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_void_p,
+                                  c_void_p]),
     "bpr_train_strict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
                                  c_float, c_uint64, c_uint64, c_int64, c_void_p]),
     "bpr_item_delta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -88,6 +92,7 @@ SIGNATURES = {
     "bpr_flush_lazy": (c_int, [c_void_p]),
     "bpr_get_step_host": (c_int, [c_void_p, POINTER(c_int64)]),
     "bpr_set_step": (c_int, [c_void_p, c_int64]),
+    "bpr_set_sampler_iter": (c_int, [c_void_p, c_int64]),
     "bpr_timing_enable": (c_int, [c_void_p, c_int32]),
     "bpr_timing_read_host": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
 }

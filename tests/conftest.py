@@ -32,7 +32,23 @@ def _has_gpu() -> bool:
         return False
 
 
+# Deterministic suites first: the bit-exact kernel-vs-oracle file and the full-size property tests
+# must never sit behind a Monte-Carlo (seed-mean) test when the driver runs `pytest -x`.
+FILE_ORDER = ["test_abi", "test_oracle_golden", "test_config_cpu", "test_distributed_cpu",
+              "test_gpu_parity", "test_gpu_vstream", "test_gpu_api", "test_gpu_baseline_configs",
+              "test_gpu_fullsize", "test_gpu_config_run", "test_gpu_example",
+              # statistical (seed means against the reference's curves) — last
+              "test_gpu_sampler_stats", "test_gpu_e2e_parity", "test_gpu_multirank_parity",
+              "test_gpu_fullscale_parity"]
+
+
+def _file_rank(item) -> int:
+    name = Path(str(item.fspath)).stem
+    return FILE_ORDER.index(name) if name in FILE_ORDER else len(FILE_ORDER) // 2
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_file_rank)  # stable: the order inside a file is kept
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

@@ -71,7 +71,8 @@ def evaluate(model, data, seen_all):
 
 
 ADAM_LR = 0.0005  # torch.optim.Adam, default betas: the optimizer of 14 of the 22 reference configs
-OPT_KW = {"adam": {"lr": ADAM_LR, "betas": [0.9, 0.999]},
+OPT_KW = {"sgd": {"lr": LR},
+          "adam": {"lr": ADAM_LR, "betas": [0.9, 0.999]},
           "rmsprop": {"lr": 0.0005, "alpha": 0.9},  # alpha as in configs/RQ2/optimizers/rmsprop-*.yaml.j2
           "nesterov": {"lr": 0.01, "momentum": 0.9, "nesterov": True}}
 OPTIMIZERS = {
@@ -115,9 +116,24 @@ def run(data, seen_all, sampler_kind, sampler_seed, optimizer="sgd"):
     return curve
 
 
+def merge(name):
+    """`make_golden_e2e.py merge sgd|adam|rmsprop|nesterov`: fold the per-run files written by
+    `make_golden_e2e.py <optimizer> <kind>_<seed> ...` into the optimizer's fixture and remove them."""
+    main_file = OUT / ("e2e_reference.json" if name == "sgd" else f"e2e_reference_{name}.json")
+    res = json.loads(main_file.read_text())
+    for f in sorted(OUT.glob(f"e2e_reference_{name}_*_*.json")):
+        run = f.stem[len(f"e2e_reference_{name}_"):]
+        j = json.loads(f.read_text())
+        res["runs"][run] = {"ndcg@100": j["ndcg@100"], "recall@20": j["recall@20"]}
+        f.unlink()
+    main_file.write_text(json.dumps(res, indent=1))
+    print(main_file.name, sorted(res["runs"]))
+
+
 def main_opt(name, only):
-    """`make_golden_e2e.py adam|rmsprop|nesterov [adaptive_1 ...]`: the same protocol with another
-    torch.optim optimizer -> tests/golden/e2e_reference_<optimizer>_<run>.json (one file per run, so seeds can run in parallel);
+    """`make_golden_e2e.py sgd|adam|rmsprop|nesterov <kind>_<seed> ...`: the same protocol with the
+    named torch.optim optimizer, any sampler seed -> tests/golden/e2e_reference_<optimizer>_<run>.json
+    (one file per run, so seeds can run in parallel; `merge` folds them into the fixture);
     the dataset file is not rewritten."""
     torch.set_num_threads(1)
     data = synthetic.generate_latent(USERS, ITEMS, ACTIONS, factors=8, strength=1.5,
@@ -125,20 +141,21 @@ def main_opt(name, only):
     saved = np.load(OUT / "e2e_data.npz")
     assert np.array_equal(saved["users"], data.users) and np.array_equal(saved["items"], data.items)
     seen_all = padded_seen(data, np.arange(data.num_users))
-    for kind in ("uniform", "adaptive"):
-        for s in SAMPLER_SEEDS:
-            if only and f"{kind}_{s}" not in only:
-                continue
-            t0 = time.time()
-            curve = run(data, seen_all, kind, s, optimizer=name)
-            out = {"optimizer": name, **OPT_KW[name],
-                   "ndcg@100": [c[0] for c in curve], "recall@20": [c[1] for c in curve]}
-            (OUT / f"e2e_reference_{name}_{kind}_{s}.json").write_text(json.dumps(out, indent=1))
-            print(name, kind, s, f"{time.time() - t0:.0f}s", [round(c[0], 4) for c in curve],
-                  flush=True)
+    runs = [(k, int(s)) for k, s in (r.split("_") for r in only)] if only else \
+        [(k, s) for k in ("uniform", "adaptive") for s in SAMPLER_SEEDS]
+    for kind, s in runs:
+        t0 = time.time()
+        curve = run(data, seen_all, kind, s, optimizer=name)
+        out = {"optimizer": name, **OPT_KW[name],
+               "ndcg@100": [c[0] for c in curve], "recall@20": [c[1] for c in curve]}
+        (OUT / f"e2e_reference_{name}_{kind}_{s}.json").write_text(json.dumps(out, indent=1))
+        print(name, kind, s, f"{time.time() - t0:.0f}s", [round(c[0], 4) for c in curve],
+              flush=True)
 
 
 def main():
+    if sys.argv[1:2] == ["merge"]:
+        return merge(sys.argv[2])
     if sys.argv[1:2] and sys.argv[1] in OPT_KW:
         return main_opt(sys.argv[1], sys.argv[2:] or None)
     torch.set_num_threads(8)

@@ -131,3 +131,32 @@ def test_user_sharded_training_gloo_world2():
             deltas.append(Qr - Q)
         Q = Q + deltas[0] + deltas[1]
     assert np.allclose(Q, Q0, atol=1e-6)
+
+
+def _worker_rounds(rank, world, port, out):
+    """Ranks whose shards cut into different numbers of chunks still issue the same sequence of
+    collectives (an extra all-reduce on one rank is an RCCL hang)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Q = torch.zeros(20, 4)
+    sync = ItemSync([Q])
+    chunk, n = 100, (250 if rank == 0 else 390)  # 3 vs 4 chunks
+    rounds = sync.max_over_ranks(-(-n // chunk))
+    trained = 0
+    for k in range(rounds):
+        lo, hi = k * chunk, min((k + 1) * chunk, n)
+        if lo < hi:
+            Q[rank] += float(hi - lo)
+            trained += hi - lo
+        sync.step()
+    sync.finish()
+    sync.sync()
+    out[rank] = (rounds, trained, Q[0, 0].item(), Q[1, 0].item())
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_keep_collectives_matched():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_rounds, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: (4, 250, 250.0, 390.0), 1: (4, 390, 250.0, 390.0)}

@@ -297,3 +297,123 @@ def test_user_bias_is_carried_but_never_updated():
     assert torch.allclose(outs["hip"][0], outs["torch"][0], atol=1e-5)
     assert torch.equal(outs["hip"][1], torch.linspace(-1, 1, U)) and torch.allclose(outs["hip"][1], outs["torch"][1])
     assert torch.allclose(outs["hip"][2], outs["torch"][2], atol=1e-5)
+
+
+def _run_loop(model, opt, data, sched=None):
+    model.train()
+    for b in data:
+        out = model(b)
+        out["loss"].backward()
+        opt.step()
+        opt.zero_grad()
+        if sched is not None:
+            sched.step()
+
+
+@pytest.mark.parametrize("opt_name", ["adam", "nesterov", "rmsprop"])
+@pytest.mark.parametrize("from_torch", [False, True])
+def test_checkpoint_resume_continues_the_trajectory(opt_name, from_torch):
+    """state_dict() after 4 steps -> fresh model + optimizer -> load_state_dict -> 4 more steps ==
+    8 uninterrupted steps: the engine re-binds the LOADED exp_avg / exp_avg_sq /
+    momentum_buffer tensors and resumes its step counter from state['step'], so Adam's bias
+    corrections and the lazy replay continue at t = 5.  from_torch: the checkpoint is written by
+    the dense PyTorch restatement (stock torch.optim state: tensor steps, no step for SGD)."""
+    from revisit_bpr.models.bpr import set_backend
+
+    U, I, d, B = 300, 200, 64, 64
+    reg = {"user": 0.0016, "item": 0.0001, "neg": 0.00375}
+    data = batches(U, I, B, 8, seed=5)
+    ref = build(U, I, d, reg, True, seed=11)
+    opt = OPTS[opt_name](ref.parameters())
+    _run_loop(ref, opt, data)
+    want = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+
+    try:
+        set_backend("torch" if from_torch else "hip")
+        first = build(U, I, d, reg, True, seed=11)
+        opt1 = OPTS[opt_name](first.parameters())
+        _run_loop(first, opt1, data[:4])
+        ck_model = {k: v.detach().clone() for k, v in first.state_dict().items()}
+        ck_opt = opt1.state_dict()
+    finally:
+        set_backend("hip")
+    second = build(U, I, d, reg, True, seed=99)  # different init: everything comes from the checkpoint
+    second.load_state_dict(ck_model)
+    opt2 = OPTS[opt_name](second.parameters())
+    opt2.load_state_dict(ck_opt)
+    _run_loop(second, opt2, data[4:])
+    got = second.state_dict()
+    # (torch's SGD keeps no step counter: a loaded momentum_buffer only says "not the first step")
+    assert second.engine().step_count == (5 if from_torch and opt_name == "nesterov" else 8)
+    atol = 1e-4 if opt_name == "rmsprop" else 2e-5
+    for k in want:
+        err = (got[k] - want[k]).abs()
+        if from_torch and opt_name != "nesterov":
+            # dense autograd wrote the checkpoint: Adam / RMSprop elements whose fp32 gradient sum is
+            # within rounding of zero differ between the two backends (see close_mostly)
+            assert (err > atol).float().mean() <= 1e-3 and err.max() <= 0.1, (k, err.max())
+        else:
+            assert err.max() <= atol, (k, err.max())
+    # the state the optimizer reports is the state the engine wrote
+    key = {"adam": "exp_avg", "nesterov": "momentum_buffer", "rmsprop": "square_avg"}[opt_name]
+    for p_ref, p_new in zip(ref.parameters(), second.parameters()):
+        assert torch.allclose(opt.state[p_ref][key], opt2.state[p_new][key], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("opt_name", ["adam", "nesterov"])
+def test_lr_schedule_is_honoured_by_the_lazy_replay(opt_name):
+    """An LR scheduler changes lr between steps; rows untouched across the change must have their
+    missed zero-gradient steps replayed with the lr that was in force at each of them (ADVICE r1:
+    flush under the old hyper-parameters before the new ones are bound).  Against dense autograd."""
+    from revisit_bpr.models.bpr import set_backend
+
+    U, I, d, B = 300, 200, 32, 16  # small batches: most rows are untouched at every step
+    reg = {"user": 0.0016, "item": 0.0001, "neg": 0.00375}
+    data = batches(U, I, B, 12, seed=8)
+    res = {}
+    for backend in ("hip", "torch"):
+        set_backend(backend)
+        try:
+            model = build(U, I, d, reg, False, seed=4)
+            opt = OPTS[opt_name](model.parameters())
+            sched = torch.optim.lr_scheduler.StepLR(opt, step_size=3, gamma=0.5)
+            _run_loop(model, opt, data, sched)
+            res[backend] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        finally:
+            set_backend("hip")
+    for k in res["torch"]:
+        assert torch.allclose(res["hip"][k], res["torch"][k], rtol=0, atol=2e-5), \
+            (k, (res["hip"][k] - res["torch"][k]).abs().max())
+
+
+def test_fused_tables_in_separate_param_groups_are_refused():
+    U, I, d = 50, 40, 16
+    model = build(U, I, d, None, False, seed=1)
+    lm = model.logits_model
+    opt = torch.optim.SGD([{"params": [lm._user_emb.weight], "lr": 0.1},
+                           {"params": [lm._item_emb.weight], "lr": 0.01}])
+    b = batches(U, I, 8, 1, seed=2)[0]
+    model.train()
+    model(b)["loss"].backward()
+    with pytest.raises(NotImplementedError):
+        opt.step()
+    model.engine().discard_grad()
+
+
+def test_eval_after_forward_without_step_discards_the_pending_gradients():
+    U, I, d = 50, 40, 16
+    model = build(U, I, d, None, False, seed=1)
+    b = batches(U, I, 8, 1, seed=2)[0]
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.train()
+    model(b)  # no backward, no step
+    model.eval()  # must not leave stale accumulators behind, nor skip the flush silently
+    gP, gQ, _ = model.engine().get_grad()
+    assert not gP.any() and not gQ.any()
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k])
+    model.train()
+    model(b)["loss"].backward()
+    with pytest.raises(RuntimeError):
+        model.eval()  # armed but never stepped
+    model.engine().discard_grad()
