@@ -107,31 +107,195 @@ struct VTable {
   float* Gb;  // [2, rows]
 };
 
+// ---------------------------------------------------------------------------------------------
+// Optimizer math of the batched stream: fp32 only, templated on the optimizer kind.
+// (The STRICT kernels' replay — bpr_opt.h — carries its bias-correction powers in double and one
+// code path for every kind; inlined into this kernel it took 200+ VGPRs, i.e. one or two waves
+// per SIMD for a kernel whose throughput is the number of triples in flight.)
+//
+// Bias corrections y_t = 1 - beta^t: seeded with -expm1f(t ln beta) (accurate to ~1e-7 relative
+// for every t, no cancellation) and advanced by y_{t+1} = y_t beta + (1 - beta), a contraction
+// whose rounding errors do not accumulate.  Exactly 1 from step t_sat on.
+// ---------------------------------------------------------------------------------------------
+constexpr int VADAM_SERIES = 3;
+struct VOpt {
+  float lr, mu, damp;
+  int32_t nesterov;
+  float b1, b2, eps, alpha;
+  float ln_b1, ln_b2;                    // natural logs (-1e30 for beta = 0)
+  float log2_mu, log2_alpha, log2_b1, log2_b2;
+  float sqrt_b2, mom_c;                  // mom_c = (nesterov ? mu : 1) mu / (1 - mu)
+  int32_t kmax;                          // Adam: replayed terms beyond are < 1e-8 of the first
+  int32_t t_sat;                         // Adam: 1 - beta^t == 1.0f for t >= t_sat (INT32_MAX: never)
+  // Adam, gaps >= 16 steps past t_sat, in closed form: the replayed movement is
+  //   lr (m / sqrt v) sum_s q^s / (1 + e r^-s),  q = b1 / r, r = sqrt b2, e = eps / sqrt v
+  //   = lr (m / sqrt v) sum_j (-e)^j G_j(k),     G_j(k) = z_j (1 - z_j^k) / (1 - z_j), z_j = b1 / r^(j+1)
+  // three terms; needs e r^-k <= 0.02 (truncation < 1e-5 of the movement), else the step loop
+  float zc[VADAM_SERIES], log2_z[VADAM_SERIES];  // z_j / (1 - z_j), log2 z_j   (zc[0] < 0: off)
+  float sv_min;                                  // sqrt v >= eps r^-kmax / 0.02
+};
+
+template <int KIND>
+__device__ __forceinline__ void vo_step_consts(const VOpt& o, int64_t t, float& step, float& ibc2) {
+  step = o.lr;
+  ibc2 = 1.f;  // 1 / sqrt(1 - b2^t)
+  if constexpr (KIND == OPT_ADAM) {
+    if (t < (int64_t)o.t_sat) {
+      const float tf = (float)t;
+      step = o.lr / (-expm1f(tf * o.ln_b1));
+      ibc2 = 1.0f / sqrtf(-expm1f(tf * o.ln_b2));
+    }
+  }
+}
+
+// the optimizer step proper (torch.optim single-tensor formulas, as bpr_opt.h: opt_update_at)
+template <int KIND>
+__device__ __forceinline__ void vo_update(float& w, float g, float& m, float& v, const VOpt& o,
+                                          bool first, float adam_step, float adam_ibc2) {
+  if constexpr (KIND == OPT_SGD) {
+    w = w - o.lr * g;
+  } else if constexpr (KIND == OPT_MOMENTUM) {
+    const float buf = first ? g : o.mu * m + (1.0f - o.damp) * g;
+    m = buf;
+    const float eff = o.nesterov ? g + o.mu * buf : buf;
+    w = w - o.lr * eff;
+  } else if constexpr (KIND == OPT_ADAM) {
+    const float wgt = 1.0f - o.b1;
+    m = (wgt < 0.5f) ? m + wgt * (g - m) : g - (g - m) * (1.0f - wgt);
+    v = o.b2 * v + (1.0f - o.b2) * g * g;
+    const float denom = sqrtf(v) * adam_ibc2 + o.eps;
+    w = w - adam_step * (m / denom);
+  } else {
+    v = o.alpha * v + (1.0f - o.alpha) * g * g;
+    w = w - o.lr * (g / (sqrtf(v) + o.eps));
+  }
+}
+
+// k zero-gradient steps s0+1 .. s0+k of a dense torch optimizer on the E elements a lane holds of
+// one row (STATE = false: only w is wanted — a view)
+template <int KIND, int E, bool STATE>
+__device__ __forceinline__ void vo_replay(float (&w)[E], float (&m)[E], float (&v)[E], int64_t s0,
+                                          int64_t k, const VOpt& o) {
+  if (k <= 0) return;
+  if constexpr (KIND == OPT_MOMENTUM) {
+    const float muk = __builtin_amdgcn_exp2f(fmaxf((float)k * o.log2_mu, -126.f));
+    const float c = o.lr * o.mom_c * (1.0f - muk);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      w[e] -= c * m[e];
+      if constexpr (STATE) m[e] *= muk;
+    }
+  } else if constexpr (KIND == OPT_RMSPROP) {
+    if constexpr (STATE) {
+      const float ak = __builtin_amdgcn_exp2f(fmaxf((float)k * o.log2_alpha, -126.f));
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] *= ak;
+    }
+  } else if constexpr (KIND == OPT_ADAM) {
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < E; ++e) any |= m[e] != 0.f;
+    const int kk = (int)(k < (int64_t)o.kmax ? k : (int64_t)o.kmax);
+    bool closed = any && o.zc[0] >= 0.f && s0 >= (int64_t)o.t_sat && k >= 16;
+    if (closed) {
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (m[e] != 0.f) closed = closed && (v[e] >= o.sv_min * o.sv_min);
+    }
+    if (closed) {
+      float Gs[VADAM_SERIES];
+#pragma unroll
+      for (int j = 0; j < VADAM_SERIES; ++j)
+        Gs[j] = o.zc[j] * (1.0f - __builtin_amdgcn_exp2f(fmaxf((float)kk * o.log2_z[j], -126.f)));
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (m[e] != 0.f) {
+          const float isv = __builtin_amdgcn_rsqf(v[e]);
+          const float ne = -o.eps * isv;
+          const float acc = fmaf(fmaf(Gs[2], ne, Gs[1]), ne, Gs[0]);
+          w[e] -= o.lr * (m[e] * isv) * acc;
+        }
+      }
+    } else if (any && kk > 0) {
+      float y1 = 1.f, y2 = 1.f;  // 1 - b1^s, 1 - b2^s of the step being replayed
+      const bool warm = s0 < (int64_t)o.t_sat;
+      if (warm) {
+        const float sf = (float)s0;
+        y1 = -expm1f(sf * o.ln_b1);
+        y2 = -expm1f(sf * o.ln_b2);
+      }
+      float ms[E], sv[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        ms[e] = m[e];
+        sv[e] = sqrtf(v[e]);
+      }
+      const float c1 = 1.0f - o.b1, c2 = 1.0f - o.b2;
+      for (int s = 0; s < kk; ++s) {
+        float step = o.lr, ibc2 = 1.f;
+        if (warm) {
+          y1 = fmaf(y1, o.b1, c1);
+          y2 = fmaf(y2, o.b2, c2);
+          step = o.lr * __builtin_amdgcn_rcpf(y1);
+          ibc2 = __builtin_amdgcn_rsqf(y2);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          ms[e] *= o.b1;
+          sv[e] *= o.sqrt_b2;
+          const float denom = fmaf(sv[e], ibc2, o.eps);
+          w[e] -= step * (ms[e] * __builtin_amdgcn_rcpf(denom));  // (m = 0: ms stays 0)
+        }
+      }
+    }
+    if constexpr (STATE) {
+      const float mk = __builtin_amdgcn_exp2f(fmaxf((float)k * o.log2_b1, -126.f));
+      const float vk = __builtin_amdgcn_exp2f(fmaxf((float)k * o.log2_b2, -126.f));
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        m[e] *= mk;
+        v[e] *= vk;
+      }
+    }
+  }
+}
+
 // one optimizer step `gs` with gradient g on a row held in registers, after the k = gs-1-a
 // zero-gradient steps it missed since `a`
-template <int E, bool STATEFUL>
+template <int KIND, int E>
 __device__ __forceinline__ void vs_apply(float (&w)[E], float (&m)[E], float (&v)[E],
                                          const float (&g)[E], int64_t a, int64_t gs,
-                                         const OptDev& o) {
-  if constexpr (STATEFUL) opt_replay_row<E, true>(w, m, v, a, gs - 1 - a, o);
-  float stp, bc2;
-  adam_step_consts(o, gs, stp, bc2);
+                                         const VOpt& o) {
+  vo_replay<KIND, E, true>(w, m, v, a, gs - 1 - a, o);
+  float stp, ibc2;
+  vo_step_consts<KIND>(o, gs, stp, ibc2);
 #pragma unroll
-  for (int e = 0; e < E; ++e) opt_update_at(w[e], g[e], m[e], v[e], o, gs == 1, stp, bc2);
+  for (int e = 0; e < E; ++e) vo_update<KIND>(w[e], g[e], m[e], v[e], o, gs == 1, stp, ibc2);
 }
-template <bool STATEFUL>
+// the same for the scalar riding on an item row (item_bias), held by the group's lane 0
+template <int KIND, bool STATE>
+__device__ __forceinline__ void vo_replay1(float& w, float& m, float& v, int64_t s0, int64_t k,
+                                           const VOpt& o) {
+  float w1[1] = {w}, m1[1] = {m}, v1[1] = {v};
+  vo_replay<KIND, 1, STATE>(w1, m1, v1, s0, k, o);
+  w = w1[0];
+  m = m1[0];
+  v = v1[0];
+}
+template <int KIND>
 __device__ __forceinline__ void vs_apply1(float& w, float& m, float& v, float g, int64_t a,
-                                          int64_t gs, const OptDev& o) {
-  if constexpr (STATEFUL) opt_replay(w, m, v, a, gs - 1 - a, o);
-  float stp, bc2;
-  adam_step_consts(o, gs, stp, bc2);
-  opt_update_at(w, g, m, v, o, gs == 1, stp, bc2);
+                                          int64_t gs, const VOpt& o) {
+  vo_replay1<KIND, true>(w, m, v, a, gs - 1 - a, o);
+  float stp, ibc2;
+  vo_step_consts<KIND>(o, gs, stp, ibc2);
+  vo_update<KIND>(w, g, m, v, o, gs == 1, stp, ibc2);
 }
 
 // The row as of virtual step t-1 (nothing is written).  wb: the riding scalar's view (0 if none).
-template <int G, int E, bool STATEFUL>
+template <int G, int E, int KIND>
 __device__ __forceinline__ void vs_view(float (&w)[E], float& wb, const VTable& T, uint32_t row,
-                                        int d, int gl, int64_t t, const OptDev& o) {
+                                        int d, int gl, int64_t t, const VOpt& o) {
+  constexpr bool STATEFUL = KIND != OPT_SGD;
   const VHdr h{ld_hdr(T.H + row)};
   const size_t off = (size_t)row * (size_t)d;
   load_row_sc1<G, E>(w, T.W + off, d, gl);
@@ -157,25 +321,26 @@ __device__ __forceinline__ void vs_view(float (&w)[E], float& wb, const VTable& 
     const size_t goff = ((size_t)h.slot() * (size_t)T.rows + row) * (size_t)d;
     float g[E];
     load_row_sc1<G, E>(g, T.Gacc + goff, d, gl);
-    vs_apply<E, STATEFUL>(w, m, v, g, a, gs, o);
+    vs_apply<KIND, E>(w, m, v, g, a, gs, o);
     if (T.b != nullptr) {
       const float gb = ld_sc1(T.Gb + (size_t)h.slot() * (size_t)T.rows + row);
-      vs_apply1<STATEFUL>(wb, bm, bv, gb, a, gs, o);
+      vs_apply1<KIND>(wb, bm, bv, gb, a, gs, o);
     }
     a = gs;
   }
   if constexpr (STATEFUL) {
     const int64_t k = (t - 1) - a;
-    opt_replay_row<E, false>(w, m, v, a, k, o);
-    if (T.b != nullptr) opt_replay(wb, bm, bv, a, k, o);
+    vo_replay<KIND, E, false>(w, m, v, a, k, o);
+    if (T.b != nullptr) vo_replay1<KIND, false>(wb, bm, bv, a, k, o);
   }
 }
 
 // Add this triple's gradient g (and gb for the riding scalar) to row's virtual step t.
-template <int G, int E, bool STATEFUL>
+template <int G, int E, int KIND>
 __device__ __forceinline__ void vs_contribute(const VTable& T, uint32_t row, int d, int gl,
                                               int lane, int64_t t, const float (&g)[E], float gb,
-                                              bool act, const OptDev& o) {
+                                              bool act, const VOpt& o) {
+  constexpr bool STATEFUL = KIND != OPT_SGD;
   const size_t off = (size_t)row * (size_t)d;
   bool done = !act;
   while (!__all(done)) {
@@ -222,7 +387,7 @@ __device__ __forceinline__ void vs_contribute(const VTable& T, uint32_t row, int
               if (T.M != nullptr) load_row_sc1<G, E>(m, T.M + off, d, gl);
               if (T.V != nullptr) load_row_sc1<G, E>(v, T.V + off, d, gl);
             }
-            vs_apply<E, STATEFUL>(w, m, v, go, a, gs, o);
+            vs_apply<KIND, E>(w, m, v, go, a, gs, o);
             store_row_sc1<G, E>(T.W + off, w, d, gl);
             if constexpr (STATEFUL) {
               if (T.M != nullptr) store_row_sc1<G, E>(T.M + off, m, d, gl);
@@ -235,7 +400,7 @@ __device__ __forceinline__ void vs_contribute(const VTable& T, uint32_t row, int
                 if (T.vb != nullptr) bv = ld_sc1(T.vb + row);
               }
               const float gbo = xchg_zero(T.Gb + (size_t)h.slot() * (size_t)T.rows + row);
-              vs_apply1<STATEFUL>(wb, bm, bv, gbo, a, gs, o);
+              vs_apply1<KIND>(wb, bm, bv, gbo, a, gs, o);
               st_sc1(T.b + row, wb);
               if constexpr (STATEFUL) {
                 if (T.mb != nullptr) st_sc1(T.mb + row, bm);
@@ -309,12 +474,17 @@ struct VStreamArgs {
   int32_t pad_user, pad_item;
   int32_t bm_words, gpw_active;
   float au, ai, an, inv_log1mp;
-  OptDev o;
+  VOpt o;
 };
 
-template <int G, int E, int SAMPLER, int SEEN, bool STATEFUL>
+// rows of the triple as of step t-1 are staged in LDS ([3][G*E] floats per group: p_u, q_i, q_j),
+// so that view() and contribute() each exist ONCE in the instruction stream (a loop over the
+// three rows) instead of three times with all three rows live in registers around them: the
+// optimizer replay inlined six times cost 256 VGPRs (one wave per SIMD); the kernel is bound by
+// the latency of its dependent memory round trips, i.e. by how many triples are in flight.
+template <int G, int E, int SAMPLER, int SEEN, int KIND>
 __global__ __launch_bounds__(256) void k_vstream(const VStreamArgs a) {
-  constexpr int GPW = 64 / G;
+  constexpr int DP = G * E;
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
   const int gw = lane / G;
@@ -324,9 +494,23 @@ __global__ __launch_bounds__(256) void k_vstream(const VStreamArgs a) {
   const int gpw = a.gpw_active;  // 1: only the first group of each wave works (sequential limit)
   const bool stats = a.partials != nullptr;
   float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
-  uint32_t* lds = bpr_vsmem + (threadIdx.x / G) * a.bm_words;
-  float sg[E];
-  if constexpr (SAMPLER == NEG_ADAPTIVE) load_row<G, E>(sg, a.sigma, d, gl);
+  uint32_t* lds = bpr_vsmem + (threadIdx.x / G) * (a.bm_words + 3 * DP);
+  float* rows = reinterpret_cast<float*>(lds + a.bm_words);  // [3][DP]
+
+  auto table = [&](int r) {  // uniform selects: the user table for r == 0, else the item table
+    VTable T;
+    T.W = r == 0 ? a.P.W : a.Q.W;
+    T.M = r == 0 ? a.P.M : a.Q.M;
+    T.V = r == 0 ? a.P.V : a.Q.V;
+    T.Gacc = r == 0 ? a.P.Gacc : a.Q.Gacc;
+    T.H = r == 0 ? a.P.H : a.Q.H;
+    T.rows = r == 0 ? a.P.rows : a.Q.rows;
+    T.b = r == 0 ? nullptr : a.Q.b;
+    T.mb = r == 0 ? nullptr : a.Q.mb;
+    T.vb = r == 0 ? nullptr : a.Q.vb;
+    T.Gb = r == 0 ? nullptr : a.Q.Gb;
+    return T;
+  };
 
   for (int base = wave * gpw; base < a.n; base += n_waves * gpw) {
     const int k = base + gw;
@@ -335,79 +519,88 @@ __global__ __launch_bounds__(256) void k_vstream(const VStreamArgs a) {
     const uint32_t u = (uint32_t)a.users[kk];
     const uint32_t i = (uint32_t)a.pos[kk];
     const int64_t t = a.t_base + (int64_t)(kk / a.B);
-    float p[E], qi[E], qj[E];
-    float bu_unused, bi, bj;
-    vs_view<G, E, STATEFUL>(p, bu_unused, a.P, u, d, gl, t, a.o);
-    vs_view<G, E, STATEFUL>(qi, bi, a.Q, i, d, gl, t, a.o);
-    int32_t j;
-    if constexpr (SAMPLER == NEG_GIVEN) {
-      j = a.neg[kk];
-    } else {
-      const int64_t lo = a.indptr[u], hi = a.indptr[u + 1];
-      using Seen = typename std::conditional<
-          SEEN == SEEN_BITMAP, SeenBitmap,
-          typename std::conditional<SEEN == SEEN_LIST, SeenList, SeenCsr>::type>::type;
-      Seen seen;
-      if constexpr (SEEN == SEEN_BITMAP) {
-        seen_bitmap_build<G>(lds, a.bm_words, a.indices, lo, hi, gl);
-        seen = SeenBitmap{lds};
-      } else if constexpr (SEEN == SEEN_LIST) {
-        const int32_t ln = seen_list_build<G>(lds, a.bm_words, a.indices, lo, hi, gl);
-        seen = SeenList{reinterpret_cast<const int32_t*>(lds), ln, a.indices, lo, hi};
-      } else {
-        seen = SeenCsr{a.indices, lo, hi};
-      }
-      const uint64_t ctr = a.offset + (uint64_t)kk;
-      if constexpr (SAMPLER == NEG_UNIFORM) {
-        j = sample_uniform<G>(seen, a.I, a.seed, ctr, lane);
-      } else {
-        const AdaptiveRandoms rnd =
-            adaptive_randoms(a.seed, ctr, a.inv_log1mp, (int64_t)(a.I - 1) - (hi - lo));
-        j = sample_adaptive<G, E>(p, d, sg, a.order, a.I, seen, hi - lo, rnd, lane).item;
-      }
-      if (a.neg != nullptr && act && gl == 0) a.neg[k] = j;
-    }
-    vs_view<G, E, STATEFUL>(qj, bj, a.Q, (uint32_t)j, d, gl, t, a.o);
-
-    // x_uij = <p_u, q_i - q_j> + b_i - b_j   (model.py:48-64, 131-145)
-    float xl = 0.f;
+    int32_t j = 0;
+    float bi = 0.f, bj = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+      if (r == 2) {  // the negative: drawn from the user's row as of t-1, like the reference
+        if constexpr (SAMPLER == NEG_GIVEN) {
+          j = a.neg[kk];
+        } else {
+          const int64_t lo = a.indptr[u], hi = a.indptr[u + 1];
+          using Seen = typename std::conditional<
+              SEEN == SEEN_BITMAP, SeenBitmap,
+              typename std::conditional<SEEN == SEEN_LIST, SeenList, SeenCsr>::type>::type;
+          Seen seen;
+          if constexpr (SEEN == SEEN_BITMAP) {
+            seen_bitmap_build<G>(lds, a.bm_words, a.indices, lo, hi, gl);
+            seen = SeenBitmap{lds};
+          } else if constexpr (SEEN == SEEN_LIST) {
+            const int32_t ln = seen_list_build<G>(lds, a.bm_words, a.indices, lo, hi, gl);
+            seen = SeenList{reinterpret_cast<const int32_t*>(lds), ln, a.indices, lo, hi};
+          } else {
+            seen = SeenCsr{a.indices, lo, hi};
+          }
+          const uint64_t ctr = a.offset + (uint64_t)kk;
+          if constexpr (SAMPLER == NEG_UNIFORM) {
+            j = sample_uniform<G>(seen, a.I, a.seed, ctr, lane);
+          } else {
+            float p[E], sg[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) xl = fmaf(p[e], qi[e] - qj[e], xl);
+            for (int e = 0; e < E; ++e) p[e] = rows[e * G + gl];
+            load_row<G, E>(sg, a.sigma, d, gl);
+            const AdaptiveRandoms rnd =
+                adaptive_randoms(a.seed, ctr, a.inv_log1mp, (int64_t)(a.I - 1) - (hi - lo));
+            j = sample_adaptive<G, E>(p, d, sg, a.order, a.I, seen, hi - lo, rnd, lane).item;
+          }
+          if (a.neg != nullptr && act && gl == 0) a.neg[k] = j;
+        }
+      }
+      const uint32_t row = r == 0 ? u : (r == 1 ? i : (uint32_t)j);
+      float w[E], wb;
+      vs_view<G, E, KIND>(w, wb, table(r), row, d, gl, t, a.o);
+#pragma unroll
+      for (int e = 0; e < E; ++e) rows[r * DP + e * G + gl] = w[e];
+      bi = r == 1 ? wb : bi;
+      bj = r == 2 ? wb : bj;
+    }
+    // x_uij = <p_u, q_i - q_j> + b_i - b_j   (model.py:48-64, 131-145)
+    float xl = 0.f, reg = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float pe = rows[e * G + gl], qie = rows[DP + e * G + gl], qje = rows[2 * DP + e * G + gl];
+      xl = fmaf(pe, qie - qje, xl);
+      reg += a.ai * qie * qie + a.an * qje * qje + a.au * pe * pe;
+    }
     const float x = group_sum<G>(xl, lane) + (bi - bj);
     if (stats && act) {
-      s_reg += 0.5f * (a.ai * dot<E>(qi, qi) + a.an * dot<E>(qj, qj) + a.au * dot<E>(p, p));
+      s_reg += 0.5f * reg;
       if (gl == 0) {
         s_loss += neg_logsigmoid(x);
         s_abs += fabsf(x);
         s_cnt += 1.f;
       }
     }
-    // per-triple gradients, w = sigma(-x); summed per row and virtual step
-    const float w = 1.0f / (1.0f + expf(x));
-    float gu[E], gi[E], gj[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      gu[e] = -w * (qi[e] - qj[e]) + a.au * p[e];
-      gi[e] = -w * p[e] + a.ai * qi[e];
-      gj[e] = w * p[e] + a.an * qj[e];
-    }
+    // per-triple gradients, w = sigma(-x): row r gets c_p p + c_i q_i + c_j q_j.
     // padding_idx drops the gradient of the pad EMBEDDING row (torch's embedding backward); the
-    // pad item's bias is an ordinary parameter and keeps its gradient
-    const bool pad_i = (int32_t)i == a.pad_item, pad_j = j == a.pad_item;
-    if (pad_i | pad_j) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        gi[e] = pad_i ? 0.f : gi[e];
-        gj[e] = pad_j ? 0.f : gj[e];
-      }
-    }
+    // pad item's bias is an ordinary parameter and keeps its gradient.
+    const float w = 1.0f / (1.0f + expf(x));
     const bool has_bias = a.Q.b != nullptr;
-    vs_contribute<G, E, STATEFUL>(a.P, u, d, gl, lane, t, gu, 0.f,
-                                  act && (int32_t)u != a.pad_user, a.o);
-    vs_contribute<G, E, STATEFUL>(a.Q, i, d, gl, lane, t, gi, -w, act && (!pad_i || has_bias),
-                                  a.o);
-    vs_contribute<G, E, STATEFUL>(a.Q, (uint32_t)j, d, gl, lane, t, gj, w,
-                                  act && (!pad_j || has_bias), a.o);
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+      const uint32_t row = r == 0 ? u : (r == 1 ? i : (uint32_t)j);
+      const bool pad = (int32_t)row == (r == 0 ? a.pad_user : a.pad_item);
+      const float cp = pad ? 0.f : (r == 0 ? a.au : (r == 1 ? -w : w));
+      const float ci = pad ? 0.f : (r == 0 ? -w : (r == 1 ? a.ai : 0.f));
+      const float cj = pad ? 0.f : (r == 0 ? w : (r == 1 ? 0.f : a.an));
+      float g[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        g[e] = cp * rows[e * G + gl] + ci * rows[DP + e * G + gl] + cj * rows[2 * DP + e * G + gl];
+      const float gb = r == 0 ? 0.f : (r == 1 ? -w : w);
+      vs_contribute<G, E, KIND>(table(r), row, d, gl, lane, t, g, gb,
+                                    act && (!pad || (r != 0 && has_bias)), a.o);
+    }
   }
   if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);
 }
@@ -420,10 +613,11 @@ struct VFlushArgs {
   VTable T;
   int32_t d, pad;
   int64_t now;
-  OptDev o;
+  VOpt o;
 };
-template <int G, int E, bool STATEFUL>
+template <int G, int E, int KIND>
 __global__ __launch_bounds__(256) void k_vflush(const VFlushArgs a) {
+  constexpr bool STATEFUL = KIND != OPT_SGD;
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
   const int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) / G;
@@ -467,20 +661,20 @@ __global__ __launch_bounds__(256) void k_vflush(const VFlushArgs a) {
           g1[f] = 0.f;
         }
       }
-      vs_apply<E, STATEFUL>(w, m, v, g, a0, gs, a.o);  // (the pad row's g is all zero)
+      vs_apply<KIND, E>(w, m, v, g, a0, gs, a.o);  // (the pad row's g is all zero)
       if (T.b != nullptr) {
         const float gb = T.Gb[row] + T.Gb[T.rows + row];
         if (gl == 0) {
           T.Gb[row] = 0.f;
           T.Gb[T.rows + row] = 0.f;
         }
-        vs_apply1<STATEFUL>(wb, bm, bv, gb, a0, gs, a.o);
+        vs_apply1<KIND>(wb, bm, bv, gb, a0, gs, a.o);
       }
       cur = gs;
     }
     if constexpr (STATEFUL) {
-      opt_replay_row<E, true>(w, m, v, cur, a.now - cur, a.o);
-      if (T.b != nullptr) opt_replay(wb, bm, bv, cur, a.now - cur, a.o);
+      vo_replay<KIND, E, true>(w, m, v, cur, a.now - cur, a.o);
+      if (T.b != nullptr) vo_replay1<KIND, true>(wb, bm, bv, cur, a.now - cur, a.o);
     }
     store_row<G, E>(T.W + off, w, d, gl);
     if constexpr (STATEFUL) {

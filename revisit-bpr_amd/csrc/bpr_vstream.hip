@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <limits.h>
+
 #include <algorithm>
 #include <string>
 
@@ -25,6 +27,51 @@ static VTable table_Q(const bpr_ctx* c) {
     t.b = c->bias; t.mb = c->mb; t.vb = c->vb; t.Gb = c->vGb;
   }
   return t;
+}
+
+// fp32 view of the ctx's optimizer for the batched-stream kernels (bpr_vstream.h: VOpt)
+static VOpt vopt(const bpr_ctx* c) {
+  VOpt o;
+  memset(&o, 0, sizeof(o));
+  const bpr_opt_params& p = c->opt;
+  o.lr = p.lr; o.mu = p.momentum; o.damp = p.dampening; o.nesterov = p.nesterov;
+  o.b1 = p.beta1; o.b2 = p.beta2; o.eps = p.eps; o.alpha = p.alpha;
+  auto ln = [](double x) { return x > 0.0 ? log(x) : -1.0e30; };
+  auto l2 = [](double x) { return x > 0.0 ? log2(x) : -1.0e30; };
+  o.ln_b1 = (float)ln(p.beta1); o.ln_b2 = (float)ln(p.beta2);
+  o.log2_mu = (float)l2(p.momentum); o.log2_alpha = (float)l2(p.alpha);
+  o.log2_b1 = (float)l2(p.beta1); o.log2_b2 = (float)l2(p.beta2);
+  o.sqrt_b2 = (float)sqrt((double)p.beta2);
+  o.mom_c = (float)((p.nesterov ? (double)p.momentum : 1.0) * (double)p.momentum /
+                    (1.0 - (double)p.momentum));
+  o.kmax = 0;
+  o.t_sat = INT32_MAX;
+  o.zc[0] = -1.f;
+  if (c->opt_kind == BPR_OPT_ADAM) {
+    const double b1 = p.beta1, b2 = p.beta2;
+    // 1 - beta^t rounds to 1.0f once beta^t < 2^-25
+    if (b2 > 0.0 && b2 < 1.0 && b1 < 1.0) {
+      const double lim = log(ldexp(1.0, -25));
+      const double t1 = b1 > 0.0 ? ceil(lim / log(b1)) : 1.0, t2 = ceil(lim / log(b2));
+      const double ts = t1 > t2 ? t1 : t2;
+      if (ts < 2.0e9) o.t_sat = (int32_t)ts;
+    }
+    if (b1 > 0.0) {
+      const double ratio = b1 / sqrt(b2);
+      o.kmax = ratio < 1.0 ? (int)ceil(log(1e-8) / log(ratio)) : 1 << 20;
+      const bool no_closed = getenv("BPR_NO_ADAM_CLOSED") != nullptr;  // tests compare both routes
+      const double zmax = b1 / pow(b2, 0.5 * VADAM_SERIES);
+      if (!no_closed && zmax < 0.999 && o.kmax >= 16 && o.kmax < (1 << 20)) {
+        for (int j = 0; j < VADAM_SERIES; ++j) {
+          const double lz = log(b1) - 0.5 * (j + 1) * log(b2), z = exp(lz);
+          o.zc[j] = (float)(z / (1.0 - z));
+          o.log2_z[j] = (float)(lz / log(2.0));
+        }
+        o.sv_min = (float)((double)p.eps * pow(b2, -0.5 * o.kmax) / 0.02);
+      }
+    }
+  }
+  return o;
 }
 
 void vs_free(bpr_ctx* c) {
@@ -70,7 +117,7 @@ int vs_flush(bpr_ctx* c, bool users, bool items) {
   memset(&a, 0, sizeof(a));
   a.d = c->d;
   a.now = c->step;
-  a.o = opt_dev(c, c->step);
+  a.o = vopt(c);
   return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
     constexpr int G = T::G, E = T::E;
@@ -79,10 +126,19 @@ int vs_flush(bpr_ctx* c, bool users, bool items) {
       a.pad = pad;
       const int64_t per_block = 256 / G;
       const unsigned grid = (unsigned)std::min<int64_t>((t.rows + per_block - 1) / per_block, 8192);
-      if (stateful)
-        hipLaunchKernelGGL((k_vflush<G, E, true>), dim3(grid), dim3(256), 0, c->stream, a);
-      else
-        hipLaunchKernelGGL((k_vflush<G, E, false>), dim3(grid), dim3(256), 0, c->stream, a);
+      switch (c->opt_kind) {
+        case BPR_OPT_SGD:
+          hipLaunchKernelGGL((k_vflush<G, E, OPT_SGD>), dim3(grid), dim3(256), 0, c->stream, a);
+          break;
+        case BPR_OPT_MOMENTUM:
+          hipLaunchKernelGGL((k_vflush<G, E, OPT_MOMENTUM>), dim3(grid), dim3(256), 0, c->stream, a);
+          break;
+        case BPR_OPT_ADAM:
+          hipLaunchKernelGGL((k_vflush<G, E, OPT_ADAM>), dim3(grid), dim3(256), 0, c->stream, a);
+          break;
+        default:
+          hipLaunchKernelGGL((k_vflush<G, E, OPT_RMSPROP>), dim3(grid), dim3(256), 0, c->stream, a);
+      }
     };
     if (users) go(table_P(c), c->pad_user);
     if (items) go(table_Q(c), c->pad_item);
@@ -115,27 +171,15 @@ static int launch_vstream(bpr_ctx* c, VStreamArgs a, int sampler, int64_t cap_gr
       block = (unsigned)(((cap_groups * G + 63) / 64) * 64);
       if (cap_groups < GPW) a.gpw_active = (int)cap_groups;  // one wave, fewer groups at work
     }
-    // "seen?" structure in LDS, rebuilt per triple (bpr_device.h): the I-bit bitmap while a
-    // block's bitmaps fit 64 KiB, else the user's sorted list (LIST_CAP entries, longer lists
-    // fall back to the CSR in HBM).  BPR_SEEN=csr|bitmap|list forces one (tests).
-    const int words = (int)(((c->I + 31) / 32 + 3) / 4 * 4);
+    // "seen?" per triple (the stream is not grouped by user): the user's sorted seen list staged
+    // in LDS (LIST_CAP entries, binary search in LDS; longer lists search the CSR in HBM).
+    // BPR_SEEN=csr stages nothing (every lookup searches the CSR: tests).
     const char* force_env = getenv("BPR_SEEN");
     const std::string force = force_env ? force_env : "";
     constexpr int LIST_CAP = 512;
-    int seen = SEEN_CSR, lds_words = 0;
-    if (sampler != NEG_GIVEN && force != "csr") {
-      const bool bm_fits = (size_t)(block / G) * words * sizeof(uint32_t) <= 64 * 1024;
-      if (force == "list" || (force != "bitmap" && !bm_fits)) {
-        seen = SEEN_LIST;
-        lds_words = LIST_CAP;
-      } else if (bm_fits) {
-        seen = SEEN_BITMAP;
-        lds_words = words;
-      } else {
-        return fail(BPR_ERR_UNSUPPORTED, "BPR_SEEN=bitmap: item table too large for LDS bitmaps");
-      }
-    }
-    const size_t shmem = (size_t)(block / G) * (size_t)lds_words * sizeof(uint32_t);
+    const int lds_words = (sampler != NEG_GIVEN && force != "csr") ? LIST_CAP : 0;
+    // per group: the seen list + the triple's three rows as of t-1 (bpr_vstream.h)
+    const size_t shmem = (size_t)(block / G) * (size_t)(lds_words + 3 * G * E) * sizeof(uint32_t);
     const int64_t per_block = (int64_t)(block / 64) * a.gpw_active;
     int64_t want = a.n;
     if (cap_groups > 0 && want > cap_groups) want = cap_groups;
@@ -144,29 +188,27 @@ static int launch_vstream(bpr_ctx* c, VStreamArgs a, int sampler, int64_t cap_gr
     if (nblk > resident) nblk = resident;
     const unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
     a.bm_words = lds_words;
-    const bool stateful = c->opt_kind != BPR_OPT_SGD;
     {
       Timer tm(c, true);
       (void)tm;
-      auto go = [&](auto smp, auto sn) {
-        constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
-        if (stateful)
-          hipLaunchKernelGGL((k_vstream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
-                             c->stream, a);
-        else
-          hipLaunchKernelGGL((k_vstream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
-                             c->stream, a);
+      auto go = [&](auto smp, auto knd) {
+        constexpr int SMP = decltype(smp)::value, KND = decltype(knd)::value;
+        constexpr int SN = SMP == NEG_GIVEN ? SEEN_CSR : SEEN_LIST;
+        hipLaunchKernelGGL((k_vstream<G, E, SMP, SN, KND>), dim3(grid), dim3(block), shmem,
+                           c->stream, a);
       };
       using std::integral_constant;
-      auto with_seen = [&](auto smp) {
-        if (seen == SEEN_BITMAP) go(smp, integral_constant<int, SEEN_BITMAP>{});
-        else if (seen == SEEN_LIST) go(smp, integral_constant<int, SEEN_LIST>{});
-        else go(smp, integral_constant<int, SEEN_CSR>{});
+      auto with_kind = [&](auto smp) {
+        switch (c->opt_kind) {
+          case BPR_OPT_SGD: go(smp, integral_constant<int, OPT_SGD>{}); break;
+          case BPR_OPT_MOMENTUM: go(smp, integral_constant<int, OPT_MOMENTUM>{}); break;
+          case BPR_OPT_ADAM: go(smp, integral_constant<int, OPT_ADAM>{}); break;
+          default: go(smp, integral_constant<int, OPT_RMSPROP>{});
+        }
       };
-      if (sampler == NEG_GIVEN)
-        go(integral_constant<int, NEG_GIVEN>{}, integral_constant<int, SEEN_CSR>{});
-      else if (sampler == NEG_UNIFORM) with_seen(integral_constant<int, NEG_UNIFORM>{});
-      else with_seen(integral_constant<int, NEG_ADAPTIVE>{});
+      if (sampler == NEG_GIVEN) with_kind(integral_constant<int, NEG_GIVEN>{});
+      else if (sampler == NEG_UNIFORM) with_kind(integral_constant<int, NEG_UNIFORM>{});
+      else with_kind(integral_constant<int, NEG_ADAPTIVE>{});
     }
     if (out_scalars != nullptr)
       hipLaunchKernelGGL(k_vsum_partials, dim3(1), dim3(256), 0, c->stream, a.partials, (int)grid,
@@ -213,7 +255,7 @@ int bpr_train_stream_batched(bpr_ctx* c, const int32_t* users, const int32_t* po
   a.pad_user = c->pad_user; a.pad_item = c->pad_item;
   a.au = c->au; a.ai = c->ai; a.an = c->an;
   a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
-  a.o = opt_dev(c, c->step + 1);
+  a.o = vopt(c);
   if (int rc = launch_vstream(c, a, sampler, max_inflight, out_scalars)) return rc;
   c->step += steps;
   return BPR_OK;
