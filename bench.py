@@ -115,6 +115,104 @@ def cpu_baseline(data, d, reg, lr, p, seconds, seed, sampler="adaptive"):
     }
 
 
+def cpu_reference_op_sequence(data, d, reg, lr, p, sampler, seed, warm=20, reps=3, steps=8):
+    """(b) of SURVEY §8d: the REFERENCE's op sequence restated on CPU tensors and timed with every
+    host core — per batch of 256: `_sampling_weights` ([B, I] weights, seen + item 0 zeroed, row
+    normalised: revisit_bpr/modules/neg_samplers.py:135-141) -> `torch.multinomial` (:31-37) or the
+    adaptive path ([B, I] gather of the snapshot, scatter -1e13, full argsort: :74-124) -> dense
+    autograd forward / backward (models/bpr/model.py:48-68, set_backend("torch") here) -> dense
+    `torch.optim.SGD.step` over both tables (example.py:176-180).  >= 20 warm steps, median of 3
+    timed blocks."""
+    from revisit_bpr.models import BPR
+    from revisit_bpr.models.bpr import MF, set_backend
+
+    host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    U, I, B = data.num_users, data.num_items, 256
+    torch.manual_seed(seed)
+    model = BPR(fuse_forward=True, reg_alphas=dict(zip(("user", "item", "neg"), reg)),
+                logits_model=MF(torch.nn.Embedding(U, d, padding_idx=0),
+                                torch.nn.Embedding(I, d, padding_idx=0)))
+    opt = torch.optim.SGD(model.parameters(), lr=lr)
+    gen = torch.Generator().manual_seed(seed)
+    lens = np.diff(data.indptr)
+    S = int(min(lens.max(), 4096))
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(data.nnz)
+    users_t = torch.from_numpy(data.users.astype(np.int64))
+    items_t = torch.from_numpy(data.items.astype(np.int64))
+    ones = torch.ones(I)
+    feats = model.logits_model.get_features()
+    snap_T = feats["item"].detach().t().clone()                  # update_stats (:126-132)
+    snap_std = feats["item"][1:].detach().std(dim=0, keepdim=True)
+
+    def seen_of(u):  # the padded [B, S] seen matrix the reference's collator hands over
+        out = np.zeros((len(u), S), np.int64)
+        for r, uu in enumerate(u):
+            row = data.indices[data.indptr[uu]:data.indptr[uu + 1]][:S]
+            out[r, :len(row)] = row
+        return torch.from_numpy(out)
+
+    def one_step(k):
+        idx = perm[k * B:(k + 1) * B]
+        u = users_t[idx]
+        seen = seen_of(data.users[idx])
+        w = ones.expand(len(idx), -1).scatter(-1, seen, 0.0)      # _sampling_weights
+        w[:, 0] = 0.0
+        w = w * w.sum(-1, keepdim=True).reciprocal()
+        if sampler == "adaptive":
+            n_unseen = w.gt(0).sum(-1, keepdim=True)
+            pu = feats["user"].detach()[u]
+            factor = torch.multinomial(pu.abs() * snap_std, 1, generator=gen)
+            rank = torch.empty_like(factor).geometric_(p, generator=gen).clamp_(max=n_unseen)
+            rank = torch.where(pu.gather(-1, factor).gt(0), rank - 1, n_unseen - rank)
+            seen0 = torch.hstack((seen, torch.zeros_like(rank)))
+            neg = torch.argsort(-snap_T[factor.squeeze(-1)].scatter(-1, seen0, -1e13), dim=-1) \
+                .gather(-1, rank)
+        else:
+            neg = torch.multinomial(w, 1, generator=gen)
+        out = model({"user": u, "item": items_t[idx].unsqueeze(-1), "neg": neg})
+        out["loss"].backward()
+        opt.step()
+        opt.zero_grad()
+
+    set_backend("torch")
+    try:
+        model.train()
+        # every host core is offered; torch's intra-op pool is slower with hundreds of threads on
+        # these op sizes than with a few dozen, so the thread count is the fastest of a short probe
+        probe = {}
+        for th in sorted({min(host, 8), min(host, 32), min(host, 64), host}):
+            torch.set_num_threads(th)
+            one_step(0)
+            t0 = time.perf_counter()
+            for k in range(2):
+                one_step(1 + k)
+            probe[th] = (time.perf_counter() - t0) / 2
+        threads = min(probe, key=probe.get)
+        torch.set_num_threads(threads)
+        for k in range(warm):
+            one_step(k)
+        times = []
+        for r in range(reps):
+            t0 = time.perf_counter()
+            for k in range(steps):
+                one_step(warm + r * steps + k)
+            times.append((time.perf_counter() - t0) / steps)
+    finally:
+        set_backend("hip")
+    ms = float(np.median(times)) * 1e3
+    return {
+        "value": B / (ms * 1e-3), "unit": "triples/s", "cores": threads,
+        "kind": "reference-op-sequence",
+        "sample": f"the reference's op sequence restated on CPU tensors (torch {torch.__version__}, "
+                  f"{threads} threads = the fastest of {sorted(probe)} on this {host}-core host): "
+                  f"[256, I] sampling weights + "
+                  f"{'adaptive argsort' if sampler == 'adaptive' else 'multinomial'}, dense autograd, "
+                  f"dense torch.optim.SGD; {warm} warm steps, median of {reps} x {steps} timed steps "
+                  f"({ms:.1f} ms per step of 256 triples) of the same workload",
+    }
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,6 +310,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    q_before = Q.double().sum().item(), Q.abs().double().sum().item()
     step(0)  # plans the first epoch
     for k in range(1, args.warmup + 1):
         step(k)
@@ -233,6 +332,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     sc = scalars.cpu().numpy()
+    if batched:
+        e.flush_lazy()
+    q_after = Q.double().sum().item(), Q.abs().double().sum().item()
+    # a kernel that did nothing cannot produce a number: every triple of the timed region was
+    # counted by the kernel itself, the loss it accumulated is a real -log sigma, the tables moved
+    assert int(round(float(sc[3]))) == args.steps * chunk, (sc[3], args.steps * chunk)
+    assert 0.0 < float(sc[0] / sc[3]) < 5.0 and q_after != q_before and torch.isfinite(Q).all()
 
     opt_desc = {"sgd": f"SGD lr={args.lr}", "momentum": f"SGD(momentum 0.9) lr={args.lr}",
                 "adam": f"Adam lr={args.lr} betas={tuple(args.betas)}",
@@ -279,6 +385,8 @@ def main():
                 "parallelism": f"user-sharded x{world}, item table replicated, async delta "
                                f"all-reduce every {args.sync_every} step(s)" if world > 1 else "single GPU",
                 "mean_bpr_loss": float(sc[0] / max(sc[3], 1.0)),
+                "triples_counted_by_kernel": int(round(float(sc[3]))),
+                "item_table_abs_sum_before_after": [q_before[1], q_after[1]],
             },
             "roofline": {
                 "bound": "hbm",
@@ -296,8 +404,13 @@ def main():
             },
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(data, d, reg, args.lr, args.adaptive_p,
-                                               args.cpu_seconds, args.seed, args.sampler)
+            smp = "uniform" if args.sampler == "given" else args.sampler
+            out["cpu_baseline"] = cpu_reference_op_sequence(data, d, reg, args.lr, args.adaptive_p,
+                                                            smp, args.seed)
+            # the 1-core C port of the same path (the oracle) beside it: sparse apply, no [B, I]
+            # weights — kinder to the CPU than the reference's own op sequence
+            out["cpu_baseline_c_port"] = cpu_baseline(data, d, reg, args.lr, args.adaptive_p,
+                                                      args.cpu_seconds, args.seed, smp)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -175,6 +175,7 @@ struct StreamArgs {
   int32_t n, I, d;
   int32_t pad_user, pad_item;
   int32_t run_len, grouped, bm_words, dbg;
+  int32_t gpw_active;  // groups of a wave that work (G = 32: 2; 1 = one triple at a time, tests)
   float au, ai, an, lr, inv_log1mp;
   // hot item rows: updates of row i with hot_slot[i] = s >= 0 go to the replica delta row
   // hot_delta[wave & hot_rmask][s]; its value is Q[i] + the sum of its replicas (NULL = off)
@@ -230,9 +231,10 @@ void k_stream(const StreamArgs a) {
     load_row<G, E>(sg, a.sigma, d, gl);
   }
 
-  for (int rbase = wave * GPW; rbase < n_runs; rbase += n_waves * GPW) {
+  const int gpw = GPW == 1 ? 1 : a.gpw_active;
+  for (int rbase = wave * gpw; rbase < n_runs; rbase += n_waves * gpw) {
     const int run = rbase + gw;
-    const bool run_act = run < n_runs;
+    const bool run_act = gw < gpw && run < n_runs;
     const int t0 = run_act ? run * L : 0;
     const int t1 = run_act ? min(t0 + L, a.n) : 0;
     // ---- run prologue: ONE coalesced load brings the ids of the whole run (lane k holds triple

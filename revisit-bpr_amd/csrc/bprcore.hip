@@ -224,7 +224,11 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     constexpr int G = T::G, E = T::E;
     const int64_t n_runs = (a.n + a.run_len - 1) / a.run_len;
     unsigned block = 256;
-    if (cap_groups > 0 && cap_groups * G < 256) block = (unsigned)(((cap_groups * G + 63) / 64) * 64);
+    a.gpw_active = 64 / G;
+    if (cap_groups > 0 && cap_groups * G < 256) {
+      block = (unsigned)(((cap_groups * G + 63) / 64) * 64);
+      if (cap_groups < 64 / G) a.gpw_active = (int)cap_groups;  // one wave, one group at work
+    }
     // "seen?" answers (bpr_device.h): the LDS bitmap (I bits per group) while a full 256-thread
     // block's bitmaps fit 64 KiB (>= 2 blocks per CU at full width: I <= 65,536 for d <= 128,
     // 131,072 above); larger item tables stage the user's sorted seen list in LDS instead
@@ -257,7 +261,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     const size_t shmem = (size_t)(block / G) * (size_t)lds_words * sizeof(uint32_t);
     int64_t want = n_runs;
     if (cap_groups > 0 && want > cap_groups) want = cap_groups;
-    const int64_t per_block = block / G;
+    const int64_t per_block = (int64_t)(block / 64) * a.gpw_active;
     int64_t nblk = (want + per_block - 1) / per_block;
     if (cap_groups <= 0 || n_runs <= cap_groups) nblk = (2 * nblk + 2) / 3;  // 1.5 runs per group
     const int64_t max_blk = std::min<int64_t>(stream_grid_cap() * (256 / block), STREAM_MAX_GRID);
