@@ -49,12 +49,12 @@ typedef enum bpr_opt_kind {
   BPR_OPT_SGD = 0,      /* torch.optim.SGD(lr)                               */
   BPR_OPT_MOMENTUM = 1, /* torch.optim.SGD(lr, momentum, dampening, nesterov) */
   BPR_OPT_ADAM = 2,     /* torch.optim.Adam(lr, betas, eps)                   */
-  BPR_OPT_RMSPROP = 3   /* torch.optim.RMSprop(lr, alpha, eps, momentum=0)    */
+  BPR_OPT_RMSPROP = 3   /* torch.optim.RMSprop(lr, alpha, eps, momentum)      */
 } bpr_opt_kind;
 
 typedef struct bpr_opt_params {
   float lr;
-  float momentum;  /* MOMENTUM */
+  float momentum;  /* MOMENTUM; RMSPROP (0 = none) */
   float dampening; /* MOMENTUM */
   int32_t nesterov;
   float beta1, beta2; /* ADAM */
@@ -111,7 +111,8 @@ int bpr_set_reg(bpr_ctx* ctx, float alpha_user, float alpha_item, float alpha_ne
 /* torch.optim hyper-parameters (read from optimizer.param_groups by the host shim each step). */
 int bpr_set_optimizer(bpr_ctx* ctx, int32_t kind, const bpr_opt_params* params);
 /* Optimizer state, same shapes as the tables (caller-owned so checkpoints keep working):
- *   MOMENTUM: m_* = momentum_buffer;  ADAM: m_* = exp_avg, v_* = exp_avg_sq;  RMSPROP: v_* = square_avg.
+ *   MOMENTUM: m_* = momentum_buffer;  ADAM: m_* = exp_avg, v_* = exp_avg_sq;  RMSPROP: v_* = square_avg
+ *   (+ m_* = momentum_buffer when momentum > 0).
  * *_bias may be NULL when there is no item_bias.  All zero-initialised by the caller. */
 int bpr_bind_opt_state(bpr_ctx* ctx, float* m_P, float* v_P, float* m_Q, float* v_Q,
                        float* m_bias, float* v_bias);

@@ -55,6 +55,11 @@ __device__ __forceinline__ void opt_replay(float& w, float& m, float& v, int64_t
     m *= (float)exp((double)k * o.log_b1);
     v *= (float)exp((double)k * o.log_b2);
   } else if (o.kind == OPT_RMSPROP) {
+    if (o.mu > 0.f) {  // RMSprop(momentum): buf <- mu buf, w <- w - lr buf on every zero-gradient step
+      const float muk = (float)exp((double)k * o.log_mu);
+      w -= o.lr * m * o.mu * (1.0f - muk) / (1.0f - o.mu);
+      m *= muk;
+    }
     v *= (float)exp((double)k * o.log_alpha);
   }
 }
@@ -158,6 +163,14 @@ __device__ __forceinline__ void opt_replay_row(float (&w)[E], float (&m)[E], flo
       }
     }
   } else if (o.kind == OPT_RMSPROP) {
+    if (o.mu > 0.f) {  // momentum buffer keeps moving the row (torch.optim.RMSprop, momentum > 0)
+      const float muk = (float)exp((double)k * o.log_mu);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        w[e] -= o.lr * m[e] * o.mu * (1.0f - muk) / (1.0f - o.mu);
+        m[e] *= muk;
+      }
+    }
     if constexpr (STATE) {
       const float ak = (float)exp((double)k * o.log_alpha);
 #pragma unroll
@@ -187,7 +200,12 @@ __device__ __forceinline__ void opt_update_at(float& w, float g, float& m, float
   } else {
     v = o.alpha * v + (1.0f - o.alpha) * g * g;
     const float avg = sqrtf(v) + o.eps;
-    w = w - o.lr * (g / avg);
+    if (o.mu > 0.f) {  // torch: buf.mul_(momentum).addcdiv_(grad, avg); param.add_(buf, alpha=-lr)
+      m = o.mu * m + g / avg;
+      w = w - o.lr * m;
+    } else {
+      w = w - o.lr * (g / avg);
+    }
   }
 }
 __device__ __forceinline__ void opt_update(float& w, float g, float& m, float& v, const OptDev& o,

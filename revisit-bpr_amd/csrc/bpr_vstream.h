@@ -167,7 +167,13 @@ __device__ __forceinline__ void vo_update(float& w, float g, float& m, float& v,
     w = w - adam_step * (m / denom);
   } else {
     v = o.alpha * v + (1.0f - o.alpha) * g * g;
-    w = w - o.lr * (g / (sqrtf(v) + o.eps));
+    const float avg = sqrtf(v) + o.eps;
+    if (o.mu > 0.f) {  // torch.optim.RMSprop(momentum > 0)
+      m = o.mu * m + g / avg;
+      w = w - o.lr * m;
+    } else {
+      w = w - o.lr * (g / avg);
+    }
   }
 }
 
@@ -186,6 +192,15 @@ __device__ __forceinline__ void vo_replay(float (&w)[E], float (&m)[E], float (&
       if constexpr (STATE) m[e] *= muk;
     }
   } else if constexpr (KIND == OPT_RMSPROP) {
+    if (o.mu > 0.f) {  // the momentum buffer keeps moving the row
+      const float muk = __builtin_amdgcn_exp2f(fmaxf((float)k * o.log2_mu, -126.f));
+      const float c = o.lr * o.mom_c * (1.0f - muk);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        w[e] -= c * m[e];
+        if constexpr (STATE) m[e] *= muk;
+      }
+    }
     if constexpr (STATE) {
       const float ak = __builtin_amdgcn_exp2f(fmaxf((float)k * o.log2_alpha, -126.f));
 #pragma unroll

@@ -173,7 +173,8 @@ static ApplyArgs apply_args(const bpr_ctx* c, int64_t t) {
 }
 
 int check_opt_state(const bpr_ctx* c, const char* who) {
-  const bool need_m = c->opt_kind == BPR_OPT_MOMENTUM || c->opt_kind == BPR_OPT_ADAM;
+  const bool need_m = c->opt_kind == BPR_OPT_MOMENTUM || c->opt_kind == BPR_OPT_ADAM ||
+                      (c->opt_kind == BPR_OPT_RMSPROP && c->opt.momentum > 0.f);
   const bool need_v = c->opt_kind == BPR_OPT_ADAM || c->opt_kind == BPR_OPT_RMSPROP;
   if ((need_m && (!c->mP || !c->mQ || (c->bias && !c->mb))) ||
       (need_v && (!c->vP || !c->vQ || (c->bias && !c->vb))))
@@ -448,7 +449,8 @@ int bpr_set_optimizer(bpr_ctx* c, int32_t kind, const bpr_opt_params* params) {
     return fail(BPR_ERR_INVALID, "bpr_set_optimizer: NULL argument");
   if (kind < BPR_OPT_SGD || kind > BPR_OPT_RMSPROP)
     return fail(BPR_ERR_INVALID, "bpr_set_optimizer: unknown optimizer kind");
-  if (kind == BPR_OPT_MOMENTUM && !(params->momentum >= 0.f && params->momentum < 1.f))
+  if ((kind == BPR_OPT_MOMENTUM || kind == BPR_OPT_RMSPROP) &&
+      !(params->momentum >= 0.f && params->momentum < 1.f))
     return fail(BPR_ERR_INVALID, "bpr_set_optimizer: momentum must be in [0, 1)");
   if (c->vs_active && (kind != c->opt_kind || memcmp(&c->opt, params, sizeof(*params)) != 0)) {
     // batched STREAM: pending steps and the replay of missed ones use the hyper-parameters in

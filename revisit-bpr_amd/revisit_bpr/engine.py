@@ -114,6 +114,7 @@ class Engine:
                                alpha)
         native.check(self._lib.bpr_set_optimizer(self._ctx, kind, ctypes.byref(prm)))
         self.opt_kind = kind
+        self._momentum = momentum
 
     def bind_opt_state(self, mP=None, vP=None, mQ=None, vQ=None, mb=None, vb=None) -> None:
         self._keep["opt_state"] = (mP, vP, mQ, vQ, mb, vb)
@@ -123,7 +124,8 @@ class Engine:
     def alloc_opt_state(self) -> dict:
         """Zero state tensors of the shapes the current optimizer kind needs, bound to the ctx."""
         z = torch.zeros_like
-        need_m = self.opt_kind in (OPT_MOMENTUM, OPT_ADAM)
+        need_m = self.opt_kind in (OPT_MOMENTUM, OPT_ADAM) or (
+            self.opt_kind == OPT_RMSPROP and getattr(self, "_momentum", 0.0) > 0)
         need_v = self.opt_kind in (OPT_ADAM, OPT_RMSPROP)
         st = {
             "mP": z(self.P) if need_m else None, "vP": z(self.P) if need_v else None,
@@ -175,6 +177,13 @@ class Engine:
         native.check(self._lib.bpr_adaptive_get_snapshot(self._ctx, order.data_ptr(),
                                                          sigma.data_ptr()))
         return order, sigma
+
+    def adaptive_sigma(self) -> torch.Tensor:
+        """sigma_f of the current snapshot (AdaptiveSampler._factor_std), [d] fp32."""
+        self._sync_stream()
+        sigma = torch.empty(self.d, dtype=torch.float32, device=self.device)
+        native.check(self._lib.bpr_adaptive_get_snapshot(self._ctx, None, sigma.data_ptr()))
+        return sigma
 
     # ---- hot path ---------------------------------------------------------------------------
     def _outs(self, B: int, want_logits: bool, scalars: Optional[torch.Tensor]):

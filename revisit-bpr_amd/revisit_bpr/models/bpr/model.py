@@ -166,6 +166,7 @@ class Model(torch.nn.Module):
         self._pending = False
         self._opt_sig = None
         self._state_sig = None
+        self._reg_n = 1
         self._anchor = None
 
     # ---- fused engine plumbing ------------------------------------------------------------
@@ -193,6 +194,7 @@ class Model(torch.nn.Module):
             self._engine_key = key
             self._opt_sig = None
             self._state_sig = None
+            self._reg_n = 1
             self._pending = self._armed = False
             for prm in (P, Q, b):
                 if prm is not None:
@@ -238,8 +240,6 @@ class Model(torch.nn.Module):
         kind = _OPT_KINDS[name]
         if name == "SGD" and group.get("momentum", 0) != 0:
             kind = 1
-        if name == "RMSprop" and group.get("momentum", 0) != 0:
-            raise NotImplementedError("RMSprop with momentum is not fused")
         sig = (kind, float(group["lr"]), group.get("momentum", 0.0), group.get("dampening", 0.0),
                bool(group.get("nesterov", False)), tuple(group.get("betas", (0.9, 0.999))),
                group.get("eps", 1e-8), group.get("alpha", 0.99))
@@ -320,7 +320,9 @@ class Model(torch.nn.Module):
         ``Model.sync()``), so bias corrections and the lazy replay continue where they stopped."""
         if kind == 0:
             return
-        keys = {1: ("momentum_buffer", None), 2: ("exp_avg", "exp_avg_sq"), 3: (None, "square_avg")}[kind]
+        rms_mom = kind == 3 and self._opt_sig is not None and self._opt_sig[2] != 0
+        keys = {1: ("momentum_buffer", None), 2: ("exp_avg", "exp_avg_sq"),
+                3: ("momentum_buffer" if rms_mom else None, "square_avg")}[kind]
         bufs, created = [], False
         for prm in self._fused_params():
             st = optimizer.state[prm]
@@ -403,6 +405,15 @@ class Model(torch.nn.Module):
         shape = item.shape
         n = item.numel() // max(user.numel(), 1)
         users = user if n == 1 else user.repeat_interleave(n)
+        if n != self._reg_n:
+            # Model.regularization counts the user term once per ROW and the item terms once per
+            # (row, item) pair (model.py:87-93): with n items per row the n triples of a row share
+            # one user term
+            from revisit_bpr.engine import resolve_reg_alphas
+
+            a_user, a_item, a_neg = resolve_reg_alphas(self._reg_alphas)
+            eng.set_reg(a_user / n, a_item, a_neg)
+            self._reg_n = n
         lp, ln, sc = eng.forward_grad(users, item.reshape(-1), neg.reshape(-1))
         self._pending = True
         self._armed = False

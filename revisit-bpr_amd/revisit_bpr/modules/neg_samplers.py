@@ -43,11 +43,21 @@ def csr_from_padded(users: torch.Tensor, seen_items: torch.Tensor, num_users: in
 
 
 def _num(batch) -> int:
-    num = batch["item"].size(-1) if batch["item"].dim() > 1 else 1
-    if num != 1:
-        raise NotImplementedError("the device samplers draw one negative per positive (every "
-                                  "reference config uses num = 1)")
-    return num
+    """Negatives per row: num = batch["item"].size(-1) (reference: neg_samplers.py:32,76)."""
+    return batch["item"].size(-1) if batch["item"].dim() > 1 else 1
+
+
+def _distinct_rows(neg: torch.Tensor, redraw) -> torch.Tensor:
+    """multinomial(..., num_samples=num) draws WITHOUT replacement (neg_samplers.py:33-37): the
+    device sampler's independent draws are repeated where a row holds the same item twice
+    (rejection — the accepted rows are uniform over the sets of `num` distinct unseen items)."""
+    for _ in range(64):
+        srt, _ = torch.sort(neg, dim=1)
+        bad = (srt[:, 1:] == srt[:, :-1]).any(dim=1)
+        if not bool(bad.any()):
+            return neg
+        neg[bad] = redraw(bad)
+    raise RuntimeError("could not draw distinct negatives (fewer unseen items than negatives per row?)")
 
 
 class UniformSampler(Sampler):
@@ -71,7 +81,7 @@ class UniformSampler(Sampler):
         return self._engine
 
     def sample(self, batch: dict[str, torch.Tensor]) -> torch.Tensor:
-        _num(batch)
+        num = _num(batch)
         users, seen = batch["user"].reshape(-1), batch["seen_items"]
         if not users.is_cuda:
             raise RuntimeError("UniformSampler draws on the GPU: move the batch to the ROCm device")
@@ -82,10 +92,16 @@ class UniformSampler(Sampler):
         local_ptr[1:uniq.numel() + 1] = torch.cumsum(counts, 0)
         local_ptr[uniq.numel() + 1:] = local_ptr[uniq.numel()]
         eng.bind_seen_csr(local_ptr, indices)
-        neg = eng.sample_uniform(inv.to(torch.int32), seed=self._neg_gen.initial_seed(),
-                                 offset=self._drawn)
-        self._drawn += users.numel()
-        return neg.to(torch.long).unsqueeze(-1)
+        rows = inv.to(torch.int32)
+
+        def draw(sel: torch.Tensor) -> torch.Tensor:  # `num` draws for the selected batch rows
+            r = rows[sel].repeat_interleave(num)
+            out = eng.sample_uniform(r, seed=self._neg_gen.initial_seed(), offset=self._drawn)
+            self._drawn += r.numel()
+            return out.to(torch.long).view(-1, num)
+
+        neg = draw(torch.ones_like(rows, dtype=torch.bool))
+        return neg if num == 1 else _distinct_rows(neg, draw)
 
 
 class AdaptiveSampler(Sampler):
@@ -112,19 +128,42 @@ class AdaptiveSampler(Sampler):
 
     def sample(self, batch: dict[str, torch.Tensor]) -> torch.Tensor:
         self._iteration_cnt += 1
-        _num(batch)
+        num = _num(batch)
         model = self._bpr()
         eng = model.engine()
         users = batch["user"].reshape(-1)
         if not getattr(model, "_has_csr", False):
             indptr, indices = csr_from_padded(users, batch["seen_items"], eng.U)
             eng.bind_seen_csr(indptr, indices)
-        neg = eng.sample_adaptive(users, self._sampling_prob, seed=self._neg_gen.initial_seed(),
-                                  offset=self._drawn)
-        self._drawn += users.numel()
+        if num == 1:
+            neg = eng.sample_adaptive(users, self._sampling_prob, seed=self._neg_gen.initial_seed(),
+                                      offset=self._drawn).to(torch.long).unsqueeze(-1)
+            self._drawn += users.numel()
+        else:
+            neg = self._sample_many(model, eng, users, num)
         if self._iteration_cnt % self._every == 0:
             self.update_stats()
-        return neg.to(torch.long).unsqueeze(-1)
+        return neg
+
+    @torch.no_grad()
+    def _sample_many(self, model, eng, users: torch.Tensor, num: int) -> torch.Tensor:
+        """num > 1 negatives per row, literally as the reference (neg_samplers.py:84-121):
+        `num` DISTINCT factors per row (multinomial without replacement over |p_uf| sigma_f), an
+        independent Geometric rank for each, orientation by the sign of p_uf, and the rank-th
+        unseen item of that factor's snapshot order (`bpr_adaptive_pick`).  Factors and ranks come
+        from torch's generator here; no reference config uses num > 1."""
+        model.sync()  # the live user rows, as of now
+        p_u = model.logits_model.get_features()["user"].detach()[users]
+        sigma = eng.adaptive_sigma()
+        indptr = eng._keep["csr"][0]
+        n_unseen = (eng.I - 1 - (indptr[users + 1] - indptr[users])).unsqueeze(-1)
+        factor = torch.multinomial(p_u.abs() * sigma, num_samples=num, generator=self._neg_gen)
+        rank = torch.empty_like(factor).geometric_(self._sampling_prob, generator=self._neg_gen)
+        rank = torch.minimum(rank, n_unseen)
+        rank = torch.where(p_u.gather(-1, factor).gt(0), rank - 1, n_unseen - rank)
+        rank = rank.clamp(min=torch.zeros_like(n_unseen), max=n_unseen - 1)
+        neg = eng.adaptive_pick(users.repeat_interleave(num), factor.reshape(-1), rank.reshape(-1))
+        return neg.to(torch.long).view(-1, num)
 
     @torch.no_grad()
     def update_stats(self) -> None:

@@ -42,6 +42,8 @@ OPTS = {
     "adam": lambda p: torch.optim.Adam(p, lr=0.01, betas=(0.9, 0.999)),
     "adam01": lambda p: torch.optim.Adam(p, lr=0.01, betas=(0.1, 0.999)),
     "rmsprop": lambda p: torch.optim.RMSprop(p, lr=0.01, alpha=0.9),
+    # momentum is in the Optuna space of configs/RQ2/optimizers/rmsprop-ml-20m.yaml.j2:62-64
+    "rmsprop_mom": lambda p: torch.optim.RMSprop(p, lr=0.005, alpha=0.9, momentum=0.8),
 }
 
 
@@ -84,7 +86,7 @@ def test_reference_loop_fused_equals_dense_torch(opt_name, item_bias):
     (sd_h, l_h), (sd_t, l_t) = results["hip"], results["torch"]
     assert np.allclose(l_h, l_t, rtol=2e-5)
     # RMSprop divides by sqrt(v) ~ |g|: elements whose gradient is ~0 amplify fp32 rounding of g
-    atol = 1e-4 if opt_name == "rmsprop" else 2e-5
+    atol = 1e-4 if opt_name.startswith("rmsprop") else 2e-5
     for k in sd_t:
         assert torch.allclose(sd_h[k], sd_t[k], rtol=0, atol=atol), (k, (sd_h[k] - sd_t[k]).abs().max())
 
@@ -417,3 +419,57 @@ def test_eval_after_forward_without_step_discards_the_pending_gradients():
     with pytest.raises(RuntimeError):
         model.eval()  # armed but never stepped
     model.engine().discard_grad()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "adaptive"])
+def test_samplers_with_several_negatives_per_positive(kind):
+    """num = batch["item"].size(-1) > 1 (reference: neg_samplers.py:32-37, 76-121): [B, num]
+    negatives, never item 0, never a seen item; uniform rows hold DISTINCT items (multinomial draws
+    without replacement); and the fused forward / step on the [B, num] batch equals dense autograd."""
+    from revisit_bpr.models.bpr import set_backend
+    from revisit_bpr.modules import AdaptiveSampler, UniformSampler
+
+    U, I, d, B, num = 200, 120, 32, 64, 3
+    reg = {"user": 0.0016, "item": 0.0001, "neg": 0.00375}
+    g = torch.Generator().manual_seed(5)
+    seen = torch.zeros(U, 12, dtype=torch.long)
+    for u in range(1, U):
+        k = int(torch.randint(3, 12, (1,), generator=g))
+        seen[u, :k] = torch.randperm(I - 1, generator=g)[:k] + 1
+    seen = seen.cuda()
+    users = torch.randint(1, U, (B,), generator=g).cuda()
+    pos = torch.stack([seen[u, torch.randint(0, 3, (num,), generator=g)] for u in users.tolist()])
+    model = build(U, I, d, reg, False, seed=2)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    batch = {"user": users, "item": pos, "seen_items": seen[users]}
+    if kind == "uniform":
+        sampler = UniformSampler(I, gen)
+    else:
+        sampler = AdaptiveSampler(model, I, 0.1, gen, every=10 ** 9)
+        sampler.update_stats()
+    neg = sampler.sample(batch)
+    assert neg.shape == (B, num) and neg.dtype == torch.long
+    assert int(neg.min()) >= 1 and int(neg.max()) < I
+    assert not bool((neg.unsqueeze(-1) == seen[users].unsqueeze(1)).any())
+    if kind == "uniform":
+        srt, _ = torch.sort(neg, dim=1)
+        assert not bool((srt[:, 1:] == srt[:, :-1]).any())
+    batch["neg"] = neg
+    res = {}
+    for backend in ("hip", "torch"):
+        set_backend(backend)
+        try:
+            m = build(U, I, d, reg, False, seed=2)
+            opt = torch.optim.SGD(m.parameters(), lr=0.05)
+            m.train()
+            out = m(batch)
+            assert out["logits"].shape == (B, num)
+            out["loss"].backward()
+            opt.step()
+            m.eval()
+            res[backend] = (float(out["loss"].detach()), {k: v.detach().clone() for k, v in m.state_dict().items()})
+        finally:
+            set_backend("hip")
+    assert abs(res["hip"][0] - res["torch"][0]) <= 2e-5 * abs(res["torch"][0])
+    for k in res["torch"][1]:
+        assert torch.allclose(res["hip"][1][k], res["torch"][1][k], rtol=0, atol=2e-6)

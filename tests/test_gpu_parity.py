@@ -220,6 +220,7 @@ def test_adam_lazy_replay_long_gaps_after_warmup(d, route, monkeypatch):
     ("momentum", dict(kind=1, lr=0.01, momentum=0.9)),
     ("momentum_damp", dict(kind=1, lr=0.02, momentum=0.5, dampening=0.3)),
     ("rmsprop", dict(kind=3, lr=0.0005, alpha=0.9)),
+    ("rmsprop_mom", dict(kind=3, lr=0.0003, alpha=0.9, momentum=0.8)),
     ("adam_01", dict(kind=2, lr=0.001, betas=(0.1, 0.999))),
 ])
 @pytest.mark.parametrize("d", [32, 128])

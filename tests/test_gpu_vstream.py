@@ -31,6 +31,7 @@ OPTS = {
     "adam_01": dict(kind=2, lr=0.003, betas=(0.1, 0.999)),
     "adam_00": dict(kind=2, lr=0.003, betas=(0.0, 0.99)),
     "rmsprop": dict(kind=3, lr=0.0005, alpha=0.9),
+    "rmsprop_mom": dict(kind=3, lr=0.0003, alpha=0.9, momentum=0.8),
 }
 REG = (0.0016, 0.0001, 0.00375)
 
