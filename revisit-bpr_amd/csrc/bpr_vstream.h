@@ -308,8 +308,8 @@ __device__ __forceinline__ void vs_apply1(float& w, float& m, float& v, float g,
 
 // The row as of virtual step t-1 (nothing is written).  wb: the riding scalar's view (0 if none).
 template <int G, int E, int KIND>
-__device__ __forceinline__ void vs_view(float (&w)[E], float& wb, const VTable& T, uint32_t row,
-                                        int d, int gl, int64_t t, const VOpt& o) {
+__device__ __forceinline__ uint64_t vs_view(float (&w)[E], float& wb, const VTable& T, uint32_t row,
+                                            int d, int gl, int64_t t, const VOpt& o) {
   constexpr bool STATEFUL = KIND != OPT_SGD;
   const VHdr h{ld_hdr(T.H + row)};
   const size_t off = (size_t)row * (size_t)d;
@@ -348,19 +348,27 @@ __device__ __forceinline__ void vs_view(float (&w)[E], float& wb, const VTable& 
     vo_replay<KIND, E, false>(w, m, v, a, k, o);
     if (T.b != nullptr) vo_replay1<KIND, false>(wb, bm, bv, a, k, o);
   }
+  return h.raw;  // the header this view was taken under (vs_contribute's first guess)
 }
 
 // Add this triple's gradient g (and gb for the riding scalar) to row's virtual step t.
+// `hint`: the header the row's view was taken under.  When it says "t closes the pending step" the
+// CAS is tried on it directly (the CAS itself validates it: one round trip saved on the common
+// path — a user row, a cold item row); a "join" is always decided on a fresh header, so that the
+// add lands in the accumulator that is current NOW.
 template <int G, int E, int KIND>
 __device__ __forceinline__ void vs_contribute(const VTable& T, uint32_t row, int d, int gl,
                                               int lane, int64_t t, const float (&g)[E], float gb,
-                                              bool act, const VOpt& o) {
+                                              bool act, const VOpt& o, uint64_t hint) {
   constexpr bool STATEFUL = KIND != OPT_SGD;
   const size_t off = (size_t)row * (size_t)d;
   bool done = !act;
+  bool guess = true;
   while (!__all(done)) {
     if (!done) {
-      const VHdr h{ld_hdr(T.H + row)};
+      VHdr h{hint};
+      if (!guess || t <= h.gstep() || h.locked()) h.raw = ld_hdr(T.H + row);
+      guess = false;
       const int64_t gs = h.gstep();
       if (t <= gs) {
         // the row's pending step is mine, or already a later one (I am a straggler: join it)
@@ -498,7 +506,7 @@ struct VStreamArgs {
 // optimizer replay inlined six times cost 256 VGPRs (one wave per SIMD); the kernel is bound by
 // the latency of its dependent memory round trips, i.e. by how many triples are in flight.
 template <int G, int E, int SAMPLER, int SEEN, int KIND>
-__global__ __launch_bounds__(256) void k_vstream(const VStreamArgs a) {
+__global__ __launch_bounds__(256, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void k_vstream(const VStreamArgs a) {
   constexpr int DP = G * E;
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
@@ -536,6 +544,7 @@ __global__ __launch_bounds__(256) void k_vstream(const VStreamArgs a) {
     const int64_t t = a.t_base + (int64_t)(kk / a.B);
     int32_t j = 0;
     float bi = 0.f, bj = 0.f;
+    uint64_t hu = 0, hi_ = 0, hj = 0;  // headers the three views were taken under
 #pragma unroll 1
     for (int r = 0; r < 3; ++r) {
       if (r == 2) {  // the negative: drawn from the user's row as of t-1, like the reference
@@ -573,7 +582,10 @@ __global__ __launch_bounds__(256) void k_vstream(const VStreamArgs a) {
       }
       const uint32_t row = r == 0 ? u : (r == 1 ? i : (uint32_t)j);
       float w[E], wb;
-      vs_view<G, E, KIND>(w, wb, table(r), row, d, gl, t, a.o);
+      const uint64_t hr = vs_view<G, E, KIND>(w, wb, table(r), row, d, gl, t, a.o);
+      hu = r == 0 ? hr : hu;
+      hi_ = r == 1 ? hr : hi_;
+      hj = r == 2 ? hr : hj;
 #pragma unroll
       for (int e = 0; e < E; ++e) rows[r * DP + e * G + gl] = w[e];
       bi = r == 1 ? wb : bi;
@@ -614,7 +626,8 @@ __global__ __launch_bounds__(256) void k_vstream(const VStreamArgs a) {
         g[e] = cp * rows[e * G + gl] + ci * rows[DP + e * G + gl] + cj * rows[2 * DP + e * G + gl];
       const float gb = r == 0 ? 0.f : (r == 1 ? -w : w);
       vs_contribute<G, E, KIND>(table(r), row, d, gl, lane, t, g, gb,
-                                    act && (!pad || (r != 0 && has_bias)), a.o);
+                                act && (!pad || (r != 0 && has_bias)), a.o,
+                                r == 0 ? hu : (r == 1 ? hi_ : hj));
     }
   }
   if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);

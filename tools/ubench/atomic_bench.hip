@@ -10,6 +10,10 @@
 //   store               both item rows read-modify-written with plain stores (no atomics: lost
 //                       updates, the bandwidth floor)
 //   none                no item update at all
+//   u64-packed          two fixed-point int32 fields per 64-bit integer atomic (global_atomic_add_x2):
+//                       half as many atomic operations for the same 128 values per row
+//   u32 / f64           32-bit integer adds (one per value), double adds (one per PAIR of values'
+//                       worth of bytes) — is the unit's rate per operation or per byte?
 //
 //   hipcc -O3 --offload-arch=gfx950 atomic_bench.hip -o atomic_bench && ./atomic_bench [n] [U] [I] [hot]
 //   llvm-objdump -d --offloading atomic_bench | grep global_atomic      (scope bits of each variant)
@@ -34,7 +38,7 @@ __device__ __forceinline__ float gsum(float v) {
 }
 
 enum { S_AGENT = 0, S_WG = 1, S_WAVE = 2, S_SYS = 3, S_XCD_WG = 4, S_NEG_ONLY = 5, S_STORE = 6, S_NONE = 7,
-       S_AGENT_RET = 8 };
+       S_AGENT_RET = 8, S_U64 = 9, S_U32 = 10, S_F64 = 11 };
 
 template <int V>
 __device__ __forceinline__ void upd(float* p, float v) {
@@ -91,6 +95,27 @@ __global__ __launch_bounds__(256) void k(float* P, float* Q, float* Qrep, int64_
         } else if constexpr (V == S_AGENT_RET) {
           acc += __hip_atomic_fetch_add(iw + e * G + gl, di, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           acc += __hip_atomic_fetch_add(jw + e * G + gl, dj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if constexpr (V == S_U64 || V == S_F64) {
+          // 64 qwords per row: two instructions of 32 lanes x 8 B (256 contiguous bytes) per row
+          if (e < 2) {
+            if constexpr (V == S_U64) {
+              unsigned long long* i64 = reinterpret_cast<unsigned long long*>(iw) + e * G + gl;
+              unsigned long long* j64 = reinterpret_cast<unsigned long long*>(jw) + e * G + gl;
+              const long long vi = ((long long)(int)(di * 1e9f) << 32) + (long long)(int)(dj * 1e9f);
+              __hip_atomic_fetch_add(i64, (unsigned long long)vi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_fetch_add(j64, (unsigned long long)(vi + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              double* i64 = reinterpret_cast<double*>(iw) + e * G + gl;
+              double* j64 = reinterpret_cast<double*>(jw) + e * G + gl;
+              __hip_atomic_fetch_add(i64, (double)di, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_fetch_add(j64, (double)dj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        } else if constexpr (V == S_U32) {
+          __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(iw) + e * G + gl, (unsigned)(int)(di * 1e9f),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(jw) + e * G + gl, (unsigned)(int)(dj * 1e9f),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if constexpr (V == S_NEG_ONLY) {
           acc += di;
           upd<V>(jw + e * G + gl, dj);
@@ -171,5 +196,9 @@ int main(int argc, char** argv) {
   run<S_WAVE>("wavefront", blocks, P, Q, Qrep, stride, us, is, js, n, out);
   run<S_SYS>("system", blocks, P, Q, Qrep, stride, us, is, js, n, out);
   run<S_XCD_WG>("xcd-replica-wg", blocks, P, Q, Qrep, stride, us, is, js, n, out);
+  // (integer / double variants scribble over the fp32 table: last)
+  run<S_U32>("u32", blocks, P, Q, Qrep, stride, us, is, js, n, out);
+  run<S_U64>("u64-packed", blocks, P, Q, Qrep, stride, us, is, js, n, out);
+  run<S_F64>("f64", blocks, P, Q, Qrep, stride, us, is, js, n, out);
   return 0;
 }
