@@ -354,7 +354,8 @@ def main():
         # (profiles/r01_pmc_traffic.md: FETCH_SIZE x2 correction + WRITE_SIZE); null when the run
         # is not the profiled configuration
         traffic = None
-        tfile = ROOT / "profiles" / "traffic_r01.json"
+        tfiles = sorted((ROOT / "profiles").glob("traffic_r*.json"))
+        tfile = tfiles[-1] if tfiles else ROOT / "profiles" / "none"
         if tfile.exists() and args.workload == "ml-20m" and d == 128 and args.sampler == "adaptive" \
                 and args.scale == 1.0 and not batched:
             tj = json.loads(tfile.read_text())
@@ -396,7 +397,10 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" if traffic else None,
+                "traffic_source": (f"profiles/{tfile.stem.replace('traffic_', '')}_pmc_traffic.md (separate rocprofv3 --pmc "
+                                   "FETCH_SIZE / WRITE_SIZE passes of this command on an MI355X, bytes per launch, "
+                                   "gfx950 x2 read correction; replayed from the committed summary, not re-measured "
+                                   "in this run)") if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_triple * chunk,
                 "bytes_per_triple": bytes_per_triple,
                 "kernel_ms_avg": kernel_ms,

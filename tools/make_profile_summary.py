@@ -23,7 +23,9 @@ def agg(path):
     return a
 
 
-shutil.copy(G / "prof_r01" / "bench_kernel_stats.csv", P / f"{tag}_bench_kernel_stats.csv")
+shutil.copy(G / f"prof_{tag}" / "bench_kernel_stats.csv", P / f"{tag}_bench_kernel_stats.csv")
+if (G / f"prof_{tag}_adam" / "bench_kernel_stats.csv").exists():
+    shutil.copy(G / f"prof_{tag}_adam" / "bench_kernel_stats.csv", P / f"{tag}_bench_adam_yelp_kernel_stats.csv")
 out = [f"# {tag} — rocprofv3 PMC passes (separate runs): FETCH_SIZE and WRITE_SIZE, unit KB (x1024 B)",
        "# command: rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --steps 96 --warmup 8 --no-cpu-baseline",
        "", "## calibration on known byte counts (tools/ubench/pmc_calib.hip, 1 GiB buffers > Infinity Cache)",

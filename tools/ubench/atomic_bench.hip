@@ -12,6 +12,9 @@
 //   none                no item update at all
 //   u64-packed          two fixed-point int32 fields per 64-bit integer atomic (global_atomic_add_x2):
 //                       half as many atomic operations for the same 128 values per row
+//   pos-aggregated      what aggregating the positives of a 16 k-triple window per item would leave:
+//                       24 % of the triples update their positive row with atomics, the others
+//                       park a 512-B contribution vector (16-B stores) that is read back once
 //   u32 / f64           32-bit integer adds (one per value), double adds (one per PAIR of values'
 //                       worth of bytes) — is the unit's rate per operation or per byte?
 //
@@ -38,7 +41,7 @@ __device__ __forceinline__ float gsum(float v) {
 }
 
 enum { S_AGENT = 0, S_WG = 1, S_WAVE = 2, S_SYS = 3, S_XCD_WG = 4, S_NEG_ONLY = 5, S_STORE = 6, S_NONE = 7,
-       S_AGENT_RET = 8, S_U64 = 9, S_U32 = 10, S_F64 = 11 };
+       S_AGENT_RET = 8, S_U64 = 9, S_U32 = 10, S_F64 = 11, S_AGG = 12 };
 
 template <int V>
 __device__ __forceinline__ void upd(float* p, float v) {
@@ -116,6 +119,16 @@ __global__ __launch_bounds__(256) void k(float* P, float* Q, float* Qrep, int64_
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(jw) + e * G + gl, (unsigned)(int)(dj * 1e9f),
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if constexpr (V == S_AGG) {
+          __hip_atomic_fetch_add(jw + e * G + gl, dj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (((uint32_t)tt * 2654435761u >> 8) % 100u < 24u)
+            __hip_atomic_fetch_add(iw + e * G + gl, di, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else if (e == 3) {
+            float4* cb = reinterpret_cast<float4*>(Qrep);
+            cb[tt * G + gl] = make_float4(di, dj, di + dj, di - dj);
+            const float4 o = cb[((tt * 7919) % n) * G + gl];
+            acc += o.x + o.y + o.z + o.w;
+          }
         } else if constexpr (V == S_NEG_ONLY) {
           acc += di;
           upd<V>(jw + e * G + gl, dj);
@@ -149,7 +162,7 @@ void run(const char* name, int blocks, float* P, float* Q, float* Qrep, int64_t 
   }
   std::sort(ts.begin(), ts.end());
   const double ms = ts[ts.size() / 2];
-  const double rows = (V == S_NEG_ONLY) ? 1.0 : ((V == S_NONE || V == S_STORE) ? 0.0 : 2.0);
+  const double rows = (V == S_NEG_ONLY) ? 1.0 : (V == S_AGG ? 1.24 : ((V == S_NONE || V == S_STORE) ? 0.0 : 2.0));
   printf("%-16s %8.3f ms  %8.1f Mtriples/s   %6.2f G line-atomics/s  %6.1f G dword-atomics/s\n", name, ms,
          n / ms * 1e-3, rows * 4 * n / ms * 1e-6, rows * 128 * n / ms * 1e-6);
 }
@@ -159,8 +172,8 @@ int main(int argc, char** argv) {
   int64_t U = argc > 2 ? atoll(argv[2]) : 136678, I = argc > 3 ? atoll(argv[3]) : 20109;
   int hot = argc > 4 ? atoi(argv[4]) : 2;  // 0 uniform items, 1 Zipf on neighbouring rows, 2 Zipf scattered
   float *P, *Q, *Qrep, *out; int *us, *is, *js;
-  CK(hipMalloc(&P, U * D * 4)); CK(hipMalloc(&Q, I * D * 4)); CK(hipMalloc(&Qrep, 8 * I * D * 4)); CK(hipMalloc(&out, 16));
-  CK(hipMemset(Qrep, 0, 8 * I * D * 4));
+  CK(hipMalloc(&P, U * D * 4)); CK(hipMalloc(&Q, I * D * 4)); const size_t rep_bytes = (size_t)std::max<int64_t>(8 * I, n) * D * 4; CK(hipMalloc(&Qrep, rep_bytes)); CK(hipMalloc(&out, 16));
+  CK(hipMemset(Qrep, 0, rep_bytes));
   CK(hipMalloc(&us, n * 4)); CK(hipMalloc(&is, n * 4)); CK(hipMalloc(&js, n * 4));
   std::mt19937_64 rng(13);
   std::vector<float> h(U * D); for (auto& x : h) x = ((rng() >> 40) * (1.0f / 16777216.0f) - 0.5f) / D;
@@ -196,6 +209,7 @@ int main(int argc, char** argv) {
   run<S_WAVE>("wavefront", blocks, P, Q, Qrep, stride, us, is, js, n, out);
   run<S_SYS>("system", blocks, P, Q, Qrep, stride, us, is, js, n, out);
   run<S_XCD_WG>("xcd-replica-wg", blocks, P, Q, Qrep, stride, us, is, js, n, out);
+  run<S_AGG>("pos-aggregated", blocks, P, Q, Qrep, stride, us, is, js, n, out);
   // (integer / double variants scribble over the fp32 table: last)
   run<S_U32>("u32", blocks, P, Q, Qrep, stride, us, is, js, n, out);
   run<S_U64>("u64-packed", blocks, P, Q, Qrep, stride, us, is, js, n, out);
