@@ -124,6 +124,15 @@ int bpr_bind_opt_state(bpr_ctx* ctx, float* m_P, float* v_P, float* m_Q, float* 
 int bpr_sample_uniform(bpr_ctx* ctx, const int32_t* users, int64_t B, uint64_t seed,
                        uint64_t offset, int32_t* neg_out);
 
+/* Item weights of the uniform sampler — BPRExperiment._static_sampling with
+ * item_counts ** neg_sampling_alpha (experiments/bpr/exp.py:85-91, 282-293): P(negative = i) =
+ * w_i / (sum of w over the user's unseen items), w_0 = 0.  The caller passes a Walker alias table
+ * over items 1..I-1 (accept [I] fp32, alias [I] int32, entry 0 unused; the host shim builds it):
+ * candidate = column c if frac(r (I-1) / 2^32) < accept[c] else alias[c]; seen candidates are
+ * rejected as before.  NULL, NULL = uniform (the default).  Affects every uniform draw of the ctx
+ * (bpr_sample_uniform, bpr_step, bpr_train_*). */
+int bpr_bind_item_weights(bpr_ctx* ctx, const float* accept, const int32_t* alias);
+
 /* AdaptiveSampler.update_stats (neg_samplers.py:126-132): snapshot the item table as per-factor
  * descending item orders (private scratch, d*I int32) and sigma_f = unbiased std over rows 1.. */
 int bpr_adaptive_refresh(bpr_ctx* ctx);
@@ -243,6 +252,9 @@ int bpr_plan_epoch(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_in,
  * step.  The strict path replays the missed zero-gradient steps lazily when a row is next
  * touched; this brings all rows to the current step (call before eval / checkpoint / all-reduce). */
 int bpr_flush_lazy(bpr_ctx* ctx);
+/* The same for the item table (and item_bias) only: what the item reconciliation across GPUs and
+ * the sampler snapshot need — the user shard of a rank is read by nobody else and stays lazy. */
+int bpr_flush_items(bpr_ctx* ctx);
 /* Global optimizer step counter t (number of bpr_apply calls); settable for checkpoint resume. */
 int bpr_get_step_host(bpr_ctx* ctx, int64_t* step_host);
 int bpr_set_step(bpr_ctx* ctx, int64_t step);

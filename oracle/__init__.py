@@ -182,6 +182,36 @@ def sample_uniform(indptr, indices, I, users, seed, offset=0):
     return out
 
 
+def alias_table(weights):
+    """Walker / Vose alias table over weights[1:] (weights[0], the pad item, is ignored): returns
+    (accept float32 [I], alias int32 [I]) such that drawing a column c uniformly in 1..I-1 and
+    keeping it with probability accept[c], else taking alias[c], yields item i with probability
+    w_i / sum(w).  The product's host code builds the same table (revisit_bpr.engine.alias_table)."""
+    w = np.asarray(weights, np.float64)[1:]
+    n = w.shape[0]
+    assert n >= 1 and (w >= 0).all() and w.sum() > 0
+    p = w * (n / w.sum())
+    accept = np.ones(n + 1, np.float32)
+    alias = np.arange(n + 1, dtype=np.int32)
+    small = [i for i in range(n) if p[i] < 1.0]
+    large = [i for i in range(n) if p[i] >= 1.0]
+    p = p.copy()
+    while small and large:
+        s_, l_ = small.pop(), large.pop()
+        accept[s_ + 1] = np.float32(p[s_])
+        alias[s_ + 1] = l_ + 1
+        p[l_] -= 1.0 - p[s_]
+        (small if p[l_] < 1.0 else large).append(l_)
+    return accept, alias
+
+
+def sample_weighted(indptr, indices, I, users, seed, offset, accept, alias):
+    out = np.empty(len(users), np.int32)
+    lib().orc_sample_weighted(_i64(indptr), _i32(indices), c_i64(I), _i32(users), c_i64(len(users)),
+                              c_u64(seed), c_u64(offset), _f(accept), _i32(alias), _i32(out))
+    return out
+
+
 def adaptive_stats(Q):
     I, d = Q.shape
     QT = np.empty((d, I), np.float32)

@@ -310,14 +310,42 @@ static int csr_contains(const int64_t* indptr, const int32_t* indices, int32_t u
 
 #define ORC_UNIFORM_MAX_CAND 4096
 
-static int32_t sample_uniform_one(const int64_t* indptr, const int32_t* indices, int64_t I,
-                                  int32_t user, uint64_t seed, uint64_t t) {
+/* candidate from one 32-bit draw r: column c = 1 + floor(r (I-1) / 2^32); with an alias table
+ * (Walker / Vose) over item weights the fractional part of r (I-1) / 2^32 decides between the
+ * column and its alias, so that P(candidate = i) = w_i / sum(w). */
+static int32_t uniform_candidate(uint32_t r, int64_t I, const float* accept, const int32_t* alias) {
+  uint32_t n = (uint32_t)(I - 1);
+  int32_t c = 1 + (int32_t)(((uint64_t)r * (uint64_t)n) >> 32);
+  if (accept == NULL) return c;
+  float frac = (float)(uint32_t)(r * n) * (1.0f / 4294967296.0f);
+  return frac < accept[c] ? c : alias[c];
+}
+
+static int32_t sample_weighted_one(const int64_t* indptr, const int32_t* indices, int64_t I,
+                                   int32_t user, uint64_t seed, uint64_t t, const float* accept,
+                                   const int32_t* alias) {
   for (uint32_t k = 0; k < ORC_UNIFORM_MAX_CAND; ++k) {
     uint32_t r = draw(seed, t, k >> 2, 0u, (int)(k & 3));
-    int32_t c = 1 + (int32_t)(((uint64_t)r * (uint64_t)(I - 1)) >> 32);
+    int32_t c = uniform_candidate(r, I, accept, alias);
     if (!csr_contains(indptr, indices, user, c)) return c;
   }
   return 0;
+}
+
+static int32_t sample_uniform_one(const int64_t* indptr, const int32_t* indices, int64_t I,
+                                  int32_t user, uint64_t seed, uint64_t t) {
+  return sample_weighted_one(indptr, indices, I, user, seed, t, NULL, NULL);
+}
+
+/* BPRExperiment._static_sampling with item weights count_i ** neg_sampling_alpha
+ * (experiments/bpr/exp.py:85-91, 282-293): multinomial over w_i for unseen i, 0 for seen and item 0 —
+ * here by rejection: candidates ~ w (alias table), the first unseen one wins. */
+void orc_sample_weighted(const int64_t* indptr, const int32_t* indices, int64_t I,
+                         const int32_t* users, int64_t B, uint64_t seed, uint64_t offset,
+                         const float* accept, const int32_t* alias, int32_t* neg_out) {
+  for (int64_t b = 0; b < B; ++b)
+    neg_out[b] = sample_weighted_one(indptr, indices, I, users[b], seed, offset + (uint64_t)b,
+                                     accept, alias);
 }
 
 void orc_sample_uniform(const int64_t* indptr, const int32_t* indices, int64_t I,

@@ -83,6 +83,13 @@ void orc_sample_uniform(const int64_t* indptr, const int32_t* indices, int64_t I
                         const int32_t* users, int64_t B, uint64_t seed, uint64_t offset,
                         int32_t* neg_out);
 
+/* The same with item weights (BPRExperiment._static_sampling with count_i ** neg_sampling_alpha,
+ * experiments/bpr/exp.py:85-91, 282-293): accept [I] / alias [I] are a Walker alias table over the
+ * weights of items 1..I-1 (entry 0 unused); P(negative = i) = w_i / sum of w over the unseen. */
+void orc_sample_weighted(const int64_t* indptr, const int32_t* indices, int64_t I,
+                         const int32_t* users, int64_t B, uint64_t seed, uint64_t offset,
+                         const float* accept, const int32_t* alias, int32_t* neg_out);
+
 /* AdaptiveSampler.update_stats (neg_samplers.py:126-132), literal: QT [d,I] = transpose copy,
  * sigma [d] = unbiased std over rows 1..I-1. */
 void orc_adaptive_stats(const float* Q, int64_t I, int32_t d, float* QT, float* sigma);

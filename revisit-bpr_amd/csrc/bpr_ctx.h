@@ -25,6 +25,8 @@ struct bpr_ctx {
   const int64_t* indptr = nullptr;
   const int32_t* indices = nullptr;
   float au = 0.f, ai = 0.f, an = 0.f;
+  const float* w_accept = nullptr;  // item weights of the uniform sampler (alias table, caller-owned)
+  const int32_t* w_alias = nullptr;
   int opt_kind = BPR_OPT_SGD;
   bpr_opt_params opt = {0.f, 0.f, 0.f, 0, 0.9f, 0.999f, 1e-8f, 0.99f};
   float *mP = nullptr, *vP = nullptr, *mQ = nullptr, *vQ = nullptr, *mb = nullptr, *vb = nullptr;

@@ -193,9 +193,26 @@ enum { SEEN_CSR = 0, SEEN_BITMAP = 1, SEEN_LIST = 2 };
 // the result is the first accepted candidate.  A group tests G candidates per round.
 // All lanes of the wave must call this together (wave-uniform loop).
 // ---------------------------------------------------------------------------------------------
+// Candidate from one 32-bit draw r: column c = 1 + floor(r (I-1) / 2^32).  With item weights
+// (BPRExperiment._static_sampling with count_i ** neg_sampling_alpha, experiments/bpr/exp.py:85-91,
+// 282-293) a Walker alias table decides between the column and its alias on the FRACTIONAL part of
+// r (I-1) / 2^32, so candidates are ~ w and one draw still makes one candidate.
+struct ItemWeights {
+  const float* __restrict__ accept;  // [I] (entry 0 unused); NULL = uniform
+  const int32_t* __restrict__ alias;
+};
+__device__ __forceinline__ int32_t uniform_candidate(uint32_t r, int64_t I, const ItemWeights& w) {
+  const uint32_t n = (uint32_t)(I - 1);
+  const int32_t c = 1 + (int32_t)__umulhi(r, n);
+  if (w.accept == nullptr) return c;
+  const float frac = (float)(r * n) * (1.0f / 4294967296.0f);
+  return frac < w.accept[c] ? c : w.alias[c];
+}
+
 template <int G, typename Seen>
 __device__ __forceinline__ int32_t sample_uniform(const Seen& seen, int64_t I, uint64_t seed,
-                                                  uint64_t t, int lane) {
+                                                  uint64_t t, int lane,
+                                                  const ItemWeights& iw = ItemWeights{nullptr, nullptr}) {
   const int gl = lane & (G - 1);
   int32_t result = 0;
   bool done = false;
@@ -203,7 +220,7 @@ __device__ __forceinline__ int32_t sample_uniform(const Seen& seen, int64_t I, u
   for (int round = 0; round < ROUNDS; ++round) {
     const uint32_t k = (uint32_t)(round * G + gl);
     const uint32_t r = draw(seed, t, k >> 2, PURPOSE_UNIFORM, (int)(k & 3u));
-    const int32_t c = 1 + (int32_t)__umulhi(r, (uint32_t)(I - 1));
+    const int32_t c = uniform_candidate(r, I, iw);
     const bool ok = !seen(c);
     const Ballot b = wave_ballot(ok);
     const int32_t cand = group_pick<G>(b, c, lane);

@@ -182,6 +182,7 @@ struct StreamArgs {
   const int32_t* hot_slot;
   float* hot_delta;
   int32_t hot_H, hot_rmask;
+  ItemWeights iw;  // uniform sampler with item weights (NULL: uniform)
 };
 
 // A hot row's value is its base row plus its replica delta rows; returns the replica this wave
@@ -367,13 +368,13 @@ void k_stream(const StreamArgs a) {
           const uint32_t w0 = group_bcast<G>(my_w.x, step, lane), w1 = group_bcast<G>(my_w.y, step, lane);
           const uint32_t w2 = group_bcast<G>(my_w.z, step, lane), w3 = group_bcast<G>(my_w.w, step, lane);
           const uint32_t wsel = (gl & 2) ? ((gl & 1) ? w3 : w2) : ((gl & 1) ? w1 : w0);
-          const int32_t c = 1 + (int32_t)__umulhi(wsel, (uint32_t)(a.I - 1));
+          const int32_t c = uniform_candidate(wsel, a.I, a.iw);
           const bool is_seen = seen(c);
           const Ballot b = wave_ballot(gl < 4 && !is_seen);
           if (group_first<G>(b, lane) >= 0 && step < t1 - t0) {
             j = group_pick<G>(b, c, lane);
           } else {
-            j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane);
+            j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane, a.iw);
           }
         } else {
           const AdaptiveRandoms rnd = {group_bcast<G>(my_rnd.uf, step, lane),
@@ -570,6 +571,7 @@ struct SampleArgs {
   const int32_t* lastP;
   OptDev o;
   int32_t bm_words;  // words per group of the LDS seen-bitmap (k_sample<..., BM = true>)
+  ItemWeights iw;
 };
 
 enum { SAMPLE_UNIFORM = 0, SAMPLE_ADAPTIVE = 1, SAMPLE_PICK = 2 };
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
       seen = SeenCsr{a.indices, lo, hi};
     }
     if constexpr (WHAT == SAMPLE_UNIFORM) {
-      const int32_t j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane);
+      const int32_t j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane, a.iw);
       if (act && gl == 0) a.neg[t] = j;
     } else if constexpr (WHAT == SAMPLE_ADAPTIVE) {
       float p[E];

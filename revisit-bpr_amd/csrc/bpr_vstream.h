@@ -497,6 +497,7 @@ struct VStreamArgs {
   int32_t pad_user, pad_item;
   int32_t bm_words, gpw_active;
   float au, ai, an, inv_log1mp;
+  ItemWeights iw;
   VOpt o;
 };
 
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void k_vstrea
           }
           const uint64_t ctr = a.offset + (uint64_t)kk;
           if constexpr (SAMPLER == NEG_UNIFORM) {
-            j = sample_uniform<G>(seen, a.I, a.seed, ctr, lane);
+            j = sample_uniform<G>(seen, a.I, a.seed, ctr, lane, a.iw);
           } else {
             float p[E], sg[E];
 #pragma unroll

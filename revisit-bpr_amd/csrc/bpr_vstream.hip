@@ -255,6 +255,7 @@ int bpr_train_stream_batched(bpr_ctx* c, const int32_t* users, const int32_t* po
   a.pad_user = c->pad_user; a.pad_item = c->pad_item;
   a.au = c->au; a.ai = c->ai; a.an = c->an;
   a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
+  a.iw = ItemWeights{c->w_accept, c->w_alias};
   a.o = vopt(c);
   if (int rc = launch_vstream(c, a, sampler, max_inflight, out_scalars)) return rc;
   c->step += steps;

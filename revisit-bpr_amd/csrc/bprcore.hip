@@ -438,6 +438,15 @@ int bpr_bind_seen_csr(bpr_ctx* c, const int64_t* indptr, const int32_t* indices)
   return BPR_OK;
 }
 
+int bpr_bind_item_weights(bpr_ctx* c, const float* accept, const int32_t* alias) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_bind_item_weights: ctx is NULL");
+  if ((accept == nullptr) != (alias == nullptr))
+    return fail(BPR_ERR_INVALID, "bpr_bind_item_weights: accept and alias go together");
+  c->w_accept = accept;
+  c->w_alias = alias;
+  return BPR_OK;
+}
+
 int bpr_set_reg(bpr_ctx* c, float alpha_user, float alpha_item, float alpha_neg) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_reg: ctx is NULL");
   c->au = alpha_user; c->ai = alpha_item; c->an = alpha_neg;
@@ -528,6 +537,7 @@ static SampleArgs sample_args(const bpr_ctx* c) {
   a.P = c->P; a.I = c->I; a.d = c->d;
   a.indptr = c->indptr; a.indices = c->indices;
   a.order = c->order; a.sigma = c->sigma;
+  a.iw = ItemWeights{c->w_accept, c->w_alias};
   a.mP = c->mP; a.vP = c->vP; a.lastP = c->lastP;
   a.o = opt_dev(c, c->step + 1);
   return a;
@@ -710,6 +720,7 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
     a.dbg = dbg;
   }
   a.au = c->au; a.ai = c->ai; a.an = c->an; a.lr = c->opt.lr;
+  a.iw = ItemWeights{c->w_accept, c->w_alias};
   a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
   if (c->hot_H > 0 && a.dbg == 0) {
     a.hot_slot = c->hot_slot;
@@ -870,6 +881,22 @@ int bpr_flush_lazy(bpr_ctx* c) {
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->vs_active) return vs_flush(c, true, true);  // batched STREAM bookkeeping is live
   return strict_flush_impl(c);
+}
+
+int bpr_flush_items(bpr_ctx* c) {
+  if (int rc = check_bound(c, "bpr_flush_items")) return rc;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (c->vs_active) return vs_flush(c, false, true);
+  if (c->opt_kind == BPR_OPT_SGD || c->GP == nullptr || c->step == 0) return BPR_OK;
+  if (int rc = check_opt_state(c, "bpr_flush_items")) return rc;
+  ApplyArgs a = apply_args(c, c->step);
+  return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_flush_lazy<T::G, T::E>), dim3(grid_for(c->I, T::G, 0)), dim3(256), 0,
+                       c->stream, a, 1);
+    BPR_HIP_CHECK(hipGetLastError());
+    return BPR_OK;
+  });
 }
 
 int bpr_get_step_host(bpr_ctx* c, int64_t* step_host) {

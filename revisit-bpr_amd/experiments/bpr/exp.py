@@ -60,12 +60,20 @@ class BPRExperiment:
             raise ValueError("train_mode must be 'api', 'strict' or 'stream'")
         # "api": the reference's per-batch loop (DataLoader -> sampler -> model -> backward -> step);
         # "strict": the same mini-batches, whole epochs inside the library (any optimizer);
-        # "stream": the fused throughput path (plain SGD only).  Extension: the reference has only
-        # the first.
+        # "stream": the fused throughput paths (plain SGD: the STREAM kernel; Adam / momentum /
+        # RMSprop: the batched STREAM kernel).  Extension: the reference has only the first.
         self._train_mode = train_mode
-        if neg_sampling_alpha != 0.0:
-            raise NotImplementedError("popularity-weighted negatives (neg_sampling_alpha != 0) are "
-                                      "not implemented by the device samplers")
+        # item weights of the static sampler: count ** neg_sampling_alpha for the items listed in the
+        # datasets' `item_counts` file, 1 elsewhere (reference: exp.py:85-91)
+        self._item_counts = None
+        path = self._config.get(datasets_key, {}).pop("item_counts", None) \
+            if isinstance(self._config.get(datasets_key), dict) else None
+        if path is not None:
+            counts = torch.ones(self._config["num_items"], dtype=torch.float32)
+            with open(path, "r", encoding="utf-8") as file:
+                for rec in map(json.loads, file):
+                    counts[rec["item"]] = float(rec["count"]) ** neg_sampling_alpha
+            self._item_counts = counts
         self._state = None
         self.history: list[dict] = []
 
@@ -100,16 +108,23 @@ class BPRExperiment:
         if hasattr(train_ds, "seen_csr") and hasattr(self._model, "bind_seen_csr"):
             indptr, indices = train_ds.seen_csr()
             self._model.bind_seen_csr(indptr.to(acc.device), indices.to(acc.device))
-        self._neg_gen = torch.Generator(device=acc.device).manual_seed(self._seed)
         num_items = cfg["num_items"]
+        if self._item_counts is not None and hasattr(self._model, "engine"):
+            self._model.engine().bind_item_weights(self._item_counts)  # strict / stream epochs
         if isinstance(self._adaptive_p, float):
             # the refresh is driven by the GET_BATCH_COMPLETED(every=...) handler below, which
             # runs BEFORE the sampling handler, as in the reference (exp.py:197-208)
             self._sampler = AdaptiveSampler(self._model, num_items, self._adaptive_p,
-                                            self._neg_gen, every=10 ** 18)
+                                            None, every=10 ** 18)
         else:
-            self._sampler = UniformSampler(num_items, self._neg_gen)
+            self._sampler = UniformSampler(num_items, None, item_weights=self._item_counts)
         self.trainer = self._build_trainer()
+        # "In case of preemptible tasks neg generator might sample the same data" (reference
+        # exp.py:124-128): the generator is seeded with seed + the train engine's iteration, which
+        # is where a resumed run continues (0 on a fresh start)
+        self._neg_gen = torch.Generator(device=acc.device).manual_seed(
+            self._seed + int(getattr(self.trainer.engines["train"].state, "iteration", 0) or 0))
+        self._sampler._neg_gen = self._neg_gen
         loaders = self._datasets
         if self._train_mode != "api":
             loaders = self._install_fast_epochs(max_iters)
@@ -182,22 +197,29 @@ class BPRExperiment:
         state = {"epoch": 0, "drawn": 0}
         gen = torch.Generator(device=dev).manual_seed(self._seed)
         stream = None
+        plain_sgd = True
         if self._train_mode == "stream":
-            from revisit_bpr.fast import StreamTrainer
+            from revisit_bpr.fast import BatchedStreamTrainer, StreamTrainer
 
             opt = self._optimizer
             group = opt.param_groups[0]
-            if type(opt).__name__ != "SGD" or group.get("momentum", 0) != 0:
-                raise NotImplementedError("train_mode='stream' implements plain SGD; use 'strict'")
+            plain_sgd = type(opt).__name__ == "SGD" and group.get("momentum", 0) == 0
             indptr, indices = ds.seen_csr()
-            stream = StreamTrainer(model, users, items, indptr.to(dev), indices.to(dev),
-                                   lr=group["lr"], sampler="adaptive" if adaptive else "uniform",
-                                   adaptive_p=p, batch_size=batch, seed=self._seed)
+            kind = "adaptive" if adaptive else "uniform"
+            if plain_sgd:  # the fused SGD kernel (immediate updates)
+                stream = StreamTrainer(model, users, items, indptr.to(dev), indices.to(dev),
+                                       lr=group["lr"], sampler=kind, adaptive_p=p, batch_size=batch,
+                                       seed=self._seed)
+            else:  # Adam / momentum / RMSprop: the batched STREAM kernel (virtual mini-batches)
+                stream = BatchedStreamTrainer(model, opt, users, items, indptr.to(dev),
+                                              indices.to(dev), sampler=kind, adaptive_p=p,
+                                              batch_size=batch, seed=self._seed)
 
         def epoch_step(engine, _batch) -> dict:
             model.train()
             if stream is not None:
-                stream.engine.set_optimizer(eng.OPT_SGD, lr=self._optimizer.param_groups[0]["lr"])
+                if plain_sgd:
+                    stream.engine.set_optimizer(eng.OPT_SGD, lr=self._optimizer.param_groups[0]["lr"])
                 m = stream.train_epoch()
                 n_batches = max(1, math.ceil(m["triples"] / batch))
                 out = {k: torch.tensor(m[k] * m["triples"] / n_batches, device=dev)
@@ -207,7 +229,9 @@ class BPRExperiment:
                 perm = torch.randperm(users.numel(), device=dev, generator=gen)
                 if limit is not None:
                     perm = perm[:limit * batch]
-                if adaptive:
+                if adaptive and state["epoch"] == 0:
+                    # once, as the reference does before training (exp.py:129-132); afterwards the
+                    # sampler's own counter, which keeps counting across epochs, drives the refresh
                     model.engine().adaptive_refresh()
                 scalars.zero_()
                 steps = model.train_strict(self._optimizer, users[perm].contiguous(),

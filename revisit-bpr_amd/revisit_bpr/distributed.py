@@ -67,6 +67,8 @@ class ItemSync:
         self._own = [torch.empty_like(t) for t in self.tensors]
         self._tot = [torch.empty_like(t) for t in self.tensors]
         self._pending = False
+        self.timing = False  # record the all-reduce on the side stream with events (bench.py)
+        self._events: list = []
         self._cuda = bool(self.tensors) and self.tensors[0].is_cuda
         self._side = torch.cuda.Stream() if self._cuda else None
         self._lib = None
@@ -118,7 +120,24 @@ class ItemSync:
 
     def _all_reduce(self, tot) -> None:
         if self.world > 1:
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+            if self.timing and self._cuda:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+                b.record()
+                self._events.append((a, b, tot.numel() * tot.element_size()))
+            else:
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+
+    def timing_read(self) -> dict:
+        """Average duration of the recorded all-reduces (ms, on the stream they ran on) and their
+        message size; clears the record."""
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b, _ in self._events]
+        size = self._events[0][2] if self._events else 0
+        self._events = []
+        return {"all_reduces": len(ms), "all_reduce_ms_avg": (sum(ms) / len(ms)) if ms else None,
+                "message_bytes": size}
 
     # ---- API ----------------------------------------------------------------------------------
     @torch.no_grad()

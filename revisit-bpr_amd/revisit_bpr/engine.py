@@ -35,6 +35,29 @@ def resolve_reg_alphas(reg_alphas: Optional[dict]) -> tuple[float, float, float]
     return float(user), float(item), float(neg)
 
 
+def alias_table(weights: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """Walker / Vose alias table over weights[1:] (entry 0, the pad item, is ignored): (accept
+    float32 [I], alias int32 [I]) for `Engine.bind_item_weights`."""
+    import numpy as np
+
+    w = weights.detach().double().cpu().numpy()[1:]
+    n = w.shape[0]
+    if n < 1 or (w < 0).any() or not w.sum() > 0:
+        raise ValueError("item weights must be non-negative with a positive sum")
+    p = w * (n / w.sum())
+    accept = np.ones(n + 1, np.float32)
+    alias = np.arange(n + 1, dtype=np.int32)
+    small = [i for i in range(n) if p[i] < 1.0]
+    large = [i for i in range(n) if p[i] >= 1.0]
+    while small and large:
+        s_, l_ = small.pop(), large.pop()
+        accept[s_ + 1] = np.float32(p[s_])
+        alias[s_ + 1] = l_ + 1
+        p[l_] -= 1.0 - p[s_]
+        (small if p[l_] < 1.0 else large).append(l_)
+    return torch.from_numpy(accept), torch.from_numpy(alias)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -103,6 +126,20 @@ class Engine:
         indptr, indices = indptr.contiguous(), indices.contiguous()
         self._keep["csr"] = (indptr, indices)
         native.check(self._lib.bpr_bind_seen_csr(self._ctx, indptr.data_ptr(), indices.data_ptr()))
+
+    def bind_item_weights(self, weights: Optional[torch.Tensor]) -> None:
+        """Item weights of the uniform sampler (count_i ** neg_sampling_alpha of the reference's
+        BPRExperiment): [I] non-negative; None = uniform."""
+        if weights is None:
+            self._keep.pop("item_weights", None)
+            native.check(self._lib.bpr_bind_item_weights(self._ctx, None, None))
+            return
+        if weights.numel() != self.I:
+            raise ValueError("item weights must have one entry per item row")
+        accept, alias = alias_table(weights)
+        accept, alias = accept.to(self.device), alias.to(self.device)
+        self._keep["item_weights"] = (accept, alias)
+        native.check(self._lib.bpr_bind_item_weights(self._ctx, accept.data_ptr(), alias.data_ptr()))
 
     def set_reg(self, user: float, item: float, neg: float) -> None:
         native.check(self._lib.bpr_set_reg(self._ctx, user, item, neg))
@@ -324,6 +361,11 @@ class Engine:
     def flush_lazy(self) -> None:
         self._sync_stream()
         native.check(self._lib.bpr_flush_lazy(self._ctx))
+
+    def flush_items(self) -> None:
+        """flush_lazy for the item table (+ bias) only (before an item reconciliation)."""
+        self._sync_stream()
+        native.check(self._lib.bpr_flush_items(self._ctx))
 
     @property
     def step_count(self) -> int:

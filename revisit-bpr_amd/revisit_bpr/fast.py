@@ -159,7 +159,7 @@ class StrictTrainer:
                                        adaptive_p=self.adaptive_p, seed=self.seed,
                                        offset=(self.rank << 40) + self.drawn + lo, refresh_every=0,
                                        scalars=self._scalars)
-                e.flush_lazy()
+                e.flush_items()
                 self.item_sync.step()
                 if adaptive:
                     e.adaptive_refresh()
@@ -234,7 +234,7 @@ class BatchedStreamTrainer:
                                            max_inflight=self.max_inflight, scalars=self._scalars)
                 self.drawn += hi - lo
             if self.item_sync is not None:
-                e.flush_lazy()
+                e.flush_items()
                 self.item_sync.step()
         if self.item_sync is not None:
             self.item_sync.finish()

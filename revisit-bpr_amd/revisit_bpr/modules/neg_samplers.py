@@ -61,11 +61,17 @@ def _distinct_rows(neg: torch.Tensor, redraw) -> torch.Tensor:
 
 
 class UniformSampler(Sampler):
-    """Uniform over the items the user has not seen, never item 0 (reference: :15-37)."""
+    """Uniform over the items the user has not seen, never item 0 (reference: :15-37).
 
-    def __init__(self, num_items: int, neg_gen: torch.Generator) -> None:
+    item_weights (extension; the reference's experiment class carries the same thing as
+    `_item_counts ** neg_sampling_alpha`, experiments/bpr/exp.py:85-91, 282-293): [num_items]
+    non-negative weights — a negative is drawn with probability w_i / (sum of w over the unseen)."""
+
+    def __init__(self, num_items: int, neg_gen: torch.Generator,
+                 item_weights: Optional[torch.Tensor] = None) -> None:
         self._neg_gen = neg_gen
         self._num_items = num_items
+        self._item_weights = item_weights
         self._drawn = 0
         self._engine = None
         self._cap = 0
@@ -78,6 +84,8 @@ class UniformSampler(Sampler):
             # only the row counts matter: the sampler kernels never read the tables
             self._engine = Engine(torch.zeros(self._cap, 1, device=device),
                                   torch.zeros(self._num_items, 1, device=device))
+            if self._item_weights is not None:
+                self._engine.bind_item_weights(self._item_weights)
         return self._engine
 
     def sample(self, batch: dict[str, torch.Tensor]) -> torch.Tensor:

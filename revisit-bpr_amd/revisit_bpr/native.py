@@ -54,6 +54,7 @@ SIGNATURES = {
     "bpr_bind_tables": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
                                 c_int32, c_int32]),
     "bpr_bind_seen_csr": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "bpr_bind_item_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "bpr_set_reg": (c_int, [c_void_p, c_float, c_float, c_float]),
     "bpr_set_optimizer": (c_int, [c_void_p, c_int32, POINTER(OptParams)]),
     "bpr_bind_opt_state": (c_int, [c_void_p] + [c_void_p] * 6),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "bpr_plan_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_void_p,
                                c_void_p]),
     "bpr_flush_lazy": (c_int, [c_void_p]),
+    "bpr_flush_items": (c_int, [c_void_p]),
     "bpr_get_step_host": (c_int, [c_void_p, POINTER(c_int64)]),
     "bpr_set_step": (c_int, [c_void_p, c_int64]),
     "bpr_set_sampler_iter": (c_int, [c_void_p, c_int64]),

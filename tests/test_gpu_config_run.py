@@ -12,7 +12,9 @@ CONFIG = Path(__file__).parent / "configs" / "bpr_small.yaml.j2"
 
 @pytest.mark.parametrize("variant,mode", [("uniform-sgd-bias", "api"), ("adaptive-adam", "api"),
                                           ("uniform-sgd-bias", "strict"), ("adaptive-adam", "strict"),
-                                          ("uniform-sgd-bias", "stream"), ("adaptive-sgd", "stream")])
+                                          ("uniform-sgd-bias", "stream"), ("adaptive-sgd", "stream"),
+                                          ("adaptive-adam", "stream"), ("popularity-sgd", "api"),
+                                          ("popularity-sgd", "stream")])
 def test_config_run_learns(tmp_path, variant, mode):
     from click.testing import CliRunner
 
@@ -27,6 +29,19 @@ def test_config_run_learns(tmp_path, variant, mode):
         extra += ";adaptive=1;optimizer=torch.optim.Adam;lr=0.01;item_bias=false"
     if variant == "adaptive-sgd":
         extra += ";adaptive=1;item_bias=false"
+    if variant == "popularity-sgd":
+        # item_counts + neg_sampling_alpha (reference experiments/bpr/exp.py:85-91): negatives drawn
+        # with probability proportional to count ** alpha over the unseen items
+        import json
+
+        import numpy as np
+
+        cnt = np.bincount(data.items, minlength=data.num_items)
+        with open(tmp_path / "item-counts.jsonl", "w") as f:
+            for i in range(1, data.num_items):
+                if cnt[i]:
+                    f.write(json.dumps({"item": i, "count": int(cnt[i])}) + "\n")
+        extra += f";item_counts={tmp_path / 'item-counts.jsonl'};neg_sampling_alpha=0.75;item_bias=false"
     res = CliRunner().invoke(run_mod.main, [str(CONFIG), "--extra-vars", extra, "-d", str(tmp_path / "exp"),
                                             "--train-mode", mode],
                              catch_exceptions=False, standalone_mode=False)

@@ -263,3 +263,39 @@ def test_rmsprop_momentum_matches_torch_optim(momentum):
         opt.step()
         oracle.opt_dense(o, t + 1, w, np.ascontiguousarray(g, dtype=np.float32), m, v)
         assert np.allclose(w, prm.detach().numpy(), rtol=0, atol=1e-6), t
+
+
+def test_weighted_static_sampler_follows_the_reference_formula():
+    """BPRExperiment._static_sampling with item weights count ** alpha (reference
+    experiments/bpr/exp.py:85-91, 282-293): multinomial over weights with the seen items and item 0
+    zeroed, row-normalised.  The oracle draws by rejection from an alias table; its empirical
+    distribution must be that formula (chi-square, 3 users x 40,000 draws)."""
+    rng = np.random.default_rng(5)
+    I = 60
+    counts = rng.integers(1, 200, I).astype(np.float64)
+    w = counts ** 0.75
+    w[0] = 0.0
+    rows = [np.sort(rng.choice(np.arange(1, I), size=k, replace=False)) for k in (0, 7, 25)]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    indices = np.concatenate(rows).astype(np.int32)
+    accept, alias = oracle.alias_table(w)
+    n = 40_000
+    for u, seen in enumerate(rows):
+        users = np.full(n, u, np.int32)
+        neg = oracle.sample_weighted(indptr, indices, I, users, seed=3, offset=u * n, accept=accept,
+                                     alias=alias)
+        assert neg.min() >= 1 and not np.isin(neg, seen).any()
+        expect = w.copy()
+        expect[seen] = 0.0  # _sampling_weights: scatter 0 over seen, weights[:, 0] = 0, normalise
+        expect /= expect.sum()
+        obs = np.bincount(neg, minlength=I)
+        keep = expect > 0
+        chi2 = (((obs - n * expect) ** 2)[keep] / (n * expect[keep])).sum()
+        dof = keep.sum() - 1
+        assert chi2 < dof + 5 * np.sqrt(2 * dof), (u, chi2, dof)
+    # no weights == the plain uniform sampler, draw for draw
+    users = rng.integers(0, 3, 500).astype(np.int32)
+    ones = np.ones(I)
+    a1, l1 = oracle.alias_table(ones)
+    assert np.array_equal(oracle.sample_weighted(indptr, indices, I, users, 9, 0, a1, l1),
+                          oracle.sample_uniform(indptr, indices, I, users, 9, 0))
