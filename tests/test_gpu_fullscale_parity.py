@@ -1,0 +1,123 @@
+"""Throughput paths against the reference's mini-batch semantics at the FULL ML-20M shape
+(136,677 x 20,108, ~9.6 M training triples, d = 128; BASELINE configs[2] and, for the optimizer,
+configs[4]) on a synthetic set with learnable latent structure, nDCG@100 / Recall@20 on 10,000
+held-out users, five sampler seeds per side.
+
+The reference would need hours per epoch here (its CPU step: bench.py `cpu_baseline`), and the CPU
+oracle likewise; STRICT (`bpr_train_strict`) stands in for them: it IS the reference's mini-batch
+loop — held to the oracle / the reference's golden vectors to 1e-5 by tests/test_gpu_parity.py and,
+at this very shape, by tests/test_gpu_baseline_configs.py.  Compared with it:
+
+  * STREAM (fused SGD kernel, asynchronous updates) — SGD, adaptive sampling;
+  * BATCHED STREAM (virtual mini-batches, one dense optimizer step per row and batch) — SGD and
+    Adam(0.1, 0.999) (configs/RQ3/time-split/ada-sampling-adam.yaml.j2:169-175), adaptive sampling.
+
+Acceptance (BASELINE.json: nDCG@100 within +-0.002): |difference of seed means| <= 0.002 + 2
+standard errors at the last epoch, and <= 0.004 + 2 se on the way up (epoch 3).  Statistical test:
+runs last (tests/conftest.py)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+SEEDS = (1, 2, 3, 4, 5)
+REG = {"user": 0.0016, "item": 0.0001, "neg": 0.00375}
+B, D, P_GEO = 256, 128, 0.01
+
+
+@pytest.fixture(scope="module")
+def problem():
+    from revisit_bpr.datasets import synthetic
+
+    data = synthetic.generate_latent(136677, 20108, 9_700_000, factors=16, strength=1.2,
+                                     median_per_user=37, min_per_user=5, seed=13, eval_users=10_000,
+                                     item_skew=1.2, item_shift=60.0)
+    dev = torch.device("cuda")
+    t = {k: torch.from_numpy(getattr(data, k)).to(dev)
+         for k in ("users", "items", "indptr", "indices", "eval_users", "eval_indptr", "eval_items")}
+    return data, t
+
+
+def fresh_model(data):
+    from revisit_bpr.models import BPR
+    from revisit_bpr.models.bpr import MF
+
+    torch.manual_seed(13)
+    return BPR(fuse_forward=True, reg_alphas=REG,
+               logits_model=MF(torch.nn.Embedding(data.num_users, D, padding_idx=0),
+                               torch.nn.Embedding(data.num_items, D, padding_idx=0))).cuda()
+
+
+def metrics(model, t):
+    from revisit_bpr.evaluation import evaluate_topk
+
+    model.eval()  # brings lazily-updated rows to "now"
+    f = model.logits_model.get_features()
+    out = evaluate_topk(f["user"].data, f["item"].data, None, t["eval_users"], t["eval_indptr"],
+                        t["eval_items"], t["indptr"], t["indices"], ks=(20, 100))
+    model.train()
+    return out
+
+
+def run(data, t, mode, make_opt, epochs, seed):
+    from revisit_bpr.fast import BatchedStreamTrainer, StreamTrainer, StrictTrainer
+
+    model = fresh_model(data)
+    opt = make_opt(model.parameters())
+    args = (t["users"], t["items"], t["indptr"], t["indices"])
+    if mode == "strict":
+        tr = StrictTrainer(model, opt, *args, sampler="adaptive", adaptive_p=P_GEO, batch_size=B, seed=seed)
+    elif mode == "stream":
+        tr = StreamTrainer(model, *args, lr=opt.param_groups[0]["lr"], sampler="adaptive",
+                           adaptive_p=P_GEO, batch_size=B, seed=seed)
+    else:
+        tr = BatchedStreamTrainer(model, opt, *args, sampler="adaptive", adaptive_p=P_GEO, batch_size=B,
+                                  seed=seed)
+    curve = []
+    for _ in range(epochs):
+        stats = tr.train_epoch()
+        assert stats["triples"] == data.nnz
+        m = metrics(model, t)
+        curve.append((m["ndcg@100"], m["recall@20"]))
+    return np.array(curve)
+
+
+def compare(label, ref, got, epochs):
+    """ref / got: [seeds, epochs, 2]"""
+    ok = True
+    lines = []
+    for ep, base in ((2, 0.004), (epochs - 1, 0.002)):
+        for k, name in enumerate(("ndcg@100", "recall@20")):
+            r, o = ref[:, ep, k], got[:, ep, k]
+            se = math.sqrt(r.var(ddof=1) / len(r) + o.var(ddof=1) / len(o))
+            diff, tol = o.mean() - r.mean(), base + 2 * se
+            lines.append(f"{label} {name} epoch {ep + 1}: {o.mean():.4f}+-{o.std(ddof=1):.4f} vs STRICT "
+                         f"{r.mean():.4f}+-{r.std(ddof=1):.4f} diff {diff:+.4f} tol {tol:.4f}")
+            ok &= abs(diff) <= tol
+    print("\n".join(lines))
+    assert ok, "\n".join(lines)
+
+
+def test_sgd_stream_and_batched_stream_match_strict_at_ml20m_scale(problem):
+    data, t = problem
+    epochs = 6
+    make_opt = lambda p: torch.optim.SGD(p, lr=0.05)  # noqa: E731
+    strict = np.stack([run(data, t, "strict", make_opt, epochs, s) for s in SEEDS])
+    assert strict[:, -1, 0].mean() > 0.3  # the model learns (untrained: 0.002)
+    stream = np.stack([run(data, t, "stream", make_opt, epochs, s) for s in SEEDS])
+    compare("STREAM", strict, stream, epochs)
+    batched = np.stack([run(data, t, "batched", make_opt, epochs, s) for s in SEEDS])
+    compare("BATCHED-sgd", strict, batched, epochs)
+
+
+def test_adam_batched_stream_matches_strict_at_ml20m_scale(problem):
+    data, t = problem
+    epochs = 4
+    make_opt = lambda p: torch.optim.Adam(p, lr=0.002, betas=(0.1, 0.999))  # noqa: E731
+    strict = np.stack([run(data, t, "strict", make_opt, epochs, s) for s in SEEDS])
+    assert strict[:, -1, 0].mean() > 0.3
+    batched = np.stack([run(data, t, "batched", make_opt, epochs, s) for s in SEEDS])
+    compare("BATCHED-adam", strict, batched, epochs)
