@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink users/actions (debug)")
     ap.add_argument("--max-inflight", type=int, default=0)
     ap.add_argument("--run-len", type=int, default=8)
+    ap.add_argument("--defer-pos", type=int, default=None, choices=[0, 1, 2],
+                    help="STREAM: positive rows updated once per chunk by the item-major pass "
+                         "(bpr_set_defer_positives; default: the library's)")
     ap.add_argument("--hot-rows", type=int, default=None,
                     help="delta rows for the N most popular item rows (library default 256; 0 = off)")
     ap.add_argument("--hot-replicas", type=int, default=1)
@@ -273,6 +276,8 @@ def main():
     e.set_stream_opts(not args.ungrouped, args.run_len)
     if args.hot_rows is not None:
         e.set_hot_rows(args.hot_rows, args.hot_replicas)
+    if args.defer_pos is not None:
+        e.set_defer_positives(args.defer_pos)
     sync = ItemSync([Q]) if world > 1 else None
     scalars = torch.zeros(4, device=dev)
     seed = args.seed

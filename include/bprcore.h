@@ -230,6 +230,21 @@ int bpr_shuffle_epoch(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_
  * group walks with the user row held in registers. */
 int bpr_set_stream_opts(bpr_ctx* ctx, int32_t grouped_by_user, int32_t run_len);
 
+/* Deferred positives (STREAM, plain SGD).  Half of the kernel's fp32 atomics update the POSITIVE
+ * item row of each triple, and positives are known before the epoch starts.  With mode != 0
+ * bpr_plan_epoch also orders every chunk's triples by positive item, bpr_train_stream on a whole
+ * chunk of that plan parks sigma(-x_uij) per triple instead of updating q_i, and a second,
+ * item-major kernel applies each positive row's summed update once per chunk
+ * (q_i += lr (sum_t w_t p_u(t) - n_i alpha_i q_i): no atomics, one row write per item).  Within a
+ * chunk the positive rows are therefore read at their start-of-chunk value (plus the updates they
+ * received as NEGATIVES, which stay immediate): the same staleness the adaptive sampler's snapshot
+ * has by construction (one refresh period).  mode 1 defers only rows outside the hot block
+ * (bpr_set_hot_rows: those keep their immediate delta-row updates), mode 2 every positive row,
+ * 0 (default) none.  Launches that are not whole chunks of the current plan are not deferred.
+ * Takes effect at the next bpr_plan_epoch.  No counterpart in the reference: torch.optim.SGD steps
+ * once per mini-batch (example.py:176-180); DESIGN.md section 5 holds the parity evidence. */
+int bpr_set_defer_positives(bpr_ctx* ctx, int32_t mode);
+
 /* Hot item rows.  On popularity-skewed data the STREAM kernel is limited by fp32 atomics queueing
  * on the memory channels that happen to hold the most popular item rows (rows are scattered over
  * the table, the load per channel is uneven).  bpr_plan_epoch therefore counts the training

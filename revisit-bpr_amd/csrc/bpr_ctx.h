@@ -66,6 +66,23 @@ struct bpr_ctx {
   void* plan_tmp = nullptr;
   size_t plan_tmp_bytes = 0;
   int64_t plan_cap = 0;
+  // STREAM with deferred positives (bpr_set_defer_positives): the plan also holds, per chunk, the
+  // chunk's triples ordered by positive item; the hot kernel parks sigma(-x) per triple in wbuf and
+  // k_pos_pass applies each positive row's summed update once
+  int defer_pos = 0;                   // 0 off | 1 rows outside the hot block | 2 every positive row
+  int32_t* plan_perm = nullptr;        // [plan_n] triple indices, every chunk sorted by positive
+  int32_t* plan_iota = nullptr;        // [plan_perm_cap] 0, 1, 2, ...
+  int32_t* plan_pos_sorted = nullptr;  // [plan_n] pos[plan_perm[k]]  (coalesced for k_pos_pass)
+  int32_t* plan_users_bypos = nullptr; // [plan_n] users[plan_perm[k]]
+  int64_t plan_perm_cap = 0;
+  int32_t* plan_cnt = nullptr;         // [n_chunks, I] positives of an item inside a chunk
+  int64_t plan_cnt_cap = 0;
+  const int32_t* plan_users = nullptr;  // outputs of the last bpr_plan_epoch (caller-owned)
+  const int32_t* plan_pos = nullptr;
+  int64_t plan_n = 0, plan_chunk = 0;
+  bool plan_perm_valid = false;
+  float* wbuf = nullptr;               // [wbuf_cap] sigma(-x) of the triples of one launch
+  int64_t wbuf_cap = 0;
   // hot item rows (bpr_set_hot_rows): the most popular rows take their STREAM updates in replica
   // delta rows, folded into Q right after every STREAM launch (all zero in between)
   int hot_rows_opt = 256, hot_reps_opt = 1;

@@ -105,21 +105,31 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ 
   if (threadIdx.x < 4) out[threadIdx.x] += (float)red[0][threadIdx.x];
 }
 
-// After a STREAM launch: fold the hot rows' replica deltas into Q and clear them (blocks 1..), and
-// add the launch's loss statistics to the caller's scalars (block 0, when requested).
-__global__ __launch_bounds__(256) void k_stream_epilogue(const float* __restrict__ partials,
-                                                         int n_blocks, float* __restrict__ out,
-                                                         float* __restrict__ Q,
-                                                         float* __restrict__ delta,
-                                                         const int32_t* __restrict__ hot_items,
-                                                         int H, int R, int d) {
+// After a STREAM launch: fold the hot rows' replica deltas into Q and clear them (blocks 1..fold),
+// and add the launch's loss statistics to the caller's scalars (block 0, when requested).
+// Deferred positives (pos_cnt != NULL): the L2 term of the deferred updates — n_i positives of
+// item i in this chunk shrink its row once, q_i *= 1 - lr alpha_i n_i, before k_pos_pass adds the
+// summed data terms (fold blocks: their hot rows; blocks past them: every other row).
+struct EpilogueArgs {
+  const float* partials;
+  float* out;
+  float* Q;
+  float* delta;
+  const int32_t* hot_items;
+  const int32_t* hot_slot;
+  const int32_t* pos_cnt;  // [I] of this chunk
+  int32_t n_blocks, H, R, d, fold_blocks, I, pad_item, shrink_hot;
+  float lr_ai;
+};
+
+__global__ __launch_bounds__(256) void k_stream_epilogue(const EpilogueArgs a) {
   if (blockIdx.x == 0) {
-    if (out == nullptr) return;
+    if (a.out == nullptr) return;
     __shared__ double red[256][4];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int b = threadIdx.x; b < n_blocks; b += 256)
+    for (int b = threadIdx.x; b < a.n_blocks; b += 256)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] += (double)partials[(int64_t)b * 4 + k];
+      for (int k = 0; k < 4; ++k) acc[k] += (double)a.partials[(int64_t)b * 4 + k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = acc[k];
     __syncthreads();
@@ -129,19 +139,42 @@ __global__ __launch_bounds__(256) void k_stream_epilogue(const float* __restrict
         for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
       __syncthreads();
     }
-    if (threadIdx.x < 4) out[threadIdx.x] += (float)red[0][threadIdx.x];
+    if (threadIdx.x < 4) a.out[threadIdx.x] += (float)red[0][threadIdx.x];
     return;
   }
-  const int64_t n = (int64_t)H * d;
-  for (int64_t k = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x; k < n;
-       k += (int64_t)(gridDim.x - 1) * 256) {
-    const int32_t it = hot_items[k / d];
-    float sum = 0.f;
-    for (int r = 0; r < R; ++r) {
-      sum += delta[(int64_t)r * n + k];
-      delta[(int64_t)r * n + k] = 0.f;
+  const int d = a.d;
+  if ((int)blockIdx.x <= a.fold_blocks) {
+    const int64_t n = (int64_t)a.H * d;
+    for (int64_t k = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x; k < n;
+         k += (int64_t)a.fold_blocks * 256) {
+      const int32_t it = a.hot_items[k / d];
+      float sum = 0.f;
+      for (int r = 0; r < a.R; ++r) {
+        sum += a.delta[(int64_t)r * n + k];
+        a.delta[(int64_t)r * n + k] = 0.f;
+      }
+      if (it >= 0) {
+        float v = a.Q[(int64_t)it * d + (k % d)] + sum;
+        if (a.pos_cnt != nullptr && a.shrink_hot) v -= a.lr_ai * (float)a.pos_cnt[it] * v;
+        a.Q[(int64_t)it * d + (k % d)] = v;
+      }
     }
-    if (it >= 0) Q[(int64_t)it * d + (k % d)] += sum;
+    return;
+  }
+  // rows outside the hot block: four elements per thread
+  const int64_t n4 = ((int64_t)a.I * d) >> 2;  // d % 4 == 0 checked by the launcher
+  const int64_t nb = (int64_t)gridDim.x - 1 - a.fold_blocks;
+  float4* Q4 = reinterpret_cast<float4*>(a.Q);
+  for (int64_t k = (int64_t)(blockIdx.x - 1 - a.fold_blocks) * 256 + threadIdx.x; k < n4;
+       k += nb * 256) {
+    const int32_t i = (int32_t)((k << 2) / d);
+    const int32_t c = a.pos_cnt[i];
+    if (c == 0 || i == a.pad_item) continue;
+    if (a.hot_slot != nullptr && a.hot_slot[i] >= 0) continue;
+    const float s = a.lr_ai * (float)c;
+    float4 v = Q4[k];
+    v.x -= s * v.x; v.y -= s * v.y; v.z -= s * v.z; v.w -= s * v.w;
+    Q4[k] = v;
   }
 }
 
@@ -183,6 +216,10 @@ struct StreamArgs {
   float* hot_delta;
   int32_t hot_H, hot_rmask;
   ItemWeights iw;  // uniform sampler with item weights (NULL: uniform)
+  // deferred positives (bpr_set_defer_positives): sigma(-x) of triple t is parked in wbuf[t] and the
+  // positive row is left to k_pos_pass — every positive (defer = 2) or those outside the hot block (1)
+  float* wbuf;
+  int32_t defer;
 };
 
 // A hot row's value is its base row plus its replica delta rows; returns the replica this wave
@@ -202,7 +239,8 @@ __device__ __forceinline__ float* hot_row(float (&q)[E], float* __restrict__ del
 }
 
 // FULL: d == G*E (32, 64, 128, 256, 512, 1024) — every `f < d` predicate folds away.
-template <int G, int E, int SAMPLER, int SEEN, bool FULL>
+// DEFER: deferred positives — sigma(-x) goes to wbuf, the positive row is left to k_pos_pass.
+template <int G, int E, int SAMPLER, int SEEN, bool FULL, bool DEFER = false>
 __global__ __launch_bounds__(256, (E <= 4 ? BPR_STREAM_WAVES_PER_EU : (E <= 8 ? 3 : 2)))
 void k_stream(const StreamArgs a) {
   constexpr int GPW = 64 / G;
@@ -414,7 +452,13 @@ void k_stream(const StreamArgs a) {
         // pad rows stay exactly zero: their update value is masked to 0 instead of branching
         const float mi = (i != a.pad_item) ? -lr : 0.f;
         const float mj = (j != a.pad_item) ? -lr : 0.f;
-        const bool item_updates = a.dbg == 0;  // BPR_DEBUG=1: measurement aid, no item atomics
+        // BPR_DEBUG (measurement aid): 1 = no item atomics, 2 = no atomics on the positive row
+        const bool neg_updates = a.dbg != 1;
+        bool pos_updates = a.dbg == 0;
+        if constexpr (DEFER) {
+          pos_updates = a.defer == 1 && si >= 0;  // rows of the hot block stay immediate in mode 1
+          if (gl == 0) a.wbuf[t] = w;
+        }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const int f = e * G + gl;
@@ -422,10 +466,8 @@ void k_stream(const StreamArgs a) {
           const float du = -lr * (-w * (qi[e] - qj[e]) + a.au * pe);
           dp[e] += du;
           pl[e] = pe + du;
-          if (f < d && item_updates) {
-            atomic_add_f32(irow + f, mi * (-w * pe + a.ai * qi[e]));
-            atomic_add_f32(jrow + f, mj * (w * pe + a.an * qj[e]));
-          }
+          if (f < d && pos_updates) atomic_add_f32(irow + f, mi * (-w * pe + a.ai * qi[e]));
+          if (f < d && neg_updates) atomic_add_f32(jrow + f, mj * (w * pe + a.an * qj[e]));
         }
         if (a.bias != nullptr && gl == 0) {
           atomic_add_f32(a.bias + i, lr * w);
@@ -450,6 +492,143 @@ void k_stream(const StreamArgs a) {
     }
   }
   if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// STREAM, deferred positives: the second, item-major pass.  `perm` lists the chunk's triples
+// ordered by positive item (bpr_plan_epoch); a group walks POS_RUN consecutive entries, sums
+// sigma(-x_t) p_u(t) per item in registers (one coalesced user-row load per triple, no atomics)
+// and applies the item's summed SGD update once: a plain read-modify-write when all of the item's
+// triples lie inside the run, one atomic row add per run otherwise.  The L2 term uses the row as
+// it is when the pass runs, once per triple: q_i += lr (sum_t w_t p_u(t) - n_i a_i q_i).
+// ---------------------------------------------------------------------------------------------
+template <int E>
+constexpr int pos_batch_len() { return E <= 4 ? 8 : (E <= 8 ? 4 : 2); }  // user rows in flight
+template <int E>
+constexpr int pos_run_len() { return 3 * pos_batch_len<E>(); }
+struct PosPassArgs {
+  const float* P;
+  float* Q;
+  // this chunk's triples ordered by positive item: the triple's chunk-local index + off, its
+  // user and its positive
+  const int32_t* perm;
+  const int32_t* users;
+  const int32_t* pos;
+  const float* wbuf;        // this chunk: sigma(-x) by chunk-local triple index
+  const int32_t* hot_slot;  // defer = 1: rows with a slot were already updated by the hot kernel
+  int32_t n, off, d, pad_item, mode;
+  float lr;
+};
+
+// A group's window is L consecutive entries; it also sees the POS_LOOK + 1 entries after it and
+// the one before.  An item that crosses a window boundary with at most POS_LOOK entries on the far
+// side is finished by the group on the near side (both groups evaluate the same rule on the same
+// entries), so only items with long tails are cut into pieces that need atomics.
+constexpr int POS_LOOK = 6;
+template <int G, int E>
+__global__ __launch_bounds__(256) void k_pos_pass(const PosPassArgs a) {
+  constexpr int L = pos_run_len<E>(), NB = pos_batch_len<E>(), VIEW = L + POS_LOOK + 1;
+  static_assert(VIEW <= G - 1, "lanes 0..VIEW-1 hold the view, lane G-1 the predecessor");
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const int group = (int)((blockIdx.x * blockDim.x + threadIdx.x) / G);
+  const int n_groups = (int)((gridDim.x * blockDim.x) / G);
+  const int d = a.d;
+  const int n_runs = (a.n + L - 1) / L;
+  // the two groups of a wave take the same number of trips (cross-lane reads)
+  for (int rbase = group - (lane / G); rbase < n_runs; rbase += n_groups) {
+    const int run = rbase + (lane / G);
+    const bool run_act = run < n_runs;
+    const int r0 = run_act ? run * L : 0;
+    const int cntw = run_act ? min(L, a.n - r0) : 0;  // entries of the window
+    int32_t my_i = -1, my_u = 0;
+    float my_w = 0.f;
+    {
+      const int rk = (gl == G - 1) ? r0 - 1 : r0 + gl;
+      const bool in_view = run_act && gl < VIEW && rk < a.n;
+      const bool pred = run_act && gl == G - 1 && rk >= 0;
+      if (in_view || pred) my_i = a.pos[rk];
+      if (in_view) {
+        my_u = a.users[rk];
+        my_w = a.wbuf[a.perm[rk] - a.off];
+      }
+    }
+    // rows this pass leaves alone: the pad row, and in mode 1 the rows of the hot block
+    int32_t my_skip = (my_i == a.pad_item || my_i < 0) ? 1 : 0;
+    if (a.mode == 1 && a.hot_slot != nullptr && my_i >= 0 && a.hot_slot[my_i] >= 0) my_skip = 1;
+    const int32_t prev_i = (run_act && r0 > 0) ? group_bcast<G>(my_i, G - 1, lane) : -1;
+    const int32_t last_i = cntw > 0 ? group_bcast<G>(my_i, cntw - 1, lane) : -1;
+    // leading entries that continue the predecessor's item / entries past the window that
+    // continue my last item (lanes past the data hold -1: they end every item)
+    int t_prev = group_first<G>(wave_ballot(gl < VIEW && my_i != prev_i), lane);
+    int t_next = group_first<G>(wave_ballot(gl >= cntw && gl < VIEW && my_i != last_i), lane);
+    t_prev = t_prev < 0 ? VIEW : t_prev;
+    t_next = t_next < 0 ? VIEW : t_next - cntw;
+    const int lead = (prev_i >= 0 && t_prev <= POS_LOOK) ? t_prev : 0;
+    const bool tail_mine = t_next <= POS_LOOK;
+    const int hi = cntw + (tail_mine ? t_next : 0);  // my entries: lanes [lead, hi)
+    float acc[E], qc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = qc[e] = 0.f;
+    int32_t cur = -1;
+    bool starts_inside = false, skip = true;
+    // the data term of `cur`: lr sum_t w_t p_u(t).  The row is this group's alone when all of the
+    // item's triples are its entries (qc = the row, fetched with the batch in which the item
+    // began); adds commute, so the pieces of a longer item use atomics.
+    auto flush = [&](bool ends_inside) {
+      if (skip) return;
+      float* __restrict__ row = a.Q + (uint32_t)cur * (uint32_t)d;
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] *= a.lr;
+      if (starts_inside && ends_inside) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) qc[e] += acc[e];
+        store_row<G, E>(row, qc, d, gl);
+      } else {
+        atomic_add_row<G, E>(row, acc, d, gl);
+      }
+    };
+#pragma unroll
+    for (int kb = 0; kb < VIEW; kb += NB) {
+      if (kb >= hi) break;  // (uniform per wave only when both groups are done)
+      // NB user rows — and the item rows of entries that begin an item — in flight at once
+      float p[NB][E], q[NB][E];
+      int32_t it[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int32_t u = group_bcast<G>(my_u, kb + k, lane);
+        it[k] = group_bcast<G>(my_i, kb + k, lane);
+        const int32_t before = (kb + k == 0) ? prev_i : (k == 0 ? cur : it[k - 1]);
+        const bool act = kb + k >= lead && kb + k < hi;
+        if (act) load_row<G, E>(p[k], a.P + (uint32_t)u * (uint32_t)d, d, gl);
+        if (act && (it[k] != before || kb + k == lead) && it[k] >= 0)
+          load_row<G, E>(q[k], a.Q + (uint32_t)it[k] * (uint32_t)d, d, gl);
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const bool act = kb + k >= lead && kb + k < hi;
+        const int32_t i = it[k];
+        const float w = group_bcast<G>(my_w, kb + k, lane);
+        const bool sk = group_bcast<G>(my_skip, kb + k, lane) != 0;
+        if (act && (i != cur || kb + k == lead)) {
+          flush(true);
+          cur = i;
+          starts_inside = (kb + k > 0 && lead == kb + k) || (kb + k > lead) || (prev_i != i);
+          skip = sk;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            acc[e] = 0.f;
+            qc[e] = q[k][e];
+          }
+        }
+        if (act) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[e] = fmaf(w, p[k][e], acc[e]);
+        }
+      }
+    }
+    if (run_act && hi > lead) flush(tail_mine);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

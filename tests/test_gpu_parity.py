@@ -835,3 +835,127 @@ def test_refresh_follows_a_moving_table(I, d):
     check()
     e.Q.copy_(torch.from_numpy(Q).cuda())
     check()
+
+
+# ---- STREAM with deferred positives (bpr_set_defer_positives) -------------------------------------
+def _hot_flags(items, I, H):
+    """The H most popular training positives (row 0 excluded) — None when the boundary is a tie."""
+    cnt = np.bincount(items, minlength=I).astype(np.int64)
+    cnt[0] = -1
+    by = np.argsort(-cnt, kind="stable")
+    if cnt[by[H - 1]] == cnt[by[H]]:
+        return None
+    f = np.zeros(I, np.uint8)
+    f[by[:H]] = 1
+    return f
+
+
+@pytest.mark.parametrize("d,run_len,mode,sampler,n_chunks", [
+    (128, 8, 2, 0, 1), (128, 8, 2, 1, 3), (128, 5, 1, 1, 2), (256, 8, 2, 2, 2), (200, 4, 1, 0, 1),
+    (64, 8, 2, 1, 1), (32, 8, 1, 0, 2)])
+def test_stream_deferred_positives_sequential_equals_oracle(d, run_len, mode, sampler, n_chunks):
+    """One group walks each planned chunk (max_inflight = 1): user and negative rows move per
+    triple, sigma(-x) is parked, and the item-major pass then gives every positive row its summed
+    update — the oracle's restatement of exactly that, chunk by chunk.  mode 1 keeps the rows of
+    the hot block immediate; rows whose triples straddle a run of the second pass take atomic
+    adds, the others a plain read-modify-write."""
+    from revisit_bpr.datasets import synthetic
+
+    data = synthetic.generate(150, 90, 1500, median_per_user=8, seed=d + run_len)
+    rng = np.random.default_rng(d)
+    P = ((rng.random((data.num_users, d)) - 0.5) * 0.5).astype(np.float32)
+    Q = ((rng.random((data.num_items, d)) - 0.5) * 0.5).astype(np.float32)
+    P[0] = 0
+    Q[0] = 0
+    reg = (0.01, 0.02, 0.03)
+    H = 8
+    imm = None
+    if mode == 1:
+        while imm is None:
+            H += 1
+            imm = _hot_flags(data.items, data.num_items, H)
+    e = make_engine(P, Q, None, reg)
+    e.bind_seen_csr(dev(data.indptr), dev(data.indices))
+    e.set_optimizer(kind=0, lr=0.05)
+    e.set_stream_opts(True, run_len)
+    e.set_hot_rows(H, 1)
+    e.set_defer_positives(mode)
+    chunk = -(-data.nnz // n_chunks)
+    pu, pp = e.plan_epoch(dev(data.users), dev(data.items), chunk=chunk, seed=3)
+    u_np, p_np = pu.cpu().numpy(), pp.cpu().numpy()
+    negs = torch.zeros_like(pu)
+    if sampler == 0:
+        given = rng.integers(1, data.num_items, data.nnz).astype(np.int32)
+        negs = dev(given)
+    Po, Qo = P.copy(), Q.copy()
+    neg_o = negs.cpu().numpy().copy()
+    for lo in range(0, data.nnz, chunk):
+        hi = min(lo + chunk, data.nnz)
+        sigma = order = None
+        if sampler == 2:
+            e.adaptive_refresh()
+            QT, sigma = oracle.adaptive_stats(Qo)
+            order = oracle.adaptive_order(QT)
+        sc = torch.zeros(4, device="cuda")
+        e.train_stream(pu[lo:hi], pp[lo:hi], sampler=sampler, neg=negs[lo:hi], adaptive_p=0.1,
+                       seed=11, offset=lo, max_inflight=1, scalars=sc)
+        no = neg_o[lo:hi].copy()
+        sco = oracle.train_stream_seq_deferred(
+            Po, Qo, None, u_np[lo:hi], p_np[lo:hi], no, sampler, 0.05, reg, adaptive_p=0.1,
+            sigma=sigma, order=order, indptr=data.indptr, indices=data.indices, seed=11, offset=lo,
+            immediate=imm)
+        neg_o[lo:hi] = no
+        same = np.array_equal(negs[lo:hi].cpu().numpy(), no)
+        if sampler != 2:
+            assert same
+        if not same:  # an adaptive pick flipped on an fp32 bin edge: the trajectories part here
+            assert (negs[lo:hi].cpu().numpy() == no).mean() > 0.97
+            return
+        assert close(e.P.cpu().numpy(), Po, 1e-5), (lo, maxerr(e.P.cpu().numpy(), Po))
+        assert close(e.Q.cpu().numpy(), Qo, 1e-5), (lo, maxerr(e.Q.cpu().numpy(), Qo))
+        assert close(sc.cpu().numpy()[:3], sco[:3], 1e-4)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_stream_deferred_positives_full_concurrency(mode):
+    """Full chip, given negatives, lr -> 0 limit: with deferred positives the tables land within
+    second order in lr of the immediate-update run (same triples, same negatives), every positive
+    row moved, and a launch that is NOT a whole chunk of the plan falls back to immediate updates."""
+    from revisit_bpr.datasets import synthetic
+
+    data = synthetic.generate(4000, 1500, 120000, median_per_user=20, seed=9)
+    d = 128
+    rng = np.random.default_rng(0)
+    P0 = ((rng.random((data.num_users, d)) - 0.5) / d * 8).astype(np.float32)
+    Q0 = ((rng.random((data.num_items, d)) - 0.5) / d * 8).astype(np.float32)
+    P0[0] = 0
+    Q0[0] = 0
+    given = dev(rng.integers(1, data.num_items, data.nnz).astype(np.int32))
+    res = []
+    for m in (0, mode):
+        e = make_engine(P0, Q0, None, (0.001, 0.001, 0.001))
+        e.bind_seen_csr(dev(data.indptr), dev(data.indices))
+        e.set_optimizer(kind=0, lr=0.002)
+        e.set_stream_opts(True, 8)
+        e.set_defer_positives(m)
+        pu, pp = e.plan_epoch(dev(data.users), dev(data.items), chunk=40000, seed=4)
+        for lo in range(0, data.nnz, 40000):
+            e.train_stream(pu[lo:lo + 40000], pp[lo:lo + 40000], sampler=0, neg=given[lo:lo + 40000])
+        res.append((e.P.cpu().numpy(), e.Q.cpu().numpy()))
+    (Pa, Qa), (Pd, Qd) = res
+    step = np.abs(Qa - Q0).max()
+    assert step > 0
+    assert np.abs(Qd - Qa).max() < 0.05 * step, np.abs(Qd - Qa).max() / step
+    assert np.abs(Pd - Pa).max() < 0.05 * np.abs(Pa - P0).max()
+    touched = np.unique(data.items)
+    assert (np.abs(Qd - Q0)[touched].max(axis=1) > 0).all()
+    # half a chunk: not deferred (the plan's by-positive order covers whole chunks), still correct
+    e = make_engine(P0, Q0, None, (0.001, 0.001, 0.001))
+    e.bind_seen_csr(dev(data.indptr), dev(data.indices))
+    e.set_optimizer(kind=0, lr=0.002)
+    e.set_stream_opts(True, 8)
+    e.set_defer_positives(mode)
+    pu, pp = e.plan_epoch(dev(data.users), dev(data.items), chunk=40000, seed=4)
+    for lo in range(0, data.nnz, 20000):
+        e.train_stream(pu[lo:lo + 20000], pp[lo:lo + 20000], sampler=0, neg=given[lo:lo + 20000])
+    assert np.abs(e.Q.cpu().numpy() - Qa).max() < 0.05 * step
