@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ counters of k_stream (run on the GPU box).  usage: bash tools/pmc_stream.sh <outdir> [bench args]
+# SQ counters of k_stream — or of the kernel named by $KERNEL — (run on the GPU box).
+# usage: [KERNEL=k_vstream] bash tools/pmc_stream.sh <outdir> [bench args]
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -12,7 +13,7 @@ import csv,collections,glob
 agg=collections.defaultdict(lambda:[0,0.0])
 for f in glob.glob('/root/repo/gpurun_out/$out/p*/**/x_counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_stream' in r['Kernel_Name']:
+        if '${KERNEL:-k_stream}' in r['Kernel_Name']:
             a=agg[r['Counter_Name']]; a[0]+=1; a[1]+=float(r['Counter_Value'])
 for k in sorted(agg): print('%-24s %8d launches  %16.1f per launch' % (k, agg[k][0], agg[k][1]/agg[k][0]))
 PY
