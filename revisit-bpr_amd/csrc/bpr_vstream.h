@@ -163,16 +163,18 @@ __device__ __forceinline__ void vo_update(float& w, float g, float& m, float& v,
     const float wgt = 1.0f - o.b1;
     m = (wgt < 0.5f) ? m + wgt * (g - m) : g - (g - m) * (1.0f - wgt);
     v = o.b2 * v + (1.0f - o.b2) * g * g;
-    const float denom = sqrtf(v) * adam_ibc2 + o.eps;
-    w = w - adam_step * (m / denom);
+    // 1-ulp hardware sqrt / rcp (as the replay): the IEEE sequences cost ~20 instructions per
+    // element and this kernel is bound by VALU issue (profiles/r02_sq_counters_vstream.txt)
+    const float denom = __builtin_amdgcn_sqrtf(v) * adam_ibc2 + o.eps;
+    w = w - adam_step * (m * __builtin_amdgcn_rcpf(denom));
   } else {
     v = o.alpha * v + (1.0f - o.alpha) * g * g;
-    const float avg = sqrtf(v) + o.eps;
+    const float iavg = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + o.eps);
     if (o.mu > 0.f) {  // torch.optim.RMSprop(momentum > 0)
-      m = o.mu * m + g / avg;
+      m = o.mu * m + g * iavg;
       w = w - o.lr * m;
     } else {
-      w = w - o.lr * (g / avg);
+      w = w - o.lr * (g * iavg);
     }
   }
 }
