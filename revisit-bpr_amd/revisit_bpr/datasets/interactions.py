@@ -5,8 +5,10 @@ On-disk formats are the reference's (bin/datasets/format-repro.sh:56-81, jsonl.s
   full-train-with-fold-in-user-seen-items.jsonl  {"user": u, "seen_items": [...]}  one per user
   test-grouped.jsonl                             {"user": u, "item": [...]}        one per eval user
 The reference parses them with json.loads per line into a scipy dok matrix (minutes on MSD,
-experiments/bpr/dataset.py:183-190); here pyarrow's multithreaded JSON reader produces columns that
-go straight into the CSR the engine consumes.
+experiments/bpr/dataset.py:183-190); here the native loader (include/bprio.h → libbprio.so,
+`native_io`: mmap, one piece of the file per thread, C++ CSR builder) produces the arrays the
+engine consumes.  `reader="pyarrow"` is a second, independent implementation (pyarrow's JSON reader +
+numpy) kept for cross-checks.
 """
 from __future__ import annotations
 
@@ -36,10 +38,15 @@ def _ragged(table, key: str):
     return users.astype(np.int64), offsets, flat
 
 
-def load_dataset(path, num_users: int, num_items: int) -> Interactions:
+def load_dataset(path, num_users: int, num_items: int, reader: str = "native",
+                 threads: int = 0) -> Interactions:
     """Read the three files of a dataset directory.  Duplicate (user, item) pairs are dropped, as
     the reference's dok matrix does."""
     path = Path(path)
+    if reader == "native":
+        return _load_native(path, num_users, num_items, threads)
+    if reader != "pyarrow":
+        raise ValueError("reader must be 'native' or 'pyarrow'")
     t = _read_table(path / TRAIN)
     u = t.column("user").to_numpy().astype(np.int64)
     i = t.column("item").to_numpy().astype(np.int64)
@@ -64,6 +71,31 @@ def load_dataset(path, num_users: int, num_items: int) -> Interactions:
     return Interactions(num_users=num_users, num_items=num_items, users=u.astype(np.int32),
                         items=i.astype(np.int32), indptr=indptr, indices=indices,
                         eval_users=ev_users, eval_indptr=ev_ptr, eval_items=ev_items)
+
+
+def _load_native(path: Path, num_users: int, num_items: int, threads: int) -> Interactions:
+    from revisit_bpr.datasets import native_io as nio
+
+    try:
+        tu, ti = nio.read_pairs(path / TRAIN, "item", threads)
+        # de-duplicated training pairs in (user, item) order = the rows of their CSR, expanded
+        tptr, tidx = nio.build_csr(tu, ti, num_users, num_items, drop_item0=False, threads=threads)
+        su, soff, sflat = nio.read_ragged(path / SEEN, "seen_items", threads)
+        rows = np.repeat(su, np.diff(soff))
+        indptr, indices = nio.build_csr(rows, sflat, num_users, num_items, drop_item0=True,
+                                        threads=threads)
+    except nio.BprIoError as e:
+        if "out of range" in str(e):
+            raise ValueError(str(e)) from e
+        raise
+    users = np.repeat(np.arange(num_users, dtype=np.int32), np.diff(tptr))
+    ev_users = np.zeros(0, np.int32)
+    ev_ptr, ev_items = np.zeros(1, np.int64), np.zeros(0, np.int32)
+    if (path / TEST).exists():
+        ev_users, ev_ptr, ev_items = nio.read_ragged(path / TEST, "item", threads)
+    return Interactions(num_users=num_users, num_items=num_items, users=users, items=tidx,
+                        indptr=indptr, indices=indices, eval_users=ev_users, eval_indptr=ev_ptr,
+                        eval_items=ev_items)
 
 
 def write_dataset(data: Interactions, path) -> None:
