@@ -57,11 +57,18 @@ def evaluate(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch.Tens
 @torch.no_grad()
 def evaluate_topk(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch.Tensor,
                   eval_indptr: torch.Tensor, eval_items: torch.Tensor, seen_indptr: torch.Tensor,
-                  seen_indices: torch.Tensor, ks=(5, 10, 20, 50, 100), block: int = 4096) -> dict:
+                  seen_indices: torch.Tensor, ks=(5, 10, 20, 50, 100), block: int = 4096,
+                  auc: bool = False) -> dict:
     """NDCG / Recall / Precision at every k in `ks` from ONE top-max(ks) per block of users (the
     reference runs a full argsort of I scores per metric object: 14 sorts per batch,
     experiments/bpr/exp.py:369-374 + metrics/metric.py:110-113).  Same values as the metric classes
-    (tests/test_gpu_api.py::test_evaluate_topk_equals_metric_classes)."""
+    (tests/test_gpu_api.py::test_evaluate_topk_equals_metric_classes).  `auc=True` adds the
+    ROC-AUC of the reference's RocAucMany (metrics/auc.py:70-130: all positive / negative pairs of a
+    row) from the same block of scores by rank sums — one sort per block instead of the [B, I, I]
+    comparison."""
+    from revisit_bpr.metrics.auc import RocAucManySlow
+
+    auc_metric = RocAucManySlow() if auc else None
     dev = P.device
     I = Q.shape[0]
     kmax = min(max(ks), I)
@@ -92,6 +99,8 @@ def evaluate_topk(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch
         if int(t_cnt.sum()) > 0:
             target[torch.repeat_interleave(rows, t_cnt),
                    eval_items[int(t_lo[0]):int(t_hi[-1])].long()] = 1.0
+        if auc_metric is not None:
+            auc_metric(logits, target)
         rel = torch.gather(target, 1, torch.topk(logits, kmax, dim=1).indices)  # [n, kmax]
         n_pos = t_cnt.float()
         gains = rel * disc
@@ -103,4 +112,7 @@ def evaluate_topk(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch
             sums[f"ndcg@{k}"] += torch.nan_to_num(gains[:, :kk].sum(1) / ideal).double().sum()
             sums[f"recall@{k}"] += torch.nan_to_num(hits / n_pos).double().sum()
             sums[f"precision@{k}"] += (hits / kk).double().sum()
-    return {k: float(v / max(E, 1)) for k, v in sums.items()}
+    out = {k: float(v / max(E, 1)) for k, v in sums.items()}
+    if auc_metric is not None:
+        out["auc"] = float(auc_metric.get_metric())
+    return out

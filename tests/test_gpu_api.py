@@ -263,9 +263,22 @@ def test_evaluate_topk_equals_metric_classes():
             NDCG(topk=k), Recall(topk=k), Precision(topk=k)
     args = (P, Q, b, t["eval_users"], t["eval_indptr"], t["eval_items"], t["indptr"], t["indices"])
     slow = evaluate(*args, metrics, block=128)
-    fast = evaluate_topk(*args, ks=ks, block=300)
+    fast = evaluate_topk(*args, ks=ks, block=300, auc=True)
     for name, v in slow.items():
         assert abs(fast[name] - v) < 2e-6, (name, fast[name], v)
+    # AUC by rank sums == the reference's dense all-pairs definition (metrics/auc.py RocAucMany);
+    # on users with held-out items only (a row without positives is 0 / 0 in either form, and the
+    # reference's test files list no such user)
+    from revisit_bpr.metrics import RocAucMany
+
+    cnt = np.diff(data.eval_indptr)
+    keep = cnt > 0
+    ptr = np.concatenate([[0], np.cumsum(cnt[keep])]).astype(np.int64)
+    args_pos = (P, Q, b, torch.from_numpy(data.eval_users[keep]).cuda(), torch.from_numpy(ptr).cuda(),
+                t["eval_items"], t["indptr"], t["indices"])
+    dense = evaluate(*args_pos, {"auc": RocAucMany()}, block=64)["auc"]
+    ranked = evaluate_topk(*args_pos, ks=(5,), block=300, auc=True)["auc"]
+    assert 0.0 < dense < 1.0 and abs(ranked - dense) < 2e-6, (ranked, dense)
 
 
 def test_user_bias_is_carried_but_never_updated():
