@@ -67,7 +67,7 @@ def parse_args():
     ap.add_argument("--sync-every", type=int, default=1, help="item all-reduce period in steps (N>1)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink users/actions (debug)")
     ap.add_argument("--max-inflight", type=int, default=0)
-    ap.add_argument("--run-len", type=int, default=8)
+    ap.add_argument("--run-len", type=int, default=0, help="0: chosen by the library from the launch size")
     ap.add_argument("--defer-pos", type=int, default=None, choices=[0, 1, 2],
                     help="STREAM: positive rows updated once per chunk by the item-major pass "
                          "(bpr_set_defer_positives; default: the library's)")

@@ -226,8 +226,9 @@ int bpr_shuffle_epoch(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_
  * bpr_train_stream the triples of a user are contiguous (the output of bpr_plan_epoch): a user
  * whose triples all fall in one run of `run_len` consecutive triples is then owned by one
  * wavefront group for the whole launch and its row is written back with a plain store; with 0
- * (default) every user-row update is an atomic add.  run_len (default 8) = consecutive triples one
- * group walks with the user row held in registers. */
+ * (default) every user-row update is an atomic add.  run_len = consecutive triples one
+ * group walks with the user row held in registers: 1..30, or 0 (default) = chosen per launch —
+ * 8 once that makes >= 12 k groups, 4 for smaller launches (they would leave the chip idle). */
 int bpr_set_stream_opts(bpr_ctx* ctx, int32_t grouped_by_user, int32_t run_len);
 
 /* Deferred positives (STREAM, plain SGD).  Half of the kernel's fp32 atomics update the POSITIVE

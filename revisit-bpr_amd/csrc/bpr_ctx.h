@@ -20,7 +20,7 @@ struct bpr_ctx {
   int64_t U = 0, I = 0;
   int d = 0, G = 0, E = 0;
   bool grouped = false;  // STREAM: chunks are grouped by user (bpr_plan_epoch output)
-  int run_len = 8;       // STREAM: consecutive triples walked by one group
+  int run_len = 0;       // STREAM: consecutive triples walked by one group (0: by launch size)
   int pad_user = -1, pad_item = -1;
   const int64_t* indptr = nullptr;
   const int32_t* indices = nullptr;

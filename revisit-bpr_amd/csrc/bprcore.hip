@@ -748,7 +748,9 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
   a.seed = seed; a.offset = offset;
   a.n = (int32_t)n; a.I = (int32_t)c->I; a.d = c->d;
   a.pad_user = c->pad_user; a.pad_item = c->pad_item;
-  a.run_len = c->run_len;
+  // run_len 0 = by launch size: runs of 8 once they make >= 12 k groups (the chip holds ~16 k),
+  // runs of 4 below that (Netflix-sized periods of 40 k triples: 349 -> 409 M triples/s)
+  a.run_len = c->run_len > 0 ? c->run_len : (n >= 8 * 12288 ? 8 : 4);
   a.grouped = c->grouped;
   {
     static const int dbg = getenv("BPR_DEBUG") ? atoi(getenv("BPR_DEBUG")) : 0;
@@ -939,8 +941,8 @@ int bpr_set_defer_positives(bpr_ctx* c, int32_t mode) {
 
 int bpr_set_stream_opts(bpr_ctx* c, int32_t grouped_by_user, int32_t run_len) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: ctx is NULL");
-  if (run_len < 1 || run_len > 30)
-    return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: run_len must be in [1, 30] (one lane of a "
+  if (run_len < 0 || run_len > 30)
+    return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: run_len must be 0 (by launch size) or in [1, 30] (one lane of a "
                                  "32-lane group per triple of the run, plus two neighbours)");
   c->grouped = grouped_by_user != 0;
   c->run_len = run_len;

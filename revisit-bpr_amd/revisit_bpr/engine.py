@@ -338,7 +338,7 @@ class Engine:
                                                  users.numel(), seed, uo.data_ptr(), po.data_ptr()))
         return uo, po
 
-    def set_stream_opts(self, grouped_by_user: bool, run_len: int = 8) -> None:
+    def set_stream_opts(self, grouped_by_user: bool, run_len: int = 0) -> None:
         native.check(self._lib.bpr_set_stream_opts(self._ctx, int(grouped_by_user), run_len))
 
     def set_defer_positives(self, mode: int) -> None:

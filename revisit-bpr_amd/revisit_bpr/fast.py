@@ -20,7 +20,7 @@ class StreamTrainer:
     def __init__(self, model, users: torch.Tensor, items: torch.Tensor, seen_indptr: torch.Tensor,
                  seen_indices: torch.Tensor, lr: float, sampler: str = "adaptive",
                  adaptive_p: float = 0.01, batch_size: int = 256, seed: int = 13,
-                 max_inflight: Optional[int] = None, run_len: int = 8, rank: int = 0,
+                 max_inflight: Optional[int] = None, run_len: int = 0, rank: int = 0,
                  item_sync=None, sync_every: int = 1, world: Optional[int] = None,
                  defer_positives: Optional[int] = None) -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
