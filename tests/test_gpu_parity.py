@@ -852,7 +852,7 @@ def _hot_flags(items, I, H):
 
 @pytest.mark.parametrize("d,run_len,mode,sampler,n_chunks", [
     (128, 8, 2, 0, 1), (128, 8, 2, 1, 3), (128, 5, 1, 1, 2), (256, 8, 2, 2, 2), (200, 4, 1, 0, 1),
-    (64, 8, 2, 1, 1), (32, 8, 1, 0, 2)])
+    (64, 8, 2, 1, 1), (32, 8, 1, 0, 2), (512, 4, 2, 1, 1), (1024, 3, 1, 0, 1), (100, 8, 2, 0, 1)])
 def test_stream_deferred_positives_sequential_equals_oracle(d, run_len, mode, sampler, n_chunks):
     """One group walks each planned chunk (max_inflight = 1): user and negative rows move per
     triple, sigma(-x) is parked, and the item-major pass then gives every positive row its summed
