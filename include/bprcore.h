@@ -299,7 +299,9 @@ int bpr_item_fold_delta(float* q, float* base, float* own, float* tot, float sca
 /* ---- measurement --------------------------------------------------------------------------- */
 /* Average duration (ms) of the dominant kernel over the launches recorded since the last reset,
  * measured with hipEvents on the ctx stream (bench.py's roofline.achieved uses this).
- * bpr_timing_enable(ctx, 1) turns recording on (adds two event records per launch). */
+ * bpr_timing_enable(ctx, N) turns recording on for every N-th launch (N >= 1; 0 = off).  The two
+ * event records around a timed launch cost ~6 us of stream idle time each on MI355X — ~4 % of a
+ * 0.3 ms step when every launch is timed — so bench.py samples every 8th launch of the timed region. */
 int bpr_timing_enable(bpr_ctx* ctx, int32_t on);
 int bpr_timing_read_host(bpr_ctx* ctx, double* avg_ms_host, int64_t* launches_host);
 

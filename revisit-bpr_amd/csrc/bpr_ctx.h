@@ -96,6 +96,8 @@ struct bpr_ctx {
   float* dev_scalars = nullptr;
   // timing of the dominant kernel
   bool timing = false;
+  int timing_stride = 1;      // bpr_timing_enable(ctx, N): events around every N-th launch
+  int64_t timing_seen = 0;
   std::vector<hipEvent_t> ev_start, ev_stop;
   size_t ev_used = 0;
   double timed_ms = 0.0;

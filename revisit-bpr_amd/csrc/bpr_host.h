@@ -48,6 +48,7 @@ struct Timer {
   bool on = false;
   Timer(bpr_ctx* ctx, bool enabled) : c(ctx) {
     if (!enabled || !c->timing) return;
+    if ((c->timing_seen++ % c->timing_stride) != 0) return;  // every timing_stride-th launch
     if (c->ev_used == c->ev_start.size()) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;

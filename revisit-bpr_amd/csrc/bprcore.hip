@@ -1015,6 +1015,8 @@ int bpr_timing_enable(bpr_ctx* c, int32_t on) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_timing_enable: ctx is NULL");
   if (int rc = drain_timing(c)) return rc;
   c->timing = on != 0;
+  c->timing_stride = on > 1 ? on : 1;
+  c->timing_seen = 0;
   c->timed_ms = 0.0;
   c->timed_launches = 0;
   return BPR_OK;

@@ -387,7 +387,9 @@ class Engine:
         native.check(self._lib.bpr_set_sampler_iter(self._ctx, iteration))
 
     # ---- measurement ------------------------------------------------------------------------
-    def timing_enable(self, on: bool = True) -> None:
+    def timing_enable(self, on=True) -> None:
+        """hipEvent timing of the dominant kernel: True / 1 = every launch, N > 1 = every N-th launch
+        (the event records idle the stream for a few microseconds), False / 0 = off."""
         native.check(self._lib.bpr_timing_enable(self._ctx, int(on)))
 
     def timing_read(self) -> tuple[float, int]:
