@@ -41,6 +41,30 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+# full-line fp32 atomic requests the chip retires per second (profiles/ubench_atomic_r02.txt:
+# tools/ubench/atomic_bench.hip, uniform item popularity) — what actually bounds k_stream
+ATOMIC_LINES_PEAK = 9.5e9
+# default snapshot schedule of the adaptive sampler: the one the parity gates hold
+# (tests/test_gpu_e2e_parity.py, tests/test_gpu_fullscale_parity.py)
+SCHEDULE = {"refresh_lag": 0.0, "refresh_split": 1, "refresh_cus": 0}
+
+
+def cut_user_pieces(users, L, look, grouped):
+    """Number of atomic user-row adds of one STREAM launch over `users` (device int32, grouped by
+    user): k_stream cuts a user at a nominal run boundary b (a multiple of L) when the user's
+    triples continue for more than `look` triples past b; every piece of a cut user is one atomic
+    row add, uncut users are stored plainly."""
+    n = users.numel()
+    if not grouped:
+        return float(-(-n // L))  # every run flushes its users atomically (lower bound: one each)
+    b = torch.arange(L, n, L, device=users.device)
+    if b.numel() == 0:
+        return 0.0
+    same = users[b - 1] == users[b]
+    far = b + look
+    cont = same & (far < n) & (users[torch.clamp(far, max=n - 1)] == users[b])
+    cut_users = users[b[cont]]
+    return float(cont.sum().item() + torch.unique(cut_users).numel())
 
 
 def parse_args():
@@ -70,9 +94,18 @@ def parse_args():
     ap.add_argument("--time-every", type=int, default=8,
                     help="hipEvent timing of the dominant kernel on every N-th launch of the timed region")
     ap.add_argument("--run-len", type=int, default=0, help="0: chosen by the library from the launch size")
-    ap.add_argument("--defer-pos", type=int, default=None, choices=[0, 1, 2],
-                    help="STREAM: positive rows updated once per chunk by the item-major pass "
-                         "(bpr_set_defer_positives; default: the library's)")
+    ap.add_argument("--refresh-lag", type=float, default=None,
+                    help="adaptive snapshot schedule (DESIGN.md §4.3): 0 = sorted between launches "
+                         "(the reference's update_stats), 1 = cut before the previous launch and "
+                         "sorted beside it on the side stream, 0<f<1 = cut at 1-f of the previous "
+                         "launch.  Default: the schedule the parity gates hold (see SCHEDULE)")
+    ap.add_argument("--refresh-split", type=int, default=None,
+                    help="launches (= steps) per refresh period, snapshot retaken for each")
+    ap.add_argument("--refresh-cus", type=int, default=None,
+                    help="CUs (of 256) the side stream's sort is masked to; the STREAM kernel runs "
+                         "on the complementary mask (0: unmasked streams)")
+    ap.add_argument("--main-cus", type=int, default=0,
+                    help="measurement aid: run everything on a stream masked to the LAST N CUs")
     ap.add_argument("--hot-rows", type=int, default=None,
                     help="delta rows for the N most popular item rows (library default 256; 0 = off)")
     ap.add_argument("--hot-replicas", type=int, default=1)
@@ -267,10 +300,17 @@ def main():
     e.bind_seen_csr(torch.from_numpy(data.indptr).to(dev), torch.from_numpy(data.indices).to(dev))
     sampler = {"adaptive": eng.NEG_ADAPTIVE, "uniform": eng.NEG_UNIFORM, "given": eng.NEG_GIVEN}[args.sampler]
 
+    # snapshot schedule of the adaptive sampler
+    lag = SCHEDULE["refresh_lag"] if args.refresh_lag is None else args.refresh_lag
+    split = SCHEDULE["refresh_split"] if args.refresh_split is None else args.refresh_split
+    cus = SCHEDULE["refresh_cus"] if args.refresh_cus is None else args.refresh_cus
+    if sampler != eng.NEG_ADAPTIVE or batched:
+        lag, split, cus = 0.0, 1, 0
     # epoch order: bpr_plan_epoch = seeded pseudo-random partition of the triple list into chunks of
-    # one refresh period, each grouped by user (the STREAM kernel keeps the user row in registers)
+    # one launch, each grouped by user (the STREAM kernel keeps the user row in registers)
     every = max(1, int(I * math.log(I) / args.batch_size))  # example.py:302
-    chunk = min(every * args.batch_size, data.nnz)
+    period = min(every * args.batch_size, data.nnz)
+    chunk = max(1, period // split)
     n_chunks = max(1, data.nnz // chunk)
     src_users = torch.from_numpy(data.users).to(dev)
     src_items = torch.from_numpy(data.items).to(dev)
@@ -278,34 +318,58 @@ def main():
     e.set_stream_opts(not args.ungrouped, args.run_len)
     if args.hot_rows is not None:
         e.set_hot_rows(args.hot_rows, args.hot_replicas)
-    if args.defer_pos is not None:
-        e.set_defer_positives(args.defer_pos)
+    main_stream = side_stream = None
+    if lag > 0.0 and cus > 0:
+        total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        side_stream = eng.MaskedStream(dev, eng.cu_mask(0, cus, total_cus))
+        main_stream = eng.MaskedStream(dev, eng.cu_mask(cus, total_cus - cus, total_cus))
+        e.set_side_stream(side_stream)
+    if main_stream is None and args.main_cus > 0:
+        total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        main_stream = eng.MaskedStream(dev, eng.cu_mask(total_cus - args.main_cus, args.main_cus, total_cus))
     sync = ItemSync([Q]) if world > 1 else None
     scalars = torch.zeros(4, device=dev)
     seed = args.seed
     given_neg = (torch.randint(1, I, (chunk,), device=dev, dtype=torch.int32)
                  if sampler == eng.NEG_GIVEN else None)  # measurement aid only
 
+    def launch(k: int, lo: int, hi: int, base: int):
+        if batched:
+            e.train_stream_batched(users[lo:hi], items[lo:hi], args.batch_size,
+                                   sampler=sampler, neg=given_neg, adaptive_p=args.adaptive_p,
+                                   seed=seed, offset=(rank << 40) + k * chunk + (lo - base),
+                                   max_inflight=args.max_inflight, scalars=scalars)
+        else:
+            e.train_stream(users[lo:hi], items[lo:hi], sampler=sampler,
+                           neg=None if given_neg is None else given_neg[:hi - lo],
+                           adaptive_p=args.adaptive_p, seed=seed,
+                           offset=(rank << 40) + k * chunk + (lo - base),
+                           max_inflight=args.max_inflight, scalars=scalars)
+
     def step(k: int):
         c = k % n_chunks
         lo = c * chunk
-        if c == 0:  # new epoch: re-plan (inside the timed region — it is part of the job)
+        if c == 0:  # new epoch: re-plan (part of the job)
             if batched:
                 e.shuffle_epoch(src_users, src_items, seed + k // n_chunks, out=(users, items))
             else:
                 e.plan_epoch(src_users, src_items, chunk, seed + k // n_chunks, out=(users, items))
-        if sampler == eng.NEG_ADAPTIVE:
+        if sampler != eng.NEG_ADAPTIVE:
+            launch(k, lo, lo + chunk, lo)
+        elif lag == 0.0:
             e.adaptive_refresh()  # batched: brings the item rows to "now" first
-        if batched:
-            e.train_stream_batched(users[lo:lo + chunk], items[lo:lo + chunk], args.batch_size,
-                                   sampler=sampler, neg=given_neg, adaptive_p=args.adaptive_p,
-                                   seed=seed, offset=(rank << 40) + k * chunk,
-                                   max_inflight=args.max_inflight, scalars=scalars)
-        else:
-            e.train_stream(users[lo:lo + chunk], items[lo:lo + chunk], sampler=sampler,
-                           neg=given_neg, adaptive_p=args.adaptive_p, seed=seed,
-                           offset=(rank << 40) + k * chunk, max_inflight=args.max_inflight,
-                           scalars=scalars)
+            launch(k, lo, lo + chunk, lo)
+        else:  # the same schedule as fast.StreamTrainer._chunk
+            if e.refresh_pending():
+                e.adaptive_refresh_commit()
+            else:
+                e.adaptive_refresh()
+            cut = lo if lag >= 1.0 else lo + max(1, int(round((1.0 - lag) * chunk)))
+            if cut > lo:
+                launch(k, lo, cut, lo)
+            e.adaptive_refresh_begin()
+            if cut < lo + chunk:
+                launch(k, cut, lo + chunk, lo)
         if sync is not None and (k + 1) % args.sync_every == 0:
             if batched:
                 e.flush_items()
@@ -317,26 +381,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import contextlib
+    on_main = torch.cuda.stream(main_stream.torch) if main_stream is not None else contextlib.nullcontext()
     q_before = Q.double().sum().item(), Q.abs().double().sum().item()
-    step(0)  # plans the first epoch
-    for k in range(1, args.warmup + 1):
-        step(k)
-    barrier()
-    # hipEvents around every `--time-every`-th launch of the dominant kernel (each timed launch idles
-    # the stream for ~12 us; the rocprofv3 summary under profiles/ times all of them)
-    e.timing_enable(max(1, args.time_every))
-    if sync is not None:
-        sync.timing = True
-        sync._events = []
-    scalars.zero_()
-    t0 = time.perf_counter()
-    for k in range(args.warmup + 1, args.warmup + 1 + args.steps):
-        step(k)
-    if sync is not None:
-        sync.finish()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    barrier()
+    # The timed region is K consecutive steps.  An epoch is n_chunks steps and starts with a
+    # bpr_plan_epoch; the step counter is started so that the timed region CONTAINS an epoch
+    # boundary whenever K < n_chunks (so the plan is timed at least at its amortised share).
+    k0 = 0
+    if args.steps < n_chunks:
+        k0 = (n_chunks - (args.warmup + 1) - args.steps // 2) % n_chunks
+    with on_main:
+        if k0 % n_chunks != 0:  # the warm-up starts inside an epoch: plan that epoch first
+            if batched:
+                e.shuffle_epoch(src_users, src_items, seed + k0 // n_chunks, out=(users, items))
+            else:
+                e.plan_epoch(src_users, src_items, chunk, seed + k0 // n_chunks, out=(users, items))
+        for k in range(k0, k0 + args.warmup + 1):
+            step(k)
+        barrier()
+        # hipEvents around every `--time-every`-th launch of the dominant kernel (each timed launch
+        # idles the stream for ~12 us; the rocprofv3 summary under profiles/ times all of them)
+        e.timing_enable(max(1, args.time_every))
+        if sync is not None:
+            sync.timing = True
+            sync._events = []
+        scalars.zero_()
+        t0 = time.perf_counter()
+        first = k0 + args.warmup + 1
+        for k in range(first, first + args.steps):
+            step(k)
+        if sync is not None:
+            sync.finish()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        barrier()
+    plans_timed = sum(1 for k in range(first, first + args.steps) if k % n_chunks == 0)
     kernel_ms, launches = e.timing_read()
     e.timing_enable(False)
     if world > 1:
@@ -351,6 +431,14 @@ def main():
     # counted by the kernel itself, the loss it accumulated is a real -log sigma, the tables moved
     assert int(round(float(sc[3]))) == args.steps * chunk, (sc[3], args.steps * chunk)
     assert 0.0 < float(sc[0] / sc[3]) < 5.0 and q_after != q_before and torch.isfinite(Q).all()
+    # line-atomics per triple of the chunk planned last (what the L2 atomic units see): 2 item rows
+    # of d*4/128 lines each + one row per piece of every user a run boundary cuts (k_stream's rule)
+    lines_per_row = max(1, (d * 4) // 128)
+    user_atomic_rows = 0.0
+    if not batched:
+        L = args.run_len if args.run_len > 0 else (8 if chunk >= 8 * 12288 else 4)
+        look = max(0, min(6, L - 1, (32 if d <= 128 else 64) - 2 - L))
+        user_atomic_rows = cut_user_pieces(users[:chunk], L, look, not args.ungrouped) / chunk
 
     opt_desc = {"sgd": f"SGD lr={args.lr}", "momentum": f"SGD(momentum 0.9) lr={args.lr}",
                 "adam": f"Adam lr={args.lr} betas={tuple(args.betas)}",
@@ -362,9 +450,9 @@ def main():
         # rows (+ ids + 24 B of per-row step marks); momentum / RMSprop carry one state table
         bytes_per_triple = {"sgd": 24 * d + 8, "adam": 72 * d + 32, "momentum": 48 * d + 32,
                             "rmsprop": 48 * d + 32}[args.optimizer]
-        # HBM-side bytes per k_stream launch from the rocprofv3 PMC passes of this same command
-        # (profiles/r01_pmc_traffic.md: FETCH_SIZE x2 correction + WRITE_SIZE); null when the run
-        # is not the profiled configuration
+        # HBM-side bytes per k_stream launch: NOT measured by this run — replayed from the committed
+        # summary of separate rocprofv3 --pmc passes of this same command (profiles/*_pmc_traffic.md:
+        # FETCH_SIZE x2 correction + WRITE_SIZE); null when the run is not the profiled configuration
         traffic = None
         tfiles = sorted((ROOT / "profiles").glob("traffic_r*.json"))
         tfile = tfiles[-1] if tfiles else ROOT / "profiles" / "none"
@@ -393,8 +481,13 @@ def main():
                             f"reg {reg}, {args.sampler} negative sampling"
                             + (f" p={args.adaptive_p}" if args.sampler == "adaptive" else "")
                             + (f", batched STREAM mode (virtual mini-batches of {args.batch_size})" if batched
-                               else ", STREAM mode") + f", step = refresh + {chunk} triples",
+                               else ", STREAM mode") + f", step = snapshot refresh + {chunk} triples"
+                            + ("" if lag == 0.0 else f" (snapshot sorted beside the launch: lag {lag:g}, "
+                               f"{split} launch(es) per refresh period, sort masked to {cus} CUs)"),
                 "triples_per_step_per_gpu": chunk,
+                "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus},
+                "plan_epochs_in_timed_region": plans_timed,
+                "steps_per_epoch": n_chunks,
                 "parallelism": f"user-sharded x{world}, item table replicated, async delta "
                                f"all-reduce every {args.sync_every} step(s)" if world > 1 else "single GPU",
                 "mean_bpr_loss": float(sc[0] / max(sc[3], 1.0)),
@@ -409,16 +502,27 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": (f"profiles/{tfile.stem.replace('traffic_', '')}_pmc_traffic.md (separate rocprofv3 --pmc "
-                                   "FETCH_SIZE / WRITE_SIZE passes of this command on an MI355X, bytes per launch, "
-                                   "gfx950 x2 read correction; replayed from the committed summary, not re-measured "
-                                   "in this run)") if traffic else None,
+                "traffic_measured_in_this_run": False,
+                "traffic_source": (f"replayed from profiles/{tfile.stem.replace('traffic_', '')}_pmc_traffic.md "
+                                   "(separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
+                                   "MI355X, bytes per launch, gfx950 x2 read correction)") if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_triple * chunk,
                 "bytes_per_triple": bytes_per_triple,
                 "kernel_ms_avg": kernel_ms,
                 "launches": launches,
             },
         }
+        if not batched and kernel_ms > 0:
+            # what bounds k_stream is the L2 atomic units, not HBM: full-line fp32 atomic requests
+            lpt = 2 * lines_per_row + user_atomic_rows * lines_per_row
+            rate = lpt * chunk / (kernel_ms * 1e-3)
+            out["roofline_atomic"] = {
+                "bound": "l2-atomic-units", "unit": "line-atomics/s", "achieved": rate,
+                "peak": ATOMIC_LINES_PEAK, "frac": rate / ATOMIC_LINES_PEAK,
+                "line_atomics_per_triple": lpt,
+                "user_rows_cut_per_triple": user_atomic_rows,
+                "peak_source": "profiles/ubench_atomic_r02.txt (tools/ubench/atomic_bench.hip, uniform items)",
+            }
         if sync is not None:
             # how the item reconciliation sits next to the step: the all-reduce runs on a side
             # stream under the next step's kernels; it is hidden as long as it is shorter than a step

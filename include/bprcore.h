@@ -102,7 +102,10 @@ int bpr_bind_tables(bpr_ctx* ctx, float* P, int64_t U, float* Q, int64_t I, int3
 
 /* Seen-items CSR over users: indptr [U+1] int64, indices [nnz] int32 sorted ascending inside each
  * row, no duplicates, no item 0.  Replaces the padded `seen_items` [B,S] batch tensor
- * (experiments/bpr/dataset.py:142-190, example.py:33-68) for on-device sampling. */
+ * (experiments/bpr/dataset.py:142-190, example.py:33-68) for on-device sampling.  The first
+ * sampling STREAM launch after a bind derives private scratch from it (I-bit seen bitmaps in HBM
+ * for users with more than 256 seen items: one-time, synchronous): bind again after changing the
+ * arrays' contents. */
 int bpr_bind_seen_csr(bpr_ctx* ctx, const int64_t* indptr, const int32_t* indices);
 
 /* Model.regularization alphas after the resolution rules of model.py:74-86 were applied by the host. */
@@ -136,6 +139,33 @@ int bpr_bind_item_weights(bpr_ctx* ctx, const float* accept, const int32_t* alia
 /* AdaptiveSampler.update_stats (neg_samplers.py:126-132): snapshot the item table as per-factor
  * descending item orders (private scratch, d*I int32) and sigma_f = unbiased std over rows 1.. */
 int bpr_adaptive_refresh(bpr_ctx* ctx);
+/* The same refresh in two halves, so that the sort does not stand between two STREAM launches
+ * (the reference sorts inline: update_stats is called from sample(), neg_samplers.py:122-123).
+ * _begin: the snapshot's keys are cut from the item table NOW, in the ctx stream's order — that
+ * instant is the snapshot's point in time — and their per-factor sort is queued on the ctx's SIDE
+ * stream; the ctx stream does not wait, and every sampler keeps reading the previous snapshot.
+ * _commit: the ctx stream waits for that sort; launches after it read the new snapshot.
+ * bpr_adaptive_refresh == _begin + _commit with nothing in between.  One split refresh may be
+ * pending at a time (_begin while pending: BPR_ERR_INVALID; bpr_adaptive_refresh while pending
+ * is refused as well — commit first).  What the caller puts between the two calls decides the
+ * snapshot's age: `commit; begin; bpr_train_stream(chunk)` per chunk makes every chunk sample from
+ * the item table as it was one chunk earlier (DESIGN.md section 4.3 holds the parity evidence). */
+int bpr_adaptive_refresh_begin(bpr_ctx* ctx);
+int bpr_adaptive_refresh_commit(bpr_ctx* ctx);
+/* *pending_host (HOST pointer) = 1 while a split refresh awaits its commit. */
+int bpr_adaptive_refresh_pending(bpr_ctx* ctx, int32_t* pending_host);
+/* The side stream of the split refresh (a hipStream_t of the ctx's device; NULL = a plain
+ * non-blocking stream created by the library on first use).  The caller keeps ownership. */
+int bpr_set_side_stream(bpr_ctx* ctx, void* hip_stream);
+/* Streams restricted to a subset of the CUs (hipExtStreamCreateWithCUMask): cu_mask holds
+ * mask_words 32-bit words, bit i of the mask = CU i in the driver's numbering (on MI300-class
+ * parts bits are dealt round-robin over the 8 XCDs, so a contiguous bit range takes equally from
+ * each); mask_words = 0 creates a plain non-blocking stream.  The STREAM kernel is bound by the L2
+ * atomic units and leaves most CU cycles idle, so the split refresh's sort runs beside it on a
+ * disjoint CU set: create two complementary streams, hand one to bpr_ctx_create / bpr_set_stream
+ * and the other to bpr_set_side_stream.  No reference counterpart (the reference has no streams). */
+int bpr_stream_create(int device_id, const uint32_t* cu_mask, int32_t mask_words, void** stream_out);
+int bpr_stream_destroy(void* hip_stream);
 /* AdaptiveSampler.sample: factor ~ |p_uf|·sigma_f, rank ~ Geometric(p) clamped to #unseen,
  * orientation by sign(p_uf), pick the rank-th unseen item of the snapshot order.
  * factor_out / rank_out (int32 [B], nullable) expose the intermediate draws for parity tests;
@@ -224,35 +254,24 @@ int bpr_shuffle_epoch(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_
 
 /* STREAM options.  grouped_by_user = 1 promises that inside every chunk handed to
  * bpr_train_stream the triples of a user are contiguous (the output of bpr_plan_epoch): a user
- * whose triples all fall in one run of `run_len` consecutive triples is then owned by one
- * wavefront group for the whole launch and its row is written back with a plain store; with 0
- * (default) every user-row update is an atomic add.  run_len = consecutive triples one
- * group walks with the user row held in registers: 1..30, or 0 (default) = chosen per launch —
- * 8 once that makes >= 12 k groups, 4 for smaller launches (they would leave the chip idle). */
+ * whose triples are all walked by one group is then owned by that wavefront group for the whole
+ * launch and its row is written back with a plain store; with 0 (default) every user-row update
+ * is an atomic add.  run_len = nominal number of consecutive triples one group walks with the
+ * user row held in registers: 1..24, or 0 (default) = chosen per launch — 8 once that makes
+ * >= 12 k groups, 4 for smaller launches (they would leave the chip idle).  Run boundaries bend
+ * to user boundaries: a user that crosses a nominal boundary with at most min(6, run_len - 1)
+ * triples on the far side is finished by the run that started it. */
 int bpr_set_stream_opts(bpr_ctx* ctx, int32_t grouped_by_user, int32_t run_len);
-
-/* Deferred positives (STREAM, plain SGD).  Half of the kernel's fp32 atomics update the POSITIVE
- * item row of each triple, and positives are known before the epoch starts.  With mode != 0
- * bpr_plan_epoch also orders every chunk's triples by positive item, bpr_train_stream on a whole
- * chunk of that plan parks sigma(-x_uij) per triple instead of updating q_i, and a second,
- * item-major kernel applies each positive row's summed update once per chunk
- * (q_i += lr (sum_t w_t p_u(t) - n_i alpha_i q_i): no atomics, one row write per item).  Within a
- * chunk the positive rows are therefore read at their start-of-chunk value (plus the updates they
- * received as NEGATIVES, which stay immediate): the same staleness the adaptive sampler's snapshot
- * has by construction (one refresh period).  mode 1 defers only rows outside the hot block
- * (bpr_set_hot_rows: those keep their immediate delta-row updates), mode 2 every positive row,
- * 0 (default) none.  Launches that are not whole chunks of the current plan are not deferred.
- * Takes effect at the next bpr_plan_epoch.  No counterpart in the reference: torch.optim.SGD steps
- * once per mini-batch (example.py:176-180); DESIGN.md section 5 holds the parity evidence. */
-int bpr_set_defer_positives(bpr_ctx* ctx, int32_t mode);
 
 /* Hot item rows.  On popularity-skewed data the STREAM kernel is limited by fp32 atomics queueing
  * on the memory channels that happen to hold the most popular item rows (rows are scattered over
  * the table, the load per channel is uneven).  bpr_plan_epoch therefore counts the training
  * positives per item (once per training set) and the `hot_rows` most popular rows (default 256)
- * take their STREAM updates in a compact block of delta rows that spans every channel evenly —
- * optionally `replicas` (1, 2, 4 or 8; default 1) of them, a wavefront adds to one, every reader
- * adds them all to the base row — folded into Q right after every STREAM launch.  Same algebra
+ * take their STREAM updates in a compact block of delta rows — each placed in the slot whose
+ * channels are least loaded, counting what the rows left in Q put on every channel, so that the
+ * whole launch is spread evenly; optionally `replicas` (1, 2, 4 or 8; default 1) of the block, a
+ * wavefront adds to one, every reader adds them all to the base row — folded into Q right after
+ * every STREAM launch.  Same algebra
  * as updating Q directly, up to the association of fp32 sums.  hot_rows = 0 turns it off.  Takes
  * effect at the next bpr_plan_epoch. */
 int bpr_set_hot_rows(bpr_ctx* ctx, int32_t hot_rows, int32_t replicas);

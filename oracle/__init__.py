@@ -265,24 +265,6 @@ def train_stream_seq(P, Q, bias, users, pos, neg, sampler, lr, alphas=(0.0, 0.0,
     return sc
 
 
-def train_stream_seq_deferred(P, Q, bias, users, pos, neg, sampler, lr, alphas=(0.0, 0.0, 0.0),
-                              adaptive_p=0.01, sigma=None, order=None, indptr=None, indices=None,
-                              seed=0, offset=0, pad_user=0, pad_item=0, immediate=None):
-    """Sequential limit of STREAM with deferred positives (bpr_set_defer_positives)."""
-    U, d = P.shape
-    I = Q.shape[0]
-    sc = np.zeros(4, np.float64)
-    w = np.zeros(len(users), np.float32)
-    imm = None if immediate is None else np.ascontiguousarray(immediate, np.uint8)
-    lib().orc_train_stream_seq_deferred(
-        _f(P), _f(Q), _f(bias), c_i64(U), c_i64(I), c_i32(d), _i32(users), _i32(pos), _i32(neg),
-        c_i64(len(users)), c_i32(sampler), c_f(adaptive_p), _f(sigma), _i32(order), _i64(indptr),
-        _i32(indices), c_u64(seed), c_u64(offset), c_f(alphas[0]), c_f(alphas[1]), c_f(alphas[2]),
-        c_i32(pad_user), c_i32(pad_item), c_f(lr), _p(sc, np.float64), _f(w),
-        None if imm is None else imm.ctypes.data_as(ctypes.c_void_p))
-    return sc
-
-
 def num_threads() -> int:
     return 1  # scalar port
 

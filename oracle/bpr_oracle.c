@@ -329,6 +329,20 @@ static int32_t sample_weighted_one(const int64_t* indptr, const int32_t* indices
     int32_t c = uniform_candidate(r, I, accept, alias);
     if (!csr_contains(indptr, indices, user, c)) return c;
   }
+  /* every candidate was seen (a user who has seen nearly all items): the reference's multinomial
+   * over the masked weights (neg_samplers.py:31-37) still returns an unseen item — one more draw
+   * picks the r-th unseen item by rank (literal scan over the ids) */
+  {
+    int64_t lo = indptr[user], hi = indptr[user + 1];
+    int64_t n_unseen = (I - 1) - (hi - lo);
+    if (n_unseen <= 0) return 0;
+    uint32_t r = draw(seed, t, ORC_UNIFORM_MAX_CAND / 4, 0u, 0);
+    int64_t want = (int64_t)(((uint64_t)r * (uint64_t)(uint32_t)n_unseen) >> 32);
+    for (int32_t c = 1; c < I; ++c) {
+      if (csr_contains(indptr, indices, user, c)) continue;
+      if (want-- == 0) return c;
+    }
+  }
   return 0;
 }
 
@@ -461,17 +475,12 @@ void orc_sample_adaptive(const float* P, int32_t d, const float* sigma, const in
 /* ------------------------------------------------------------------------------------------
  * sequential stream (B = 1 SGD)
  * ---------------------------------------------------------------------------------------- */
-/* defer_w != NULL: the "deferred positives" variant of the product's STREAM mode (no reference
- * counterpart; include/bprcore.h bpr_set_defer_positives): sigma(-x) of triple b is parked in
- * defer_w[b] and the positive row is NOT updated here — except rows flagged in `immediate`
- * (the product's hot block in mode 1).  orc_apply_deferred_positives finishes the chunk. */
 static void stream_seq_impl(float* P, float* Q, float* item_bias, int64_t U, int64_t I, int32_t d,
                           const int32_t* users, const int32_t* pos, int32_t* neg_io, int64_t n,
                           int32_t sampler, float adaptive_p, const float* sigma,
                           const int32_t* order, const int64_t* indptr, const int32_t* indices,
                           uint64_t seed, uint64_t offset, float a_user, float a_item, float a_neg,
-                          int32_t pad_user, int32_t pad_item, float lr, double* scalars,
-                          float* defer_w, const uint8_t* immediate) {
+                          int32_t pad_user, int32_t pad_item, float lr, double* scalars) {
   (void)U;
   double loss = 0, reg = 0, sabs = 0;
   for (int64_t b = 0; b < n; ++b) {
@@ -498,18 +507,16 @@ static void stream_seq_impl(float* P, float* Q, float* item_bias, int64_t U, int
     reg += 0.5 * ((double)a_item * ddot(qi, qi, d) + (double)a_neg * ddot(qj, qj, d) +
                   (double)a_user * ddot(p, p, d));
     int same = (i == j);
-    int pos_now = !(defer_w && !(immediate && immediate[i]));
-    if (defer_w) defer_w[b] = (float)w;
     for (int32_t k = 0; k < d; ++k) {
       double pk = p[k], qik = qi[k], qjk = qj[k];
       double gp = -w * (qik - qjk) + (double)a_user * pk;
-      double gi = pos_now ? -w * pk + (double)a_item * qik : 0.0;
+      double gi = -w * pk + (double)a_item * qik;
       double gj = w * pk + (double)a_neg * qjk;
       if (u != pad_user) p[k] = (float)(pk - (double)lr * gp);
       if (same) {
         if (i != pad_item) qi[k] = (float)(qik - (double)lr * (gi + gj));
       } else {
-        if (i != pad_item && pos_now) qi[k] = (float)(qik - (double)lr * gi);
+        if (i != pad_item) qi[k] = (float)(qik - (double)lr * gi);
         if (j != pad_item) qj[k] = (float)(qjk - (double)lr * gj);
       }
     }
@@ -529,38 +536,5 @@ void orc_train_stream_seq(float* P, float* Q, float* item_bias, int64_t U, int64
                           int32_t pad_user, int32_t pad_item, float lr, double* scalars) {
   stream_seq_impl(P, Q, item_bias, U, I, d, users, pos, neg_io, n, sampler, adaptive_p, sigma, order,
                   indptr, indices, seed, offset, a_user, a_item, a_neg, pad_user, pad_item, lr,
-                  scalars, NULL, NULL);
-}
-
-void orc_train_stream_seq_deferred(float* P, float* Q, float* item_bias, int64_t U, int64_t I,
-                                   int32_t d, const int32_t* users, const int32_t* pos,
-                                   int32_t* neg_io, int64_t n, int32_t sampler, float adaptive_p,
-                                   const float* sigma, const int32_t* order, const int64_t* indptr,
-                                   const int32_t* indices, uint64_t seed, uint64_t offset,
-                                   float a_user, float a_item, float a_neg, int32_t pad_user,
-                                   int32_t pad_item, float lr, double* scalars, float* defer_w,
-                                   const uint8_t* immediate) {
-  stream_seq_impl(P, Q, item_bias, U, I, d, users, pos, neg_io, n, sampler, adaptive_p, sigma, order,
-                  indptr, indices, seed, offset, a_user, a_item, a_neg, pad_user, pad_item, lr,
-                  scalars, defer_w, immediate);
-  /* the item-major pass: q_i += lr (sum_t w_t p_u(t) - n_i a_i q_i), user rows as they are after
-   * the chunk, q_i as it is now (its negative-role updates were immediate) */
-  double* acc = (double*)calloc((size_t)I * (size_t)d, sizeof(double));
-  int64_t* cnt = (int64_t*)calloc((size_t)I, sizeof(int64_t));
-  for (int64_t b = 0; b < n; ++b) {
-    int32_t i = pos[b];
-    if (i == pad_item || (immediate && immediate[i])) continue;
-    const float* p = P + (int64_t)users[b] * d;
-    for (int32_t k = 0; k < d; ++k) acc[(int64_t)i * d + k] += (double)defer_w[b] * (double)p[k];
-    cnt[i] += 1;
-  }
-  for (int64_t i = 0; i < I; ++i) {
-    if (cnt[i] == 0) continue;
-    float* q = Q + i * d;
-    for (int32_t k = 0; k < d; ++k)
-      q[k] = (float)((double)q[k] + (double)lr * (acc[i * d + k] -
-                                                  (double)cnt[i] * (double)a_item * (double)q[k]));
-  }
-  free(acc);
-  free(cnt);
+                  scalars);
 }

@@ -121,20 +121,6 @@ void orc_train_stream_seq(float* P, float* Q, float* item_bias, int64_t U, int64
                           uint64_t seed, uint64_t offset, float a_user, float a_item, float a_neg,
                           int32_t pad_user, int32_t pad_item, float lr, double* scalars);
 
-/* The product's "deferred positives" STREAM variant in its sequential limit (no reference
- * counterpart — include/bprcore.h bpr_set_defer_positives): as above, but the positive row of a
- * triple is not updated in the stream (sigma(-x) is parked in defer_w[n]); after the chunk every
- * positive row takes q_i += lr (sum_t w_t p_u(t) - n_i a_item q_i) once.  immediate[I] (nullable)
- * flags rows that keep the immediate update (mode 1: the hot block). */
-void orc_train_stream_seq_deferred(float* P, float* Q, float* item_bias, int64_t U, int64_t I,
-                                   int32_t d, const int32_t* users, const int32_t* pos,
-                                   int32_t* neg_io, int64_t n, int32_t sampler, float adaptive_p,
-                                   const float* sigma, const int32_t* order, const int64_t* indptr,
-                                   const int32_t* indices, uint64_t seed, uint64_t offset,
-                                   float a_user, float a_item, float a_neg, int32_t pad_user,
-                                   int32_t pad_item, float lr, double* scalars, float* defer_w,
-                                   const uint8_t* immediate);
-
 #ifdef __cplusplus
 }
 #endif

@@ -48,11 +48,14 @@ struct bpr_ctx {
   float *vGP = nullptr, *vGQ = nullptr, *vGb = nullptr;
   uint64_t *vHP = nullptr, *vHQ = nullptr;
   bool vs_active = false;
-  // private scratch — adaptive sampler snapshot
+  // private scratch — adaptive sampler snapshot.  Two snapshots: `order` / `sigma` point at the
+  // FRONT one (what the samplers read); a refresh sorts into the back one and swaps.
   int32_t* order = nullptr;  // [d, I], inside order_alloc with BPR_ORDER_PAD entries of slack on
-  int32_t* order_alloc = nullptr;  // both ends (the sampler's walk reads 16-byte vectors)
-  float* sigma = nullptr;    // [d]
-  float* keysT = nullptr;    // [d, I] transposed item table
+  float* sigma = nullptr;    // [d]       both ends (the sampler's walk reads 16-byte vectors)
+  int32_t* order_alloc[2] = {nullptr, nullptr};
+  float* sigma_buf[2] = {nullptr, nullptr};
+  int snap_front = 0;
+  float* keysT = nullptr;    // [d, I] transposed item table (the keys of the running sort)
   float* keys_sorted = nullptr;  // 2 x [d, I] uint64 composite sort keys (in | out)
   int32_t* ids_in = nullptr;
   int32_t* seg_offsets = nullptr;  // [d+1]
@@ -60,38 +63,38 @@ struct bpr_ctx {
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   bool have_snapshot = false;
+  // split refresh (bpr_adaptive_refresh_begin / _commit): the keys are cut on `stream`, the sort
+  // runs on `side` while the caller keeps launching on `stream`, commit orders the swap
+  hipStream_t side = nullptr;
+  bool side_owned = false;
+  hipEvent_t ev_keys = nullptr, ev_sorted = nullptr;
+  bool refresh_pending = false;
   // private scratch — epoch planner
   uint64_t* plan_keys = nullptr;
   uint64_t* plan_keys_sorted = nullptr;
   void* plan_tmp = nullptr;
   size_t plan_tmp_bytes = 0;
   int64_t plan_cap = 0;
-  // STREAM with deferred positives (bpr_set_defer_positives): the plan also holds, per chunk, the
-  // chunk's triples ordered by positive item; the hot kernel parks sigma(-x) per triple in wbuf and
-  // k_pos_pass applies each positive row's summed update once
-  int defer_pos = 0;                   // 0 off | 1 rows outside the hot block | 2 every positive row
-  int32_t* plan_perm = nullptr;        // [plan_n] triple indices, every chunk sorted by positive
-  int32_t* plan_iota = nullptr;        // [plan_perm_cap] 0, 1, 2, ...
-  int32_t* plan_pos_sorted = nullptr;  // [plan_n] pos[plan_perm[k]]  (coalesced for k_pos_pass)
-  int32_t* plan_users_bypos = nullptr; // [plan_n] users[plan_perm[k]]
-  int64_t plan_perm_cap = 0;
-  int32_t* plan_cnt = nullptr;         // [n_chunks, I] positives of an item inside a chunk
-  int64_t plan_cnt_cap = 0;
   const int32_t* plan_users = nullptr;  // outputs of the last bpr_plan_epoch (caller-owned)
   const int32_t* plan_pos = nullptr;
   int64_t plan_n = 0, plan_chunk = 0;
-  bool plan_perm_valid = false;
-  float* wbuf = nullptr;               // [wbuf_cap] sigma(-x) of the triples of one launch
-  int64_t wbuf_cap = 0;
   // hot item rows (bpr_set_hot_rows): the most popular rows take their STREAM updates in replica
   // delta rows, folded into Q right after every STREAM launch (all zero in between)
   int hot_rows_opt = 256, hot_reps_opt = 1;
   int hot_H = 0, hot_R = 0;
   int32_t* hot_slot = nullptr;   // [I] slot of an item row, -1 = not hot
   int32_t* hot_items = nullptr;  // [hot_H]
-  float* hot_delta = nullptr;    // [hot_R, hot_H, d]
+  float* hot_delta = nullptr;    // [hot_R, hot_H, d], aligned to a channel round inside hot_delta_alloc
+  void* hot_delta_alloc = nullptr;
+  double hot_balance = 1.0;      // modelled max / mean channel load of a launch (hot_build_impl)
   const int32_t* hot_key_ptr = nullptr;  // training positives the popularity was measured on
   int64_t hot_key_n = 0;
+  // heavy users' seen bitmaps (built once per seen CSR, by the first sampling STREAM launch)
+  uint32_t* heavy_off = nullptr;   // [U] word offset of the user's row in heavy_bits, ~0u = light
+  uint32_t* heavy_bits = nullptr;  // [n_heavy, words]
+  int heavy_T = 0;                 // users with more seen items than this are heavy
+  int64_t heavy_n = 0;
+  const int64_t* heavy_for = nullptr;  // the indptr the table was built from (NULL = not built)
   // scalar slots
   float* dev_scalars = nullptr;
   // timing of the dominant kernel
@@ -106,8 +109,12 @@ struct bpr_ctx {
 
 namespace bpr {
 void set_error(const std::string& msg);
-int refresh_impl(bpr_ctx* c);       // bpr_refresh.hip
+int refresh_impl(bpr_ctx* c, bool split);  // bpr_refresh.hip: split = sort on c->side, no swap
+int refresh_commit_impl(bpr_ctx* c);        // bpr_refresh.hip
 void refresh_free(bpr_ctx* c);      // bpr_refresh.hip
+void side_free(bpr_ctx* c);         // bpr_refresh.hip
+int heavy_build_impl(bpr_ctx* c);   // bpr_refresh.hip
+void heavy_free(bpr_ctx* c);        // bpr_refresh.hip
 int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n);  // bpr_refresh.hip
 void hot_free(bpr_ctx* c);                                       // bpr_refresh.hip
 int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n,

@@ -47,7 +47,7 @@ __device__ __forceinline__ uint32_t draw(uint64_t seed, uint64_t t, uint32_t blo
 
 enum : uint32_t { PURPOSE_UNIFORM = 0u, PURPOSE_ADAPTIVE = 1u };
 enum { NEG_GIVEN = 0, NEG_UNIFORM = 1, NEG_ADAPTIVE = 2 };  // == bpr_sampler_kind
-constexpr int UNIFORM_MAX_CAND = 4096;  // candidates tried before giving up (returns item 0)
+constexpr int UNIFORM_MAX_CAND = 4096;  // rejection candidates tried before the exact rank pick
 
 // ---------------------------------------------------------------------------------------------
 // group (sub-wave) collectives.  Sums and scans run on the VALU with DPP row operations
@@ -158,21 +158,34 @@ struct SeenCsr {  // binary search in the user's sorted CSR slice (≈ log2(n_u)
     return csr_contains(indices, lo, hi, c);
   }
 };
+// Heavy users (more seen items than `heavy_T`): their I-bit seen bitmaps are precomputed ONCE per
+// seen CSR in HBM (288 GB make that cheap: a few thousand users x I/8 bytes) — building the LDS
+// structure costs a dependent HBM round trip per 128 seen items at every user change, and a user
+// with thousands of them is rebuilt by every group that walks one of its runs.  hoff = word offset
+// of the user's row in gbits, ~0u = light user (LDS structure).
+constexpr uint32_t NOT_HEAVY = 0xFFFFFFFFu;
 struct SeenBitmap {  // one LDS read: the group's I-bit bitmap of the current user (k_stream)
   const uint32_t* bm;
+  const uint32_t* __restrict__ gbits;
+  uint32_t hoff;
   __device__ __forceinline__ bool operator()(int32_t c) const {
-    return ((bm[c >> 5] >> (c & 31)) & 1u) != 0u;
+    const uint32_t w = hoff != NOT_HEAVY ? gbits[hoff + (uint32_t)(c >> 5)] : bm[c >> 5];
+    return ((w >> (c & 31)) & 1u) != 0u;
   }
 };
 
 // the user's sorted seen list staged in LDS (k_stream, item tables too large for per-group
-// bitmaps): ≈ log2(n_u) LDS reads; users with more than the staged capacity use the CSR in HBM
+// bitmaps): ≈ log2(n_u) LDS reads; users with more than the staged capacity use their HBM bitmap
+// (heavy users) or search the CSR in HBM
 struct SeenList {
   const int32_t* lst;
   int32_t n;  // < 0: not staged, search the CSR slice
   const int32_t* __restrict__ indices;
   int64_t lo, hi;
+  const uint32_t* __restrict__ gbits;
+  uint32_t hoff;
   __device__ __forceinline__ bool operator()(int32_t c) const {
+    if (hoff != NOT_HEAVY) return ((gbits[hoff + (uint32_t)(c >> 5)] >> (c & 31)) & 1u) != 0u;
     if (n < 0) return csr_contains(indices, lo, hi, c);
     int32_t b = 0, len = n;
     while (len > 0) {
@@ -209,9 +222,28 @@ __device__ __forceinline__ int32_t uniform_candidate(uint32_t r, int64_t I, cons
   return frac < w.accept[c] ? c : w.alias[c];
 }
 
+// Item number r (0-based) among the items 1..I-1 that are NOT in the sorted list seen[0..n_seen):
+// seen[k] - 1 - k items below seen[k] are unseen, so the answer is r + 1 + #{k : seen[k] - 1 - k <= r}
+// (binary search: the predicate is monotone in k).
+__device__ __forceinline__ int32_t nth_unseen(const int32_t* __restrict__ seen_ids, int64_t n_seen,
+                                              int64_t r) {
+  int64_t lo = 0, hi = n_seen;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)seen_ids[mid] - 1 - mid <= r) lo = mid + 1; else hi = mid;
+  }
+  return (int32_t)(r + 1 + lo);
+}
+
+// `seen_ids` / `n_seen`: the user's sorted CSR slice (ids >= 1).  When UNIFORM_MAX_CAND candidates
+// in a row were all seen (a user who has seen nearly every item) the pick becomes exact: one more
+// draw (the next Philox block) selects uniformly among the user's unseen items by rank, so the
+// result is always a valid unseen item, as the reference's multinomial over the masked weights
+// (neg_samplers.py:31-37); item 0 only when nothing is unseen (the reference would raise).
 template <int G, typename Seen>
-__device__ __forceinline__ int32_t sample_uniform(const Seen& seen, int64_t I, uint64_t seed,
-                                                  uint64_t t, int lane,
+__device__ __forceinline__ int32_t sample_uniform(const Seen& seen, int64_t n_seen,
+                                                  const int32_t* __restrict__ seen_ids, int64_t I,
+                                                  uint64_t seed, uint64_t t, int lane,
                                                   const ItemWeights& iw = ItemWeights{nullptr, nullptr}) {
   const int gl = lane & (G - 1);
   int32_t result = 0;
@@ -229,6 +261,13 @@ __device__ __forceinline__ int32_t sample_uniform(const Seen& seen, int64_t I, u
       done = true;
     }
     if (__all(done)) break;
+  }
+  if (!done) {
+    const int64_t n_unseen = (I - 1) - n_seen;
+    if (n_unseen > 0) {
+      const uint32_t r = draw(seed, t, (uint32_t)(UNIFORM_MAX_CAND / 4), PURPOSE_UNIFORM, 0);
+      result = nth_unseen(seen_ids, n_seen, (int64_t)__umulhi(r, (uint32_t)n_unseen));
+    }
   }
   return result;
 }
@@ -344,23 +383,24 @@ __device__ __forceinline__ AdaptiveRandoms adaptive_randoms(uint64_t seed, uint6
   return o;
 }
 
-template <int G, int E, typename Seen>
+// `sigma` is any indexable holder of the snapshot's per-factor std in the element layout of this
+// file (a register array, or an LDS view: k_stream keeps it in LDS to save registers).
+template <int G, int E, typename Seen, typename Sigma>
 __device__ __forceinline__ AdaptiveDraw sample_adaptive(
-    const float (&p)[E], int d, const float (&sigma)[E],
+    const float (&p)[E], int d, const Sigma& sigma,
     const int32_t* __restrict__ order, int64_t I, const Seen& seen, int64_t n_seen,
     const AdaptiveRandoms& rnd, int lane) {
   const int gl = lane & (G - 1);
   // ---- factor ~ Categorical(|p_uf|·σ_f)  (neg_samplers.py:84-88): inverse CDF in factor order
-  // f = e*G + gl, i.e. chunk e after chunk e-1, lanes in order inside a chunk
-  float w[E], incl[E], carry[E];
+  // f = e*G + gl, i.e. chunk e after chunk e-1, lanes in order inside a chunk.  Two passes over the
+  // chunks — total first, then the search — so that only one chunk's weights are live at a time
+  // (the scans are a handful of DPP adds; registers, not VALU cycles, are what this kernel lacks).
   float total = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int f = e * G + gl;
-    w[e] = (f < d) ? fabsf(p[e]) * sigma[e] : 0.f;
-    incl[e] = group_scan_incl<G>(w[e]);
-    carry[e] = total;
-    total += group_last<G>(incl[e], lane);
+    const float w = (f < d) ? fabsf(p[e]) * sigma[e] : 0.f;
+    total += group_last<G>(group_scan_incl<G>(w), lane);
   }
   const float thr = rnd.uf * total;
   // first factor with weight whose inclusive CDF exceeds thr; psel = my element of its chunk
@@ -368,19 +408,26 @@ __device__ __forceinline__ AdaptiveDraw sample_adaptive(
   // dynamically indexed private array by the compiler, which moves p[] to scratch memory)
   int fsel = -1;
   float psel = p[0];
+  float carry = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const int first = group_first<G>(wave_ballot(w[e] > 0.f && carry[e] + incl[e] > thr), lane);
+    const int f = e * G + gl;
+    const float w = (f < d) ? fabsf(p[e]) * sigma[e] : 0.f;
+    const float incl = group_scan_incl<G>(w);
+    const int first = group_first<G>(wave_ballot(w > 0.f && carry + incl > thr), lane);
     const bool take = fsel < 0 && first >= 0;
     fsel = take ? e * G + first : fsel;
     psel = take ? p[e] : psel;
+    carry += group_last<G>(incl, lane);
   }
   if (fsel < 0) {  // thr rounded up to the total: the last factor with weight (0 if there is none)
     fsel = 0;
     psel = p[0];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int last = group_last_set<G>(wave_ballot(w[e] > 0.f), lane);
+      const int f = e * G + gl;
+      const float w = (f < d) ? fabsf(p[e]) * sigma[e] : 0.f;
+      const int last = group_last_set<G>(wave_ballot(w > 0.f), lane);
       if (last >= 0) {
         fsel = e * G + last;
         psel = p[e];

@@ -107,19 +107,13 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ 
 
 // After a STREAM launch: fold the hot rows' replica deltas into Q and clear them (blocks 1..fold),
 // and add the launch's loss statistics to the caller's scalars (block 0, when requested).
-// Deferred positives (pos_cnt != NULL): the L2 term of the deferred updates — n_i positives of
-// item i in this chunk shrink its row once, q_i *= 1 - lr alpha_i n_i, before k_pos_pass adds the
-// summed data terms (fold blocks: their hot rows; blocks past them: every other row).
 struct EpilogueArgs {
   const float* partials;
   float* out;
   float* Q;
   float* delta;
   const int32_t* hot_items;
-  const int32_t* hot_slot;
-  const int32_t* pos_cnt;  // [I] of this chunk
-  int32_t n_blocks, H, R, d, fold_blocks, I, pad_item, shrink_hot;
-  float lr_ai;
+  int32_t n_blocks, H, R, d, fold_blocks;
 };
 
 __global__ __launch_bounds__(256) void k_stream_epilogue(const EpilogueArgs a) {
@@ -143,53 +137,36 @@ __global__ __launch_bounds__(256) void k_stream_epilogue(const EpilogueArgs a) {
     return;
   }
   const int d = a.d;
-  if ((int)blockIdx.x <= a.fold_blocks) {
-    const int64_t n = (int64_t)a.H * d;
-    for (int64_t k = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x; k < n;
-         k += (int64_t)a.fold_blocks * 256) {
-      const int32_t it = a.hot_items[k / d];
-      float sum = 0.f;
-      for (int r = 0; r < a.R; ++r) {
-        sum += a.delta[(int64_t)r * n + k];
-        a.delta[(int64_t)r * n + k] = 0.f;
-      }
-      if (it >= 0) {
-        float v = a.Q[(int64_t)it * d + (k % d)] + sum;
-        if (a.pos_cnt != nullptr && a.shrink_hot) v -= a.lr_ai * (float)a.pos_cnt[it] * v;
-        a.Q[(int64_t)it * d + (k % d)] = v;
-      }
+  const int64_t n = (int64_t)a.H * d;
+  for (int64_t k = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x; k < n;
+       k += (int64_t)a.fold_blocks * 256) {
+    const int32_t it = a.hot_items[k / d];
+    float sum = 0.f;
+    for (int r = 0; r < a.R; ++r) {
+      sum += a.delta[(int64_t)r * n + k];
+      a.delta[(int64_t)r * n + k] = 0.f;
     }
-    return;
-  }
-  // rows outside the hot block: four elements per thread
-  const int64_t n4 = ((int64_t)a.I * d) >> 2;  // d % 4 == 0 checked by the launcher
-  const int64_t nb = (int64_t)gridDim.x - 1 - a.fold_blocks;
-  float4* Q4 = reinterpret_cast<float4*>(a.Q);
-  for (int64_t k = (int64_t)(blockIdx.x - 1 - a.fold_blocks) * 256 + threadIdx.x; k < n4;
-       k += nb * 256) {
-    const int32_t i = (int32_t)((k << 2) / d);
-    const int32_t c = a.pos_cnt[i];
-    if (c == 0 || i == a.pad_item) continue;
-    if (a.hot_slot != nullptr && a.hot_slot[i] >= 0) continue;
-    const float s = a.lr_ai * (float)c;
-    float4 v = Q4[k];
-    v.x -= s * v.x; v.y -= s * v.y; v.z -= s * v.z; v.w -= s * v.w;
-    Q4[k] = v;
+    if (it >= 0) a.Q[(int64_t)it * d + (k % d)] += sum;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // STREAM: the throughput kernel.
 //
-// The chunk [0, n) is cut into runs of `run_len` consecutive triples; group g walks run g, g+NG, …
-// While consecutive triples share the user, the user row lives in registers (read once, written
-// once).  When the chunk is grouped by user (bpr_plan_epoch) a user whose triples all fall inside
-// one run is owned exclusively by that group for the whole launch → plain store, no atomics and no
-// cross-XCD coherence question; a user whose triples straddle a run boundary gets the group's
-// accumulated delta added atomically instead.  Item rows are shared by everybody → one full-line
-// fp32 atomic add per 128 B of row.
+// The chunk [0, n) is cut into runs of nominally `run_len` consecutive triples; group g walks run
+// g, g+NG, …  While consecutive triples share the user, the user row lives in registers (read once,
+// written once).  When the chunk is grouped by user (bpr_plan_epoch) a user whose triples are all
+// walked by one group is owned exclusively by that group for the whole launch → plain store, no
+// atomics and no cross-XCD coherence question.  Run boundaries bend to user boundaries: a user that
+// crosses a nominal boundary with at most `look` triples on the far side is FINISHED by the run
+// that started it (both neighbours evaluate the same rule on the same ids, so they agree without
+// talking); only users with a longer tail are cut, and a cut user gets the groups' accumulated
+// deltas added atomically instead.  Item rows are shared by everybody → one full-line fp32 atomic
+// add per 128 B of row.
 // ---------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) uint32_t bpr_smem[];
+
+constexpr int STREAM_LOOK_MAX = 6;
 
 // kernel arguments of k_stream only (kept small: every field costs SGPRs for the whole kernel)
 struct StreamArgs {
@@ -207,7 +184,7 @@ struct StreamArgs {
   uint64_t seed, offset;
   int32_t n, I, d;
   int32_t pad_user, pad_item;
-  int32_t run_len, grouped, bm_words, dbg;
+  int32_t run_len, look, grouped, bm_words;
   int32_t gpw_active;  // groups of a wave that work (G = 32: 2; 1 = one triple at a time, tests)
   float au, ai, an, lr, inv_log1mp;
   // hot item rows: updates of row i with hot_slot[i] = s >= 0 go to the replica delta row
@@ -216,17 +193,19 @@ struct StreamArgs {
   float* hot_delta;
   int32_t hot_H, hot_rmask;
   ItemWeights iw;  // uniform sampler with item weights (NULL: uniform)
-  // deferred positives (bpr_set_defer_positives): sigma(-x) of triple t is parked in wbuf[t] and the
-  // positive row is left to k_pos_pass — every positive (defer = 2) or those outside the hot block (1)
-  float* wbuf;
-  int32_t defer;
+  // heavy users' precomputed seen bitmaps (bpr_device.h): word offset per user, ~0u = light
+  const uint32_t* heavy_off;
+  const uint32_t* heavy_bits;
+  int32_t heavy_T;
 };
 
-// A hot row's value is its base row plus its replica delta rows; returns the replica this wave
-// adds its update to.
+// A hot row's value is its base row plus its replica delta rows; returns where this wave adds its
+// update: an encoded row offset — >= 0: element offset into Q, < 0: ~(element offset into the
+// delta block) — one register instead of a 64-bit pointer.
 template <int G, int E>
-__device__ __forceinline__ float* hot_row(float (&q)[E], float* __restrict__ delta, int32_t slot,
-                                          int32_t H, int32_t rmask, int wave, int d, int gl) {
+__device__ __forceinline__ int32_t hot_row(float (&q)[E], const float* __restrict__ delta,
+                                           int32_t slot, int32_t H, int32_t rmask, int wave, int d,
+                                           int gl) {
   for (int32_t r = 0; r <= rmask; ++r) {
     const float* __restrict__ row = delta + (uint32_t)(r * H + slot) * (uint32_t)d;
 #pragma unroll
@@ -235,13 +214,41 @@ __device__ __forceinline__ float* hot_row(float (&q)[E], float* __restrict__ del
       if (f < d) q[e] += row[f];
     }
   }
-  return delta + (uint32_t)((wave & rmask) * H + slot) * (uint32_t)d;
+  return ~(int32_t)((uint32_t)((wave & rmask) * H + slot) * (uint32_t)d);
+}
+__device__ __forceinline__ float* row_at(float* Q, float* delta, int32_t enc) {
+  return enc >= 0 ? Q + (uint32_t)enc : delta + (uint32_t)(~enc);
+}
+
+// the snapshot's sigma, kept in LDS (k_stream): entry e of lane gl is factor e*G + gl
+template <int G>
+struct SigmaLds {
+  const float* s;
+  int gl;
+  __device__ __forceinline__ float operator[](int e) const { return s[e * G + gl]; }
+};
+
+// max / min over the groups of a wave of a group-uniform value
+template <int G>
+__device__ __forceinline__ int wave_max_groups(int v) {
+  if constexpr (G == 64) return v;
+  return max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
+}
+template <int G>
+__device__ __forceinline__ int wave_min_groups(int v) {
+  if constexpr (G == 64) return v;
+  return min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
 }
 
 // FULL: d == G*E (32, 64, 128, 256, 512, 1024) — every `f < d` predicate folds away.
-// DEFER: deferred positives — sigma(-x) goes to wbuf, the positive row is left to k_pos_pass.
-template <int G, int E, int SAMPLER, int SEEN, bool FULL, bool DEFER = false>
-__global__ __launch_bounds__(256, (E <= 4 ? BPR_STREAM_WAVES_PER_EU : (E <= 8 ? 3 : 2)))
+// (occupancy: the adaptive sampler over the staged-list structure needs a few registers more than
+// 5 waves per SIMD leave; measured on MI355X, 4 and 5 waves run the kernel equally fast — it is not
+// bound by occupancy — so that variant asks for 4 instead of spilling)
+template <int G, int E, int SAMPLER, int SEEN, bool FULL>
+__global__ __launch_bounds__(256, (E <= 4 ? (SAMPLER == NEG_ADAPTIVE && SEEN == SEEN_LIST
+                                                 ? BPR_STREAM_WAVES_PER_EU - 1
+                                                 : BPR_STREAM_WAVES_PER_EU)
+                                          : (E <= 8 ? 3 : 2)))
 void k_stream(const StreamArgs a) {
   constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -251,6 +258,8 @@ void k_stream(const StreamArgs a) {
   const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
   const int d = FULL ? G * E : a.d;
   const int L = a.run_len;
+  const int LOOK = a.look;
+  const int VIEW = L + LOOK + 1;  // <= G - 1 (launcher): lanes 0..VIEW-1 hold the view
   const int n_runs = (a.n + L - 1) / L;
   const bool stats = a.partials != nullptr;
   float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
@@ -264,52 +273,68 @@ void k_stream(const StreamArgs a) {
     for (int k = gl; k < (W >> 2); k += G) bm4[k] = make_uint4(0u, 0u, 0u, 0u);
   }
   int32_t list_n = -1;
-  int64_t cur_lo = 0, cur_hi = 0;  // CSR slice of the current user
-  float sg[E];                     // snapshot sigma of this lane's factors (adaptive only)
+  uint32_t hoff = NOT_HEAVY;       // current user's row in the heavy users' HBM bitmaps
+  int64_t cur_lo = 0;              // CSR slice of the current user: indices[cur_lo .. cur_lo + cur_n)
+  int32_t cur_n = 0;
+  __shared__ float s_sigma[SAMPLER == NEG_ADAPTIVE ? G * E : 1];  // snapshot sigma (adaptive only)
   if constexpr (SAMPLER == NEG_ADAPTIVE) {
-    load_row<G, E>(sg, a.sigma, d, gl);
+    for (int k = threadIdx.x; k < G * E; k += blockDim.x) s_sigma[k] = k < d ? a.sigma[k] : 0.f;
+    __syncthreads();
   }
+  const SigmaLds<G> sg{s_sigma, gl};
 
   const int gpw = GPW == 1 ? 1 : a.gpw_active;
   for (int rbase = wave * gpw; rbase < n_runs; rbase += n_waves * gpw) {
     const int run = rbase + gw;
     const bool run_act = gw < gpw && run < n_runs;
     const int t0 = run_act ? run * L : 0;
-    const int t1 = run_act ? min(t0 + L, a.n) : 0;
-    // ---- run prologue: ONE coalesced load brings the ids of the whole run (lane k holds triple
-    // t0+k; lane L the successor, lane G-1 the predecessor) and one more the users' CSR bounds,
-    // so the per-triple dependent chain starts at the row gathers instead of at the ids.
+    const int cntw = run_act ? min(L, a.n - t0) : 0;  // triples of the nominal window
+    // ---- run prologue: ONE coalesced load brings the ids of the whole view (lane k holds triple
+    // t0+k, k < VIEW; lane G-1 the predecessor) and one more the users' CSR bounds, so the
+    // per-triple dependent chain starts at the row gathers instead of at the ids.
     int32_t my_u = 0, my_i = 0, my_si = -1;
-    int64_t my_lo = 0, my_hi = 0;
+    int64_t my_lo = 0;
+    int32_t my_cnt = 0;  // the user's seen items: indices[my_lo .. my_lo + my_cnt)
+    bool in_view;
     {
       const int tk = (gl == G - 1) ? t0 - 1 : t0 + gl;
-      const bool in_run = run_act && gl < L && tk < t1;
-      const bool neighbour = run_act && ((gl == L && tk < a.n) || (gl == G - 1 && tk >= 0));
-      if (in_run || neighbour) my_u = a.users[tk];
-      if (in_run) {
+      in_view = run_act && gl < VIEW && tk < a.n;
+      const bool pred = run_act && gl == G - 1 && tk >= 0;
+      if (in_view || pred) my_u = a.users[tk];
+      if (in_view) {
         my_i = a.pos[tk];
         if (a.hot_slot != nullptr) my_si = a.hot_slot[my_i];
         if constexpr (SAMPLER != NEG_GIVEN) {
           my_lo = a.indptr[my_u];
-          my_hi = a.indptr[my_u + 1];
+          my_cnt = (int32_t)(a.indptr[my_u + 1] - my_lo);
         }
       }
     }
-    // the model-independent draws of the run's triples, all at once (lane k = triple t0+k)
+    // the model-independent draws of the view's triples, all at once (lane k = triple t0+k)
     AdaptiveRandoms my_rnd = {0.f, 0};
     if constexpr (SAMPLER == NEG_ADAPTIVE) {
       my_rnd = adaptive_randoms(a.seed, a.offset + (uint64_t)(t0 + gl), a.inv_log1mp,
-                                (int64_t)(a.I - 1) - (my_hi - my_lo));
+                                (int64_t)(a.I - 1) - (int64_t)my_cnt);
     }
-    // uniform: the first Philox block (candidates 0..3) of every triple of the run, all at once
+    // uniform: the first Philox block (candidates 0..3) of every triple of the view, all at once
     u32x4 my_w = {0u, 0u, 0u, 0u};
     if constexpr (SAMPLER == NEG_UNIFORM) {
       const uint64_t tc = a.offset + (uint64_t)(t0 + gl);
       my_w = philox4x32_10((uint32_t)tc, (uint32_t)(tc >> 32), 0u, PURPOSE_UNIFORM,
                            (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
     }
+    // ---- which triples are mine: [lead, hi) of the view.  k_b = number of triples from a nominal
+    // boundary b on that continue the user of triple b-1; k_b <= LOOK: the LEFT run finishes them.
     const int32_t prev_u = (run_act && t0 > 0) ? group_bcast<G>(my_u, G - 1, lane) : -1;
-    const int32_t next_u = (run_act && t1 < a.n) ? group_bcast<G>(my_u, t1 - t0, lane) : -1;
+    const int32_t last_u = cntw > 0 ? group_bcast<G>(my_u, cntw - 1, lane) : -1;
+    int t_prev = group_first<G>(wave_ballot(gl < VIEW && (!in_view || my_u != prev_u)), lane);
+    int t_next = group_first<G>(wave_ballot(gl >= cntw && gl < VIEW && (!in_view || my_u != last_u)),
+                                lane);
+    t_prev = t_prev < 0 ? VIEW : t_prev;
+    t_next = t_next < 0 ? VIEW : t_next - cntw;
+    const int lead = (prev_u >= 0 && t_prev <= LOOK) ? t_prev : 0;
+    const bool tail_mine = t_next <= LOOK;  // my last user ends with my last triple
+    const int hi = run_act ? cntw + (tail_mine ? t_next : 0) : 0;
     int32_t cur_u = -1;
     bool cur_starts_inside = false;
     // pl = live user row (memory value + this group's pending updates dp)
@@ -319,19 +344,16 @@ void k_stream(const StreamArgs a) {
 
     float x_mine = 0.f;  // statistics: logit of step gl of this run
     bool x_have = false;
-    for (int step = 0; step < L; ++step) {
+    const int step_lo = wave_min_groups<G>(run_act ? lead : VIEW);
+    const int step_hi = wave_max_groups<G>(hi);
+    for (int step = step_lo; step < step_hi; ++step) {
       const int t = t0 + step;
-      const bool act = run_act && t < t1;
+      const bool act = step >= lead && step < hi;
       const int tt = act ? t : (a.n - 1);
       const int32_t u = group_bcast<G>(my_u, step, lane);
       const int32_t i = group_bcast<G>(my_i, step, lane);
       const int64_t u_lo = group_bcast<G>(my_lo, step, lane);
-      const int64_t u_hi = group_bcast<G>(my_hi, step, lane);
-      float* __restrict__ irow = a.Q + (uint32_t)i * (uint32_t)d;
-      float qi[E];
-      load_row<G, E>(qi, irow, d, gl);
-      const int32_t si = group_bcast<G>(my_si, step, lane);
-      if (si >= 0) irow = hot_row<G, E>(qi, a.hot_delta, si, a.hot_H, a.hot_rmask, wave, d, gl);
+      const int32_t u_cnt = group_bcast<G>(my_cnt, step, lane);
       if (act && u != cur_u) {
         // ---- user change: write the previous user's row back, fetch the new one
         if (cur_u >= 0 && cur_u != a.pad_user) {
@@ -346,42 +368,48 @@ void k_stream(const StreamArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e) dp[e] = 0.f;
         if constexpr (SAMPLER != NEG_GIVEN) {
-          if constexpr (BM) {
-            // wipe: the whole bitmap with 16-byte LDS stores (W is a multiple of 4: 5 stores per
-            // lane for ML-20M) — cheaper than re-reading the previous user's indices from HBM
-            uint4* bm4 = reinterpret_cast<uint4*>(bm);
-            for (int k = gl; k < (W >> 2); k += G) bm4[k] = make_uint4(0u, 0u, 0u, 0u);
-          }
           cur_lo = u_lo;
-          cur_hi = u_hi;
-          if constexpr (BM) {  // set: 4 index loads in flight per trip
-            for (int64_t k = cur_lo + gl; k < cur_hi; k += 4 * G) {
-              int32_t it[4];
+          cur_n = u_cnt;
+          hoff = NOT_HEAVY;
+          if (a.heavy_off != nullptr && cur_n > a.heavy_T) hoff = a.heavy_off[u];
+          if (hoff == NOT_HEAVY) {
+            if constexpr (BM) {
+              // wipe: the whole bitmap with 16-byte LDS stores (W is a multiple of 4: 5 stores per
+              // lane for ML-20M) — cheaper than re-reading the previous user's indices from HBM
+              uint4* bm4 = reinterpret_cast<uint4*>(bm);
+              for (int k = gl; k < (W >> 2); k += G) bm4[k] = make_uint4(0u, 0u, 0u, 0u);
+              // set: 4 index loads in flight per trip
+              const int32_t* __restrict__ ids = a.indices + cur_lo;
+              for (int32_t k = gl; k < cur_n; k += 4 * G) {
+                int32_t it[4];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int64_t kk = k + q * G;
-                it[q] = kk < cur_hi ? a.indices[kk] : 0;  // bit 0 of word 0 = the pad item: harmless
+                for (int q = 0; q < 4; ++q) {
+                  const int32_t kk = k + q * G;
+                  it[q] = kk < cur_n ? ids[kk] : 0;  // bit 0 of word 0 = the pad item: harmless
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomicOr(&bm[it[q] >> 5], 1u << (it[q] & 31));
               }
-#pragma unroll
-              for (int q = 0; q < 4; ++q) atomicOr(&bm[it[q] >> 5], 1u << (it[q] & 31));
             }
-          }
-          if constexpr (SEEN == SEEN_LIST) {
-            const int64_t cnt = cur_hi - cur_lo;
-            list_n = cnt <= (int64_t)W ? (int32_t)cnt : -1;
-            for (int32_t k = gl; k < list_n; k += 4 * G) {
-              uint32_t it[4];
+            if constexpr (SEEN == SEEN_LIST) {
+              list_n = cur_n <= W ? cur_n : -1;
+              for (int32_t k = gl; k < list_n; k += 4 * G) {
+                uint32_t it[4];
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                it[q] = k + q * G < list_n ? (uint32_t)a.indices[cur_lo + k + q * G] : 0u;
+                for (int q = 0; q < 4; ++q)
+                  it[q] = k + q * G < list_n ? (uint32_t)a.indices[cur_lo + k + q * G] : 0u;
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (k + q * G < list_n) bm[k + q * G] = it[q];
+                for (int q = 0; q < 4; ++q)
+                  if (k + q * G < list_n) bm[k + q * G] = it[q];
+              }
             }
           }
         }
         cur_u = u;
-        cur_starts_inside = (step > 0) || (t == 0) || (prev_u != u);
+        // a user whose first triple is mine: it begins past my first triple, or my first triple
+        // is not a continuation (lead > 0: the view's triple `lead` is by construction the first
+        // of its user; lead == 0: the chunk's first triple, or the predecessor's user differs)
+        cur_starts_inside = (step > lead) || (lead > 0) || (t == 0) || (prev_u != u);
       }
 
       int32_t j;
@@ -393,11 +421,12 @@ void k_stream(const StreamArgs a) {
             typename std::conditional<SEEN == SEEN_LIST, SeenList, SeenCsr>::type>::type;
         Seen seen;
         if constexpr (BM) {
-          seen = SeenBitmap{bm};
+          seen = SeenBitmap{bm, a.heavy_bits, hoff};
         } else if constexpr (SEEN == SEEN_LIST) {
-          seen = SeenList{reinterpret_cast<const int32_t*>(bm), list_n, a.indices, cur_lo, cur_hi};
+          seen = SeenList{reinterpret_cast<const int32_t*>(bm), list_n, a.indices, cur_lo,
+                          cur_lo + cur_n, a.heavy_bits, hoff};
         } else {
-          seen = SeenCsr{a.indices, cur_lo, cur_hi};
+          seen = SeenCsr{a.indices, cur_lo, cur_lo + cur_n};
         }
         if constexpr (SAMPLER == NEG_UNIFORM) {
           // candidates 0..3 were drawn in the run prologue; lanes 0..3 test them.  All four seen
@@ -409,24 +438,36 @@ void k_stream(const StreamArgs a) {
           const int32_t c = uniform_candidate(wsel, a.I, a.iw);
           const bool is_seen = seen(c);
           const Ballot b = wave_ballot(gl < 4 && !is_seen);
-          if (group_first<G>(b, lane) >= 0 && step < t1 - t0) {
+          if (group_first<G>(b, lane) >= 0 && act) {
             j = group_pick<G>(b, c, lane);
           } else {
-            j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane, a.iw);
+            j = sample_uniform<G>(seen, (int64_t)cur_n, a.indices + cur_lo, a.I, a.seed,
+                                  a.offset + (uint64_t)tt, lane, a.iw);
           }
         } else {
           const AdaptiveRandoms rnd = {group_bcast<G>(my_rnd.uf, step, lane),
                                        group_bcast<G>(my_rnd.r, step, lane)};
-          j = sample_adaptive<G, E>(pl, d, sg, a.order, a.I, seen, cur_hi - cur_lo, rnd, lane).item;
+          j = sample_adaptive<G, E>(pl, d, sg, a.order, a.I, seen, (int64_t)cur_n, rnd, lane).item;
         }
         if (a.neg != nullptr && act && gl == 0) a.neg[t] = j;
       }
-      float* __restrict__ jrow = a.Q + (uint32_t)j * (uint32_t)d;
-      float qj[E];
-      load_row<G, E>(qj, jrow, d, gl);
+      // both item rows are gathered together, after the negative is known: the positive row would
+      // only sit in registers while the sampler runs (they, not issue slots, bound the occupancy)
+      int32_t irow = (int32_t)((uint32_t)i * (uint32_t)d);  // encoded row offsets (hot_row)
+      int32_t jrow = (int32_t)((uint32_t)j * (uint32_t)d);
+      float qi[E], qj[E];
+      load_row<G, E>(qi, a.Q + (uint32_t)irow, d, gl);
+      load_row<G, E>(qj, a.Q + (uint32_t)jrow, d, gl);
+      const int32_t si = group_bcast<G>(my_si, step, lane);
+      if (si >= 0) irow = hot_row<G, E>(qi, a.hot_delta, si, a.hot_H, a.hot_rmask, wave, d, gl);
       if (a.hot_slot != nullptr) {
         const int32_t sj = a.hot_slot[j];
         if (sj >= 0) jrow = hot_row<G, E>(qj, a.hot_delta, sj, a.hot_H, a.hot_rmask, wave, d, gl);
+      }
+      float bi = 0.f, bj = 0.f;
+      if (a.bias != nullptr) {
+        bi = a.bias[i];
+        bj = a.bias[j];
       }
 
       // x_uij = <p_u, q_i - q_j> (+ bias difference): one group sum
@@ -434,7 +475,7 @@ void k_stream(const StreamArgs a) {
 #pragma unroll
       for (int e = 0; e < E; ++e) xl = fmaf(pl[e], qi[e] - qj[e], xl);
       float x = group_sum<G>(xl, lane);
-      if (a.bias != nullptr) x += a.bias[i] - a.bias[j];
+      x += bi - bj;
       if (stats && act) {
         // the L2 term is accumulated per lane (its slice of the rows): no group sums; lane k keeps
         // the logit of step k and the loss terms are evaluated once per run, lane-parallel
@@ -452,13 +493,6 @@ void k_stream(const StreamArgs a) {
         // pad rows stay exactly zero: their update value is masked to 0 instead of branching
         const float mi = (i != a.pad_item) ? -lr : 0.f;
         const float mj = (j != a.pad_item) ? -lr : 0.f;
-        // BPR_DEBUG (measurement aid): 1 = no item atomics, 2 = no atomics on the positive row
-        const bool neg_updates = a.dbg != 1;
-        bool pos_updates = a.dbg == 0;
-        if constexpr (DEFER) {
-          pos_updates = a.defer == 1 && si >= 0;  // rows of the hot block stay immediate in mode 1
-          if (gl == 0) a.wbuf[t] = w;
-        }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const int f = e * G + gl;
@@ -466,8 +500,10 @@ void k_stream(const StreamArgs a) {
           const float du = -lr * (-w * (qi[e] - qj[e]) + a.au * pe);
           dp[e] += du;
           pl[e] = pe + du;
-          if (f < d && pos_updates) atomic_add_f32(irow + f, mi * (-w * pe + a.ai * qi[e]));
-          if (f < d && neg_updates) atomic_add_f32(jrow + f, mj * (w * pe + a.an * qj[e]));
+          if (f < d) {
+            atomic_add_f32(row_at(a.Q, a.hot_delta, irow) + f, mi * (-w * pe + a.ai * qi[e]));
+            atomic_add_f32(row_at(a.Q, a.hot_delta, jrow) + f, mj * (w * pe + a.an * qj[e]));
+          }
         }
         if (a.bias != nullptr && gl == 0) {
           atomic_add_f32(a.bias + i, lr * w);
@@ -483,8 +519,7 @@ void k_stream(const StreamArgs a) {
     // ---- end of run: flush the last user
     if (run_act && cur_u >= 0 && cur_u != a.pad_user) {
       float* row = a.P + (uint32_t)cur_u * (uint32_t)d;
-      const bool ends_inside = (t1 == a.n) || (next_u != cur_u);
-      if (a.grouped && cur_starts_inside && ends_inside) {
+      if (a.grouped && cur_starts_inside && tail_mine) {
         store_row<G, E>(row, pl, d, gl);
       } else {
         atomic_add_row<G, E>(row, dp, d, gl);
@@ -492,143 +527,6 @@ void k_stream(const StreamArgs a) {
     }
   }
   if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// STREAM, deferred positives: the second, item-major pass.  `perm` lists the chunk's triples
-// ordered by positive item (bpr_plan_epoch); a group walks POS_RUN consecutive entries, sums
-// sigma(-x_t) p_u(t) per item in registers (one coalesced user-row load per triple, no atomics)
-// and applies the item's summed SGD update once: a plain read-modify-write when all of the item's
-// triples lie inside the run, one atomic row add per run otherwise.  The L2 term uses the row as
-// it is when the pass runs, once per triple: q_i += lr (sum_t w_t p_u(t) - n_i a_i q_i).
-// ---------------------------------------------------------------------------------------------
-template <int E>
-constexpr int pos_batch_len() { return E <= 4 ? 8 : (E <= 8 ? 4 : 2); }  // user rows in flight
-template <int E>
-constexpr int pos_run_len() { return 3 * pos_batch_len<E>(); }
-struct PosPassArgs {
-  const float* P;
-  float* Q;
-  // this chunk's triples ordered by positive item: the triple's chunk-local index + off, its
-  // user and its positive
-  const int32_t* perm;
-  const int32_t* users;
-  const int32_t* pos;
-  const float* wbuf;        // this chunk: sigma(-x) by chunk-local triple index
-  const int32_t* hot_slot;  // defer = 1: rows with a slot were already updated by the hot kernel
-  int32_t n, off, d, pad_item, mode;
-  float lr;
-};
-
-// A group's window is L consecutive entries; it also sees the POS_LOOK + 1 entries after it and
-// the one before.  An item that crosses a window boundary with at most POS_LOOK entries on the far
-// side is finished by the group on the near side (both groups evaluate the same rule on the same
-// entries), so only items with long tails are cut into pieces that need atomics.
-constexpr int POS_LOOK = 6;
-template <int G, int E>
-__global__ __launch_bounds__(256) void k_pos_pass(const PosPassArgs a) {
-  constexpr int L = pos_run_len<E>(), NB = pos_batch_len<E>(), VIEW = L + POS_LOOK + 1;
-  static_assert(VIEW <= G - 1, "lanes 0..VIEW-1 hold the view, lane G-1 the predecessor");
-  const int lane = threadIdx.x & 63;
-  const int gl = lane & (G - 1);
-  const int group = (int)((blockIdx.x * blockDim.x + threadIdx.x) / G);
-  const int n_groups = (int)((gridDim.x * blockDim.x) / G);
-  const int d = a.d;
-  const int n_runs = (a.n + L - 1) / L;
-  // the two groups of a wave take the same number of trips (cross-lane reads)
-  for (int rbase = group - (lane / G); rbase < n_runs; rbase += n_groups) {
-    const int run = rbase + (lane / G);
-    const bool run_act = run < n_runs;
-    const int r0 = run_act ? run * L : 0;
-    const int cntw = run_act ? min(L, a.n - r0) : 0;  // entries of the window
-    int32_t my_i = -1, my_u = 0;
-    float my_w = 0.f;
-    {
-      const int rk = (gl == G - 1) ? r0 - 1 : r0 + gl;
-      const bool in_view = run_act && gl < VIEW && rk < a.n;
-      const bool pred = run_act && gl == G - 1 && rk >= 0;
-      if (in_view || pred) my_i = a.pos[rk];
-      if (in_view) {
-        my_u = a.users[rk];
-        my_w = a.wbuf[a.perm[rk] - a.off];
-      }
-    }
-    // rows this pass leaves alone: the pad row, and in mode 1 the rows of the hot block
-    int32_t my_skip = (my_i == a.pad_item || my_i < 0) ? 1 : 0;
-    if (a.mode == 1 && a.hot_slot != nullptr && my_i >= 0 && a.hot_slot[my_i] >= 0) my_skip = 1;
-    const int32_t prev_i = (run_act && r0 > 0) ? group_bcast<G>(my_i, G - 1, lane) : -1;
-    const int32_t last_i = cntw > 0 ? group_bcast<G>(my_i, cntw - 1, lane) : -1;
-    // leading entries that continue the predecessor's item / entries past the window that
-    // continue my last item (lanes past the data hold -1: they end every item)
-    int t_prev = group_first<G>(wave_ballot(gl < VIEW && my_i != prev_i), lane);
-    int t_next = group_first<G>(wave_ballot(gl >= cntw && gl < VIEW && my_i != last_i), lane);
-    t_prev = t_prev < 0 ? VIEW : t_prev;
-    t_next = t_next < 0 ? VIEW : t_next - cntw;
-    const int lead = (prev_i >= 0 && t_prev <= POS_LOOK) ? t_prev : 0;
-    const bool tail_mine = t_next <= POS_LOOK;
-    const int hi = cntw + (tail_mine ? t_next : 0);  // my entries: lanes [lead, hi)
-    float acc[E], qc[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) acc[e] = qc[e] = 0.f;
-    int32_t cur = -1;
-    bool starts_inside = false, skip = true;
-    // the data term of `cur`: lr sum_t w_t p_u(t).  The row is this group's alone when all of the
-    // item's triples are its entries (qc = the row, fetched with the batch in which the item
-    // began); adds commute, so the pieces of a longer item use atomics.
-    auto flush = [&](bool ends_inside) {
-      if (skip) return;
-      float* __restrict__ row = a.Q + (uint32_t)cur * (uint32_t)d;
-#pragma unroll
-      for (int e = 0; e < E; ++e) acc[e] *= a.lr;
-      if (starts_inside && ends_inside) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) qc[e] += acc[e];
-        store_row<G, E>(row, qc, d, gl);
-      } else {
-        atomic_add_row<G, E>(row, acc, d, gl);
-      }
-    };
-#pragma unroll
-    for (int kb = 0; kb < VIEW; kb += NB) {
-      if (kb >= hi) break;  // (uniform per wave only when both groups are done)
-      // NB user rows — and the item rows of entries that begin an item — in flight at once
-      float p[NB][E], q[NB][E];
-      int32_t it[NB];
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const int32_t u = group_bcast<G>(my_u, kb + k, lane);
-        it[k] = group_bcast<G>(my_i, kb + k, lane);
-        const int32_t before = (kb + k == 0) ? prev_i : (k == 0 ? cur : it[k - 1]);
-        const bool act = kb + k >= lead && kb + k < hi;
-        if (act) load_row<G, E>(p[k], a.P + (uint32_t)u * (uint32_t)d, d, gl);
-        if (act && (it[k] != before || kb + k == lead) && it[k] >= 0)
-          load_row<G, E>(q[k], a.Q + (uint32_t)it[k] * (uint32_t)d, d, gl);
-      }
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const bool act = kb + k >= lead && kb + k < hi;
-        const int32_t i = it[k];
-        const float w = group_bcast<G>(my_w, kb + k, lane);
-        const bool sk = group_bcast<G>(my_skip, kb + k, lane) != 0;
-        if (act && (i != cur || kb + k == lead)) {
-          flush(true);
-          cur = i;
-          starts_inside = (kb + k > 0 && lead == kb + k) || (kb + k > lead) || (prev_i != i);
-          skip = sk;
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            acc[e] = 0.f;
-            qc[e] = q[k][e];
-          }
-        }
-        if (act) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) acc[e] = fmaf(w, p[k][e], acc[e]);
-        }
-      }
-    }
-    if (run_act && hi > lead) flush(tail_mine);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -786,12 +684,13 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) atomicOr(&bm[it[q] >> 5], 1u << (it[q] & 31));
       }
-      seen = SeenBitmap{bm};
+      seen = SeenBitmap{bm, nullptr, NOT_HEAVY};
     } else {
       seen = SeenCsr{a.indices, lo, hi};
     }
     if constexpr (WHAT == SAMPLE_UNIFORM) {
-      const int32_t j = sample_uniform<G>(seen, a.I, a.seed, a.offset + (uint64_t)tt, lane, a.iw);
+      const int32_t j = sample_uniform<G>(seen, hi - lo, a.indices + lo, a.I, a.seed,
+                                          a.offset + (uint64_t)tt, lane, a.iw);
       if (act && gl == 0) a.neg[t] = j;
     } else if constexpr (WHAT == SAMPLE_ADAPTIVE) {
       float p[E];

@@ -19,6 +19,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
+#include <stdio.h>
 
 #include "bpr_ctx.h"
 
@@ -296,9 +298,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_runs(
 }
 
 template <int ITEMS>
-static void launch_sort_sub(bpr_ctx* c, int sub, int64_t len, float* keysA, int32_t* idsA) {
-  hipLaunchKernelGGL((k_sort_sub<ITEMS>), dim3(sub, c->d), dim3(1024), 0, c->stream, c->keysT,
-                     c->I, len, c->order, keysA, idsA, c->sigma, c->sig_acc);
+static void launch_sort_sub(bpr_ctx* c, hipStream_t st, int32_t* order, float* sigma, int sub,
+                            int64_t len, float* keysA, int32_t* idsA) {
+  hipLaunchKernelGGL((k_sort_sub<ITEMS>), dim3(sub, c->d), dim3(1024), 0, st, c->keysT, c->I, len,
+                     order, keysA, idsA, sigma, c->sig_acc);
 }
 
 // composite sort key: (factor << 32) | ~orderable(value)  → ascending sort = per-factor descending
@@ -368,41 +371,6 @@ __global__ void k_plan_users(const uint64_t* __restrict__ keys, int64_t n, int u
     users_out[t] = (int32_t)(keys[t] & mask);
 }
 
-__global__ void k_iota32(int32_t* __restrict__ ids, int64_t I);
-// second order of the plan: every chunk's triples by positive item (deferred positives)
-template <typename K>
-__global__ void k_plan_pos_keys(const int32_t* __restrict__ pos, int64_t n, int64_t chunk, int ibits,
-                                K* __restrict__ keys) {
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
-       t += (int64_t)gridDim.x * blockDim.x)
-    keys[t] = (K)(((uint64_t)(t / chunk) << ibits) | (uint64_t)(uint32_t)pos[t]);
-}
-
-// sorted (chunk, positive) keys -> cnt[chunk, item] = length of the key's run; the thread on a
-// run's last entry finds its first by binary search
-template <typename K>
-__global__ void k_plan_pos_counts(const K* __restrict__ keys, int64_t n, int ibits, int64_t I,
-                                  int32_t* __restrict__ cnt, const int32_t* __restrict__ perm,
-                                  const int32_t* __restrict__ users,
-                                  int32_t* __restrict__ pos_sorted,
-                                  int32_t* __restrict__ users_bypos) {
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    const K k = keys[t];
-    // the ids of entry t of the by-positive order, so that k_pos_pass reads them coalesced
-    pos_sorted[t] = (int32_t)((uint64_t)k & ((1ull << ibits) - 1ull));
-    users_bypos[t] = users[perm[t]];
-    if (t + 1 < n && keys[t + 1] == k) continue;
-    int64_t lo = 0, hi = t;  // first index holding k
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (keys[mid] < k) lo = mid + 1; else hi = mid;
-    }
-    const uint64_t kk = (uint64_t)k;
-    cnt[(int64_t)(kk >> ibits) * I + (int64_t)(kk & ((1ull << ibits) - 1ull))] = (int32_t)(t - lo + 1);
-  }
-}
-
 static int bits_for(uint64_t v) {  // bits needed to represent values 0..v
   int b = 1;
   while ((v >> b) != 0) ++b;
@@ -453,69 +421,6 @@ int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
   c->plan_pos = pos_out;
   c->plan_n = n;
   c->plan_chunk = chunk;
-  c->plan_perm_valid = false;
-  if (c->defer_pos != 0) {
-    // stable radix sort of (chunk, positive) with the triple index as payload; the key buffers of
-    // the first sort are free again (stream order)
-    if (c->plan_perm_cap < n) {
-      hipFree(c->plan_perm); hipFree(c->plan_iota);
-      hipFree(c->plan_pos_sorted); hipFree(c->plan_users_bypos);
-      c->plan_perm = c->plan_iota = c->plan_pos_sorted = c->plan_users_bypos = nullptr;
-      c->plan_perm_cap = 0;
-      BPR_HIP_CHECK(hipMalloc(&c->plan_perm, sizeof(int32_t) * n));
-      BPR_HIP_CHECK(hipMalloc(&c->plan_iota, sizeof(int32_t) * n));
-      BPR_HIP_CHECK(hipMalloc(&c->plan_pos_sorted, sizeof(int32_t) * n));
-      BPR_HIP_CHECK(hipMalloc(&c->plan_users_bypos, sizeof(int32_t) * n));
-      hipLaunchKernelGGL(k_iota32, dim3(grid), dim3(256), 0, c->stream, c->plan_iota, n);
-      c->plan_perm_cap = n;
-    }
-    const int ibits = bits_for((uint64_t)(c->I - 1));
-    if (c->plan_cnt_cap < n_chunks * c->I) {
-      hipFree(c->plan_cnt);
-      c->plan_cnt = nullptr;
-      c->plan_cnt_cap = 0;
-      BPR_HIP_CHECK(hipMalloc(&c->plan_cnt, sizeof(int32_t) * n_chunks * c->I));
-      c->plan_cnt_cap = n_chunks * c->I;
-    }
-    BPR_HIP_CHECK(hipMemsetAsync(c->plan_cnt, 0, sizeof(int32_t) * n_chunks * c->I, c->stream));
-    if (ibits + cbits <= 32) {  // the usual case: 32-bit keys halve the sort's traffic
-      uint32_t* k32 = reinterpret_cast<uint32_t*>(c->plan_keys);
-      uint32_t* k32s = reinterpret_cast<uint32_t*>(c->plan_keys_sorted);
-      size_t need = 0;
-      BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k32, k32s, c->plan_iota,
-                                                       c->plan_perm, (int)n, 0, ibits + cbits,
-                                                       c->stream));
-      if (need > c->plan_tmp_bytes) {
-        BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
-        hipFree(c->plan_tmp);
-        c->plan_tmp = nullptr;
-        BPR_HIP_CHECK(hipMalloc(&c->plan_tmp, need));
-        c->plan_tmp_bytes = need;
-      }
-      hipLaunchKernelGGL(k_plan_pos_keys<uint32_t>, dim3(grid), dim3(256), 0, c->stream, pos_out, n,
-                         chunk, ibits, k32);
-      size_t bytes2 = c->plan_tmp_bytes;
-      BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->plan_tmp, bytes2, k32, k32s, c->plan_iota,
-                                                       c->plan_perm, (int)n, 0, ibits + cbits,
-                                                       c->stream));
-      hipLaunchKernelGGL(k_plan_pos_counts<uint32_t>, dim3(grid), dim3(256), 0, c->stream, k32s, n,
-                         ibits, c->I, c->plan_cnt, c->plan_perm, users_out, c->plan_pos_sorted,
-                         c->plan_users_bypos);
-    } else {
-      hipLaunchKernelGGL(k_plan_pos_keys<uint64_t>, dim3(grid), dim3(256), 0, c->stream, pos_out, n,
-                         chunk, ibits, c->plan_keys);
-      size_t bytes2 = c->plan_tmp_bytes;
-      BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->plan_tmp, bytes2, c->plan_keys,
-                                                       c->plan_keys_sorted, c->plan_iota,
-                                                       c->plan_perm, (int)n, 0, ibits + cbits,
-                                                       c->stream));
-      hipLaunchKernelGGL(k_plan_pos_counts<uint64_t>, dim3(grid), dim3(256), 0, c->stream,
-                         c->plan_keys_sorted, n, ibits, c->I, c->plan_cnt, c->plan_perm, users_out,
-                         c->plan_pos_sorted, c->plan_users_bypos);
-    }
-    BPR_HIP_CHECK(hipGetLastError());
-    c->plan_perm_valid = true;
-  }
   return BPR_OK;
 }
 
@@ -538,21 +443,11 @@ __global__ void k_iota32(int32_t* __restrict__ ids, int64_t I) {
        k += (int64_t)gridDim.x * blockDim.x)
     ids[k] = (int32_t)k;
 }
-__global__ void k_hot_slots(const int32_t* __restrict__ by_count, const uint32_t* __restrict__ cnt,
-                            int H, int pad_item, int32_t* __restrict__ slot,
-                            int32_t* __restrict__ hot_items) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= H) return;
-  const int32_t it = by_count[s];
-  const bool ok = it != pad_item && cnt[s] > 0u;  // slot s stays unused otherwise
-  hot_items[s] = ok ? it : -1;
-  if (ok) slot[it] = s;
-}
-
 void hot_free(bpr_ctx* c) {
   hipFree(c->hot_slot);
   hipFree(c->hot_items);
-  hipFree(c->hot_delta);
+  hipFree(c->hot_delta_alloc);
+  c->hot_delta_alloc = nullptr;
   c->hot_slot = c->hot_items = nullptr;
   c->hot_delta = nullptr;
   c->hot_H = c->hot_R = 0;
@@ -560,6 +455,20 @@ void hot_free(bpr_ctx* c) {
   c->hot_key_n = 0;
 }
 
+// Channel model behind the slot assignment (tools/ubench/atomic_bench.hip): memory
+// is interleaved over HOT_CHANNELS channels in HOT_GRANULE-byte units, a row update sends one
+// atomic request per 128-byte line, and a STREAM launch lasts as long as its most loaded channel
+// (uniform popularity 0.185 ms; max/mean channel load 1.12 -> 0.207 ms, 1.455 -> 0.27 ms).
+constexpr int HOT_CHANNELS = 128;
+constexpr int64_t HOT_GRANULE = 256;
+static inline int channel_of(uint64_t byte_addr) {
+  return (int)((byte_addr / HOT_GRANULE) % HOT_CHANNELS);
+}
+
+// The H most popular rows take their STREAM updates in the delta block.  Which SLOT a row gets
+// decides which channels carry its load: the rows are placed greedily, heaviest first, each into
+// the free slot whose channels end up least loaded — counting the load the rows left in Q put on
+// every channel — so the block evens out the whole launch, not only itself.
 int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n) {
   hot_free(c);
   const int64_t I = c->I;
@@ -568,67 +477,188 @@ int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n) {
   c->hot_key_ptr = pos;
   c->hot_key_n = n;
   if (H <= 0 || R <= 0 || n <= 0) return BPR_OK;
-  uint32_t *counts = nullptr, *counts_sorted = nullptr;
-  int32_t *ids = nullptr, *ids_sorted = nullptr;
-  void* tmp = nullptr;
-  size_t bytes = 0;
+  uint32_t* counts = nullptr;
   BPR_HIP_CHECK(hipMalloc(&counts, sizeof(uint32_t) * I));
-  BPR_HIP_CHECK(hipMalloc(&counts_sorted, sizeof(uint32_t) * I));
-  BPR_HIP_CHECK(hipMalloc(&ids, sizeof(int32_t) * I));
-  BPR_HIP_CHECK(hipMalloc(&ids_sorted, sizeof(int32_t) * I));
-  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, counts, counts_sorted,
-                                                             ids, ids_sorted, (int)I, 0, 32,
-                                                             c->stream));
-  BPR_HIP_CHECK(hipMalloc(&tmp, bytes > 0 ? bytes : 16));
-  BPR_HIP_CHECK(hipMalloc(&c->hot_slot, sizeof(int32_t) * I));
-  BPR_HIP_CHECK(hipMalloc(&c->hot_items, sizeof(int32_t) * H));
-  BPR_HIP_CHECK(hipMalloc(&c->hot_delta, sizeof(float) * (size_t)R * H * c->d));
   BPR_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * I, c->stream));
-  BPR_HIP_CHECK(hipMemsetAsync(c->hot_slot, 0xff, sizeof(int32_t) * I, c->stream));
-  BPR_HIP_CHECK(hipMemsetAsync(c->hot_delta, 0, sizeof(float) * (size_t)R * H * c->d, c->stream));
   const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
   hipLaunchKernelGGL(k_item_hist, dim3(grid), dim3(256), 0, c->stream, pos, n, I, counts);
-  hipLaunchKernelGGL(k_iota32, dim3(64), dim3(256), 0, c->stream, ids, I);
-  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(tmp, bytes, counts, counts_sorted, ids,
-                                                             ids_sorted, (int)I, 0, 32, c->stream));
-  hipLaunchKernelGGL(k_hot_slots, dim3((H + 255) / 256), dim3(256), 0, c->stream, ids_sorted,
-                     counts_sorted, H, c->pad_item, c->hot_slot, c->hot_items);
-  BPR_HIP_CHECK(hipGetLastError());
-  BPR_HIP_CHECK(hipStreamSynchronize(c->stream));  // one-time setup: the scratch is freed below
+  std::vector<uint32_t> cnt((size_t)I);
+  BPR_HIP_CHECK(hipMemcpyAsync(cnt.data(), counts, sizeof(uint32_t) * I, hipMemcpyDeviceToHost,
+                               c->stream));
+  BPR_HIP_CHECK(hipStreamSynchronize(c->stream));  // one-time setup per training set
   hipFree(counts);
-  hipFree(counts_sorted);
-  hipFree(ids);
-  hipFree(ids_sorted);
-  hipFree(tmp);
+  // the H most popular rows (ties by ascending id; the pad row and rows nobody likes stay out)
+  std::vector<int32_t> by((size_t)I);
+  for (int64_t i = 0; i < I; ++i) by[i] = (int32_t)i;
+  if (c->pad_item >= 0 && c->pad_item < I) cnt[c->pad_item] = 0;
+  std::partial_sort(by.begin(), by.begin() + H, by.end(), [&](int32_t x, int32_t y) {
+    return cnt[x] != cnt[y] ? cnt[x] > cnt[y] : x < y;
+  });
+  while (H > 0 && cnt[by[H - 1]] == 0) --H;
+  if (H == 0) return BPR_OK;
+  // the block starts on a channel-round boundary so that slot -> channels is known
+  const size_t round_bytes = (size_t)HOT_CHANNELS * HOT_GRANULE;
+  const size_t block_bytes = sizeof(float) * (size_t)R * H * c->d;
+  BPR_HIP_CHECK(hipMalloc(&c->hot_delta_alloc, block_bytes + round_bytes));
+  c->hot_delta = reinterpret_cast<float*>(((uintptr_t)c->hot_delta_alloc + round_bytes - 1) /
+                                          round_bytes * round_bytes);
+  BPR_HIP_CHECK(hipMemsetAsync(c->hot_delta, 0, block_bytes, c->stream));
+  const int64_t row_bytes = (int64_t)c->d * 4;
+  const int lines = (int)((row_bytes + 127) / 128);
+  // expected line requests per row and launch: its positives, plus the negatives — close to
+  // uniform over the items under both samplers (profiles/r03_neg_hist.txt)
+  const double neg_share = (double)n / (double)(I - 1);
+  std::vector<char> is_hot((size_t)I, 0);
+  for (int k = 0; k < H; ++k) is_hot[by[k]] = 1;
+  double load[HOT_CHANNELS] = {0.0};
+  const uint64_t qbase = (uint64_t)(uintptr_t)c->Q;
+  for (int64_t i = 1; i < I; ++i) {
+    if (is_hot[i]) continue;
+    const double w = (double)cnt[i] + neg_share;
+    for (int l = 0; l < lines; ++l) load[channel_of(qbase + (uint64_t)(i * row_bytes + l * 128))] += w;
+  }
+  std::vector<int32_t> slot_of((size_t)I, -1), item_of((size_t)H, -1);
+  std::vector<char> used((size_t)H, 0);
+  const uint64_t hbase = (uint64_t)(uintptr_t)c->hot_delta;
+  static const bool naive = getenv("BPR_HOT_NAIVE") != nullptr;  // measurement aid: slot = rank
+  for (int k = 0; k < H; ++k) {
+    const int32_t it = by[k];
+    const double w = (double)cnt[it] + neg_share;
+    int best = -1;
+    double best_cost = 0.0;
+    for (int s = 0; s < H && !naive; ++s) {
+      if (used[s]) continue;
+      double cost = 0.0;  // the most loaded channel among the slot's lines, after the row moved in
+      for (int l = 0; l < lines; ++l)
+        cost = std::max(cost, load[channel_of(hbase + (uint64_t)(s * row_bytes + l * 128))] + w);
+      if (best < 0 || cost < best_cost) {
+        best = s;
+        best_cost = cost;
+      }
+    }
+    if (naive) best = k;
+    used[best] = 1;
+    slot_of[it] = best;
+    item_of[best] = it;
+    for (int l = 0; l < lines; ++l)
+      load[channel_of(hbase + (uint64_t)(best * row_bytes + l * 128))] += w;
+  }
+  {
+    double mx = 0.0, sum = 0.0;
+    for (double v : load) {
+      mx = std::max(mx, v);
+      sum += v;
+    }
+    c->hot_balance = sum > 0.0 ? mx / (sum / HOT_CHANNELS) : 1.0;
+    if (getenv("BPR_HOT_VERBOSE"))
+      fprintf(stderr, "[bprcore] hot block: %d rows, modelled channel load max/mean = %.3f\n", H,
+              c->hot_balance);
+  }
+  BPR_HIP_CHECK(hipMalloc(&c->hot_slot, sizeof(int32_t) * I));
+  BPR_HIP_CHECK(hipMalloc(&c->hot_items, sizeof(int32_t) * H));
+  BPR_HIP_CHECK(hipMemcpyAsync(c->hot_slot, slot_of.data(), sizeof(int32_t) * I,
+                               hipMemcpyHostToDevice, c->stream));
+  BPR_HIP_CHECK(hipMemcpyAsync(c->hot_items, item_of.data(), sizeof(int32_t) * H,
+                               hipMemcpyHostToDevice, c->stream));
+  BPR_HIP_CHECK(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
   c->hot_H = H;
   c->hot_R = R;
   return BPR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Heavy users' seen bitmaps (bpr_device.h SeenBitmap / SeenList): users with more than T seen
+// items get an I-bit row in HBM, filled once per seen CSR.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_heavy_mark(const int64_t* __restrict__ indptr, int64_t U, int T, uint32_t words,
+                             uint32_t* __restrict__ off, uint32_t* __restrict__ counter) {
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U;
+       u += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cnt = indptr[u + 1] - indptr[u];
+    off[u] = cnt > (int64_t)T ? atomicAdd(counter, 1u) * words : 0xFFFFFFFFu;
+  }
+}
+__global__ void k_heavy_fill(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                             int64_t U, const uint32_t* __restrict__ off,
+                             uint32_t* __restrict__ bits) {
+  for (int64_t u = blockIdx.x; u < U; u += gridDim.x) {  // a block per user (the few heavy ones work)
+    const uint32_t o = off[u];
+    if (o == 0xFFFFFFFFu) continue;
+    const int64_t lo = indptr[u], hi = indptr[u + 1];
+    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+      const int32_t it = indices[k];
+      atomicOr(&bits[o + (uint32_t)(it >> 5)], 1u << (it & 31));
+    }
+  }
+}
+
+void heavy_free(bpr_ctx* c) {
+  hipFree(c->heavy_off);
+  hipFree(c->heavy_bits);
+  c->heavy_off = c->heavy_bits = nullptr;
+  c->heavy_n = 0;
+  c->heavy_for = nullptr;
+}
+
+int heavy_build_impl(bpr_ctx* c) {
+  if (c->heavy_for == c->indptr) return BPR_OK;
+  heavy_free(c);
+  c->heavy_for = c->indptr;
+  const char* te = getenv("BPR_HEAVY_T");  // measurements: -1 = no heavy table
+  int T = te ? atoi(te) : 256;
+  if (T < 0 || c->indptr == nullptr) return BPR_OK;
+  const uint32_t words = (uint32_t)(((c->I + 31) / 32 + 3) / 4 * 4);
+  uint32_t* counter = nullptr;
+  BPR_HIP_CHECK(hipMalloc(&counter, sizeof(uint32_t)));
+  BPR_HIP_CHECK(hipMalloc(&c->heavy_off, sizeof(uint32_t) * c->U));
+  const unsigned grid = (unsigned)std::min<int64_t>((c->U + 255) / 256, 2048);
+  uint32_t n_heavy = 0;
+  for (;;) {  // at most 2^31 words (8 GB) of bitmaps: raise the threshold until they fit
+    BPR_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_heavy_mark, dim3(grid), dim3(256), 0, c->stream, c->indptr, c->U, T, words,
+                       c->heavy_off, counter);
+    BPR_HIP_CHECK(hipMemcpyAsync(&n_heavy, counter, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                 c->stream));
+    BPR_HIP_CHECK(hipStreamSynchronize(c->stream));  // one-time setup per seen CSR
+    if ((uint64_t)n_heavy * words < ((uint64_t)1 << 31)) break;
+    T *= 2;
+  }
+  hipFree(counter);
+  c->heavy_T = T;
+  c->heavy_n = n_heavy;
+  if (n_heavy == 0) {
+    hipFree(c->heavy_off);
+    c->heavy_off = nullptr;
+    return BPR_OK;
+  }
+  const size_t bytes = sizeof(uint32_t) * (size_t)n_heavy * words;
+  BPR_HIP_CHECK(hipMalloc(&c->heavy_bits, bytes));
+  BPR_HIP_CHECK(hipMemsetAsync(c->heavy_bits, 0, bytes, c->stream));
+  hipLaunchKernelGGL(k_heavy_fill, dim3((unsigned)std::min<int64_t>(c->U, 65535)), dim3(256), 0,
+                     c->stream, c->indptr, c->indices, c->U, c->heavy_off, c->heavy_bits);
+  BPR_HIP_CHECK(hipGetLastError());
+  if (getenv("BPR_HOT_VERBOSE"))
+    fprintf(stderr, "[bprcore] heavy users (> %d seen items): %u, %.1f MB of bitmaps\n", T, n_heavy,
+            bytes / 1e6);
+  return BPR_OK;
+}
+
 void refresh_free(bpr_ctx* c) {
   hot_free(c);
+  heavy_free(c);
   hipFree(c->plan_keys);
   hipFree(c->plan_keys_sorted);
   hipFree(c->plan_tmp);
   c->plan_keys = c->plan_keys_sorted = nullptr;
   c->plan_tmp = nullptr;
   c->plan_cap = 0;
-  hipFree(c->plan_perm);
-  hipFree(c->plan_iota);
-  hipFree(c->plan_pos_sorted);
-  hipFree(c->plan_users_bypos);
-  c->plan_pos_sorted = c->plan_users_bypos = nullptr;
-  hipFree(c->plan_cnt);
-  c->plan_cnt = nullptr;
-  c->plan_cnt_cap = 0;
-  hipFree(c->wbuf);
-  c->plan_perm = c->plan_iota = nullptr;
-  c->wbuf = nullptr;
-  c->plan_perm_cap = c->wbuf_cap = 0;
-  c->plan_perm_valid = false;
-  hipFree(c->order_alloc);
-  c->order_alloc = nullptr;
-  hipFree(c->sigma);
+  if (c->side != nullptr) hipStreamSynchronize(c->side);
+  for (int k = 0; k < 2; ++k) {
+    hipFree(c->order_alloc[k]);
+    hipFree(c->sigma_buf[k]);
+    c->order_alloc[k] = nullptr;
+    c->sigma_buf[k] = nullptr;
+  }
   hipFree(c->keysT);
   hipFree(c->keys_sorted);
   hipFree(c->ids_in);
@@ -643,9 +673,26 @@ void refresh_free(bpr_ctx* c) {
   c->sort_tmp = nullptr;
   c->sort_tmp_bytes = 0;
   c->have_snapshot = false;
+  c->refresh_pending = false;
 }
 
-int refresh_impl(bpr_ctx* c) {
+void side_free(bpr_ctx* c) {  // bpr_ctx_destroy: the split refresh's events and (if ours) stream
+  if (c->ev_keys) hipEventDestroy(c->ev_keys);
+  if (c->ev_sorted) hipEventDestroy(c->ev_sorted);
+  c->ev_keys = c->ev_sorted = nullptr;
+  if (c->side_owned && c->side) hipStreamDestroy(c->side);
+  c->side = nullptr;
+  c->side_owned = false;
+}
+
+// The snapshot is taken in two steps.  CUT: k_transpose copies Q into the key buffer on the
+// caller's stream — that instant is the snapshot's point in time.  SORT: the per-factor orders and
+// sigma of those keys go to the BACK snapshot.  split = false: sort on the caller's stream and swap
+// (AdaptiveSampler.update_stats as the reference calls it).  split = true
+// (bpr_adaptive_refresh_begin): the sort runs on c->side behind an event, the caller's stream goes
+// on — typically with the next STREAM launch, which is bound by the L2 atomic units and leaves the
+// CUs mostly idle — and refresh_commit_impl (bpr_adaptive_refresh_commit) orders the swap.
+int refresh_impl(bpr_ctx* c, bool split) {
   const int64_t I = c->I;
   const int d = c->d;
   const int64_t n = (int64_t)d * I;
@@ -657,12 +704,20 @@ int refresh_impl(bpr_ctx* c) {
     set_error("bpr_adaptive_refresh: need at least 3 item rows");
     return BPR_ERR_INVALID;
   }
-  if (c->order == nullptr) {
-    BPR_HIP_CHECK(hipMalloc(&c->order_alloc, sizeof(int32_t) * (n + 2 * BPR_ORDER_PAD)));
-    BPR_HIP_CHECK(hipMemsetAsync(c->order_alloc, 0, sizeof(int32_t) * (n + 2 * BPR_ORDER_PAD),
-                                 c->stream));
-    c->order = c->order_alloc + BPR_ORDER_PAD;
-    BPR_HIP_CHECK(hipMalloc(&c->sigma, sizeof(float) * d));
+  if (c->refresh_pending) {
+    set_error("bpr_adaptive_refresh: a split refresh is pending (bpr_adaptive_refresh_commit first)");
+    return BPR_ERR_INVALID;
+  }
+  if (c->order_alloc[0] == nullptr) {
+    for (int k = 0; k < 2; ++k) {
+      BPR_HIP_CHECK(hipMalloc(&c->order_alloc[k], sizeof(int32_t) * (n + 2 * BPR_ORDER_PAD)));
+      BPR_HIP_CHECK(hipMemsetAsync(c->order_alloc[k], 0, sizeof(int32_t) * (n + 2 * BPR_ORDER_PAD),
+                                   c->stream));
+      BPR_HIP_CHECK(hipMalloc(&c->sigma_buf[k], sizeof(float) * d));
+    }
+    c->snap_front = 0;
+    c->order = c->order_alloc[0] + BPR_ORDER_PAD;
+    c->sigma = c->sigma_buf[0];
     BPR_HIP_CHECK(hipMalloc(&c->keysT, sizeof(float) * n));
     BPR_HIP_CHECK(hipMalloc(&c->keys_sorted, sizeof(uint64_t) * 2 * n));  // composite keys in|out
     BPR_HIP_CHECK(hipMalloc(&c->ids_in, sizeof(int32_t) * n));
@@ -677,9 +732,28 @@ int refresh_impl(bpr_ctx* c) {
     BPR_HIP_CHECK(hipMalloc(&c->sort_tmp, bytes > 0 ? bytes : 16));
     c->sort_tmp_bytes = bytes;
   }
+  const int back = c->have_snapshot ? (c->snap_front ^ 1) : c->snap_front;
+  int32_t* const order = c->order_alloc[back] + BPR_ORDER_PAD;
+  float* const sigma = c->sigma_buf[back];
+  // ---- cut
   dim3 tgrid((unsigned)((I + 31) / 32), (unsigned)((d + 31) / 32));
   hipLaunchKernelGGL(k_transpose, tgrid, dim3(256), 0, c->stream, c->Q, c->keysT, I, d,
                      c->sig_acc);
+  hipStream_t st = c->stream;
+  if (split) {
+    if (c->side == nullptr) {
+      BPR_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+      c->side_owned = true;
+    }
+    if (c->ev_keys == nullptr) {
+      BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
+      BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
+    }
+    BPR_HIP_CHECK(hipEventRecord(c->ev_keys, c->stream));
+    BPR_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_keys, 0));
+    st = c->side;
+  }
+  // ---- sort
   static const bool no_fast = getenv("BPR_NO_FAST_REFRESH") != nullptr;
   const char* fs = getenv("BPR_REFRESH_SUB");  // tests force the split/merge paths on small tables
   const int force_sub = fs ? atoi(fs) : 0;
@@ -687,10 +761,13 @@ int refresh_impl(bpr_ctx* c) {
   // split over 2 or 4 workgroups — sorted runs merged pairwise by k_merge_runs — when they do not
   // fit, or when d workgroups would leave CUs idle and the pieces stay >= 5,000 keys (measured on
   // ML-20M, refresh + launch gaps per step: d=128 0.106 -> 0.095 ms with 2, d=64 0.100 -> 0.079 ms
-  // with 4; d=256 and Netflix's 4.8 k-item columns are fastest unsplit).
+  // with 4; d=256 and Netflix's 4.8 k-item columns are fastest unsplit).  A split refresh shares
+  // the chip with the caller's kernels: it keeps the columns whole (fewer, longer workgroups and
+  // no merge pass) whenever they fit.
   int sub = 1;
   while (sub < 4 && (I + sub - 1) / sub > 1024 * 36) sub *= 2;
-  while (sub < 4 && d * sub < 256 && I / (2 * sub) >= 5000) sub *= 2;
+  if (!split)
+    while (sub < 4 && d * sub < 256 && I / (2 * sub) >= 5000) sub *= 2;
   if (force_sub == 1 || force_sub == 2 || force_sub == 4) sub = force_sub;
   int64_t len = (I + sub - 1) / sub;
   len = (len + 15) / 16 * 16;
@@ -700,39 +777,60 @@ int refresh_impl(bpr_ctx* c) {
     float* keysB = reinterpret_cast<float*>(idsA + n);
     int32_t* idsB = reinterpret_cast<int32_t*>(keysB + n);
     const int items = (int)((len + 1023) / 1024);
-    if (items <= 6) launch_sort_sub<6>(c, sub, len, keysA, idsA);
-    else if (items <= 10) launch_sort_sub<10>(c, sub, len, keysA, idsA);
-    else if (items <= 12) launch_sort_sub<12>(c, sub, len, keysA, idsA);
-    else if (items <= 16) launch_sort_sub<16>(c, sub, len, keysA, idsA);
-    else if (items <= 20) launch_sort_sub<20>(c, sub, len, keysA, idsA);
-    else if (items <= 24) launch_sort_sub<24>(c, sub, len, keysA, idsA);
-    else if (items <= 28) launch_sort_sub<28>(c, sub, len, keysA, idsA);
-    else launch_sort_sub<36>(c, sub, len, keysA, idsA);
+    if (items <= 6) launch_sort_sub<6>(c, st, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 10) launch_sort_sub<10>(c, st, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 12) launch_sort_sub<12>(c, st, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 16) launch_sort_sub<16>(c, st, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 20) launch_sort_sub<20>(c, st, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 24) launch_sort_sub<24>(c, st, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 28) launch_sort_sub<28>(c, st, order, sigma, sub, len, keysA, idsA);
+    else launch_sort_sub<36>(c, st, order, sigma, sub, len, keysA, idsA);
     int64_t run = len;
     for (int level = sub; level > 1; level /= 2, run *= 2) {
       const int last = level == 2;
       const int tiles_per_pair = (int)((2 * run + MERGE_TILE - 1) / MERGE_TILE);
       const unsigned mgrid = (unsigned)(((I + 2 * run - 1) / (2 * run)) * tiles_per_pair);
-      hipLaunchKernelGGL(k_merge_runs, dim3(mgrid, d), dim3(MERGE_THREADS), 0, c->stream, keysA,
-                         idsA, I, run, tiles_per_pair, keysB, last ? c->order : idsB, last,
-                         c->sigma, c->sig_acc);
+      hipLaunchKernelGGL(k_merge_runs, dim3(mgrid, d), dim3(MERGE_THREADS), 0, st, keysA, idsA, I,
+                         run, tiles_per_pair, keysB, last ? order : idsB, last, sigma, c->sig_acc);
       std::swap(keysA, keysB);
       std::swap(idsA, idsB);
     }
     BPR_HIP_CHECK(hipGetLastError());
-    c->have_snapshot = true;
+  } else {
+    hipLaunchKernelGGL(k_sigma, dim3(d), dim3(256), 0, st, c->keysT, I, sigma);
+    uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
+    hipLaunchKernelGGL(k_compose_keys, dim3(2048), dim3(256), 0, st, c->keysT, k64, n, I);
+    int key_bits = 32;
+    while ((1 << (key_bits - 32)) < d) ++key_bits;
+    size_t bytes = c->sort_tmp_bytes;
+    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp, bytes, k64, k64 + n, c->ids_in,
+                                                     order, (int)n, 0, key_bits, st));
+    BPR_HIP_CHECK(hipGetLastError());
+  }
+  if (split) {
+    BPR_HIP_CHECK(hipEventRecord(c->ev_sorted, c->side));
+    c->refresh_pending = true;
     return BPR_OK;
   }
-  hipLaunchKernelGGL(k_sigma, dim3(d), dim3(256), 0, c->stream, c->keysT, I, c->sigma);
-  uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
-  hipLaunchKernelGGL(k_compose_keys, dim3(2048), dim3(256), 0, c->stream, c->keysT, k64, n, I);
-  int key_bits = 32;
-  while ((1 << (key_bits - 32)) < d) ++key_bits;
-  size_t bytes = c->sort_tmp_bytes;
-  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp, bytes, k64, k64 + n, c->ids_in,
-                                                   c->order, (int)n, 0, key_bits, c->stream));
-  BPR_HIP_CHECK(hipGetLastError());
+  c->snap_front = back;
+  c->order = order;
+  c->sigma = sigma;
   c->have_snapshot = true;
+  return BPR_OK;
+}
+
+int refresh_commit_impl(bpr_ctx* c) {
+  if (!c->refresh_pending) {
+    set_error("bpr_adaptive_refresh_commit: no split refresh is pending");
+    return BPR_ERR_INVALID;
+  }
+  BPR_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_sorted, 0));
+  const int back = c->have_snapshot ? (c->snap_front ^ 1) : c->snap_front;
+  c->snap_front = back;
+  c->order = c->order_alloc[back] + BPR_ORDER_PAD;
+  c->sigma = c->sigma_buf[back];
+  c->have_snapshot = true;
+  c->refresh_pending = false;
   return BPR_OK;
 }
 

@@ -561,16 +561,17 @@ __global__ __launch_bounds__(256, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void k_vstrea
           Seen seen;
           if constexpr (SEEN == SEEN_BITMAP) {
             seen_bitmap_build<G>(lds, a.bm_words, a.indices, lo, hi, gl);
-            seen = SeenBitmap{lds};
+            seen = SeenBitmap{lds, nullptr, NOT_HEAVY};
           } else if constexpr (SEEN == SEEN_LIST) {
             const int32_t ln = seen_list_build<G>(lds, a.bm_words, a.indices, lo, hi, gl);
-            seen = SeenList{reinterpret_cast<const int32_t*>(lds), ln, a.indices, lo, hi};
+            seen = SeenList{reinterpret_cast<const int32_t*>(lds), ln, a.indices, lo, hi, nullptr,
+                            NOT_HEAVY};
           } else {
             seen = SeenCsr{a.indices, lo, hi};
           }
           const uint64_t ctr = a.offset + (uint64_t)kk;
           if constexpr (SAMPLER == NEG_UNIFORM) {
-            j = sample_uniform<G>(seen, a.I, a.seed, ctr, lane, a.iw);
+            j = sample_uniform<G>(seen, hi - lo, a.indices + lo, a.I, a.seed, ctr, lane, a.iw);
           } else {
             float p[E], sg[E];
 #pragma unroll

@@ -218,13 +218,20 @@ static int launch_triples(bpr_ctx* c, TripleArgs a, bool timed) {
 // STREAM: one group per run of a.run_len triples; max_inflight caps the number of groups (= triples
 // in flight).  A cap below one 256-thread block shrinks the block (whole waves), so
 // max_inflight = 1 at G = 64 really is ONE wave walking the stream sequentially.
-static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_groups, float* out_scalars,
-                         const PosPassArgs* pp = nullptr) {
+static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_groups,
+                         float* out_scalars) {
   if (a.n <= 0) return BPR_OK;
   return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
     constexpr int G = T::G, E = T::E;
     const int64_t n_runs = (a.n + a.run_len - 1) / a.run_len;
+    // look-ahead of the run boundaries (k_stream): the view of a run — run_len + look + 1 triples
+    // and the predecessor — is held one triple per lane of the group
+    a.look = std::max(0, std::min({STREAM_LOOK_MAX, a.run_len - 1, G - 2 - a.run_len}));
+    {
+      const char* le = getenv("BPR_STREAM_LOOK");  // tests / measurements: 0 = nominal runs
+      if (le != nullptr) a.look = std::max(0, std::min(a.look, atoi(le)));
+    }
     unsigned block = 256;
     a.gpw_active = 64 / G;
     if (cap_groups > 0 && cap_groups * G < 256) {
@@ -275,14 +282,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       (void)tm;
       auto go = [&](auto smp, auto sn) {
         constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
-        if (a.defer != 0) {
-          if (c->d == G * E)
-            hipLaunchKernelGGL((k_stream<G, E, SMP, SN, true, true>), dim3(grid), dim3(block), shmem,
-                               c->stream, a);
-          else
-            hipLaunchKernelGGL((k_stream<G, E, SMP, SN, false, true>), dim3(grid), dim3(block),
-                               shmem, c->stream, a);
-        } else if (c->d == G * E)
+        if (c->d == G * E)
           hipLaunchKernelGGL((k_stream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
                              c->stream, a);
         else
@@ -301,7 +301,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       else with_seen(integral_constant<int, NEG_ADAPTIVE>{});
     }
     const bool hot = a.hot_slot != nullptr;
-    if (out_scalars != nullptr || hot || pp != nullptr) {
+    if (out_scalars != nullptr || hot) {
       EpilogueArgs ea;
       memset(&ea, 0, sizeof(ea));
       ea.partials = a.partials; ea.n_blocks = (int)grid; ea.out = out_scalars;
@@ -309,27 +309,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       ea.H = hot ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d;
       ea.fold_blocks =
           hot ? (int)std::min<int64_t>(((int64_t)c->hot_H * c->d + 255) / 256, 64) : 0;
-      unsigned shrink_blocks = 0;
-      if (pp != nullptr) {  // L2 term of the deferred positive updates
-        ea.pos_cnt = c->plan_cnt + (pp->off / c->plan_chunk) * c->I;
-        ea.hot_slot = a.hot_slot;
-        ea.I = (int32_t)c->I; ea.pad_item = c->pad_item;
-        ea.shrink_hot = pp->mode == 2;
-        ea.lr_ai = c->opt.lr * c->ai;
-        shrink_blocks = (unsigned)std::min<int64_t>((c->I * c->d / 4 + 255) / 256, 2048);
-      }
-      hipLaunchKernelGGL(k_stream_epilogue, dim3(1 + ea.fold_blocks + shrink_blocks), dim3(256), 0,
-                         c->stream, ea);
-    }
-    // deferred positives: the item-major pass over this chunk, after the hot rows' delta rows were
-    // folded (it reads the positive rows as they are now)
-    if (pp != nullptr) {
-      const int64_t runs = (pp->n + pos_run_len<E>() - 1) / pos_run_len<E>();
-      const int64_t per_blk = 256 / G;
-      int64_t pblk = (runs + per_blk - 1) / per_blk;
-      if (cap_groups > 0) pblk = std::min<int64_t>(pblk, (cap_groups + per_blk - 1) / per_blk);
-      hipLaunchKernelGGL((k_pos_pass<G, E>), dim3((unsigned)std::max<int64_t>(pblk, 1)), dim3(256),
-                         0, c->stream, *pp);
+      hipLaunchKernelGGL(k_stream_epilogue, dim3(1 + ea.fold_blocks), dim3(256), 0, c->stream, ea);
     }
     BPR_HIP_CHECK(hipGetLastError());
     return BPR_OK;
@@ -403,10 +383,6 @@ int bpr_ctx_create(bpr_ctx** out, int device_id, void* hip_stream) {
   bpr_ctx* c = new (std::nothrow) bpr_ctx();
   if (c == nullptr) return fail(BPR_ERR_NOMEM, "bpr_ctx_create: out of host memory");
   c->device = device_id;
-  if (const char* dp = getenv("BPR_DEFER_POS")) {  // default of bpr_set_defer_positives (tests, studies)
-    const int m = atoi(dp);
-    if (m >= 0 && m <= 2) c->defer_pos = m;
-  }
   c->stream = (hipStream_t)hip_stream;
   if (hipMalloc(&c->dev_scalars, sizeof(float) * 4 * (size_t)(STREAM_MAX_GRID + 1)) != hipSuccess) {
     delete c;
@@ -422,6 +398,7 @@ int bpr_ctx_destroy(bpr_ctx* c) {
   hipStreamSynchronize(c->stream);
   free_strict_scratch(c);
   refresh_free(c);
+  side_free(c);
   vs_free(c);
   hipFree(c->dev_scalars);
   for (auto e : c->ev_start) hipEventDestroy(e);
@@ -470,6 +447,7 @@ int bpr_bind_seen_csr(bpr_ctx* c, const int64_t* indptr, const int32_t* indices)
     return fail(BPR_ERR_INVALID, "bpr_bind_seen_csr: NULL argument");
   c->indptr = indptr;
   c->indices = indices;
+  c->heavy_for = nullptr;  // the heavy users' bitmaps belong to the CSR bound before: rebuilt lazily
   return BPR_OK;
 }
 
@@ -594,7 +572,62 @@ int bpr_adaptive_refresh(bpr_ctx* c) {
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->vs_active)  // batched STREAM: the snapshot must see the item rows as of "now"
     if (int rc = vs_flush(c, false, true)) return rc;
-  return refresh_impl(c);
+  return refresh_impl(c, false);
+}
+
+int bpr_adaptive_refresh_begin(bpr_ctx* c) {
+  if (int rc = check_bound(c, "bpr_adaptive_refresh_begin")) return rc;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (c->vs_active)
+    if (int rc = vs_flush(c, false, true)) return rc;
+  return refresh_impl(c, true);
+}
+
+int bpr_adaptive_refresh_commit(bpr_ctx* c) {
+  if (int rc = check_bound(c, "bpr_adaptive_refresh_commit")) return rc;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  return refresh_commit_impl(c);
+}
+
+int bpr_adaptive_refresh_pending(bpr_ctx* c, int32_t* pending_host) {
+  if (c == nullptr || pending_host == nullptr)
+    return fail(BPR_ERR_INVALID, "bpr_adaptive_refresh_pending: NULL argument");
+  *pending_host = c->refresh_pending ? 1 : 0;
+  return BPR_OK;
+}
+
+int bpr_set_side_stream(bpr_ctx* c, void* hip_stream) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_side_stream: ctx is NULL");
+  if (c->refresh_pending)
+    return fail(BPR_ERR_INVALID, "bpr_set_side_stream: a split refresh is pending");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (c->side != nullptr) {
+    BPR_HIP_CHECK(hipStreamSynchronize(c->side));
+    if (c->side_owned) hipStreamDestroy(c->side);
+  }
+  c->side = (hipStream_t)hip_stream;
+  c->side_owned = false;
+  return BPR_OK;
+}
+
+int bpr_stream_create(int device_id, const uint32_t* cu_mask, int32_t mask_words, void** stream_out) {
+  if (stream_out == nullptr || mask_words < 0 || (mask_words > 0 && cu_mask == nullptr))
+    return fail(BPR_ERR_INVALID, "bpr_stream_create: bad argument");
+  BPR_HIP_CHECK(hipSetDevice(device_id));
+  hipStream_t st = nullptr;
+  if (mask_words == 0)
+    BPR_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  else
+    BPR_HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask_words, cu_mask));
+  *stream_out = (void*)st;
+  return BPR_OK;
+}
+
+int bpr_stream_destroy(void* hip_stream) {
+  if (hip_stream == nullptr) return BPR_OK;
+  BPR_HIP_CHECK(hipStreamSynchronize((hipStream_t)hip_stream));
+  BPR_HIP_CHECK(hipStreamDestroy((hipStream_t)hip_stream));
+  return BPR_OK;
 }
 
 int bpr_sample_adaptive(bpr_ctx* c, const int32_t* users, int64_t B, float p, uint64_t seed,
@@ -728,8 +761,9 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
   if (int rc = check_sampler(c, "bpr_train_stream", sampler, adaptive_p, neg, n)) return rc;
   if (c->opt_kind != BPR_OPT_SGD)
     return fail(BPR_ERR_UNSUPPORTED,
-                "bpr_train_stream: STREAM mode implements plain SGD only; use STRICT "
-                "(bpr_forward_grad + bpr_apply) for momentum / Adam / RMSprop");
+                "bpr_train_stream: this launch implements plain SGD only; momentum / Adam / RMSprop "
+                "run through bpr_train_stream_batched (one launch per refresh period) or STRICT "
+                "(bpr_forward_grad + bpr_apply)");
   if (c->pending != 0)
     return fail(BPR_ERR_INVALID, "bpr_train_stream: unapplied STRICT gradients pending");
   BPR_HIP_CHECK(hipSetDevice(c->device));
@@ -752,55 +786,22 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
   // runs of 4 below that (Netflix-sized periods of 40 k triples: 349 -> 409 M triples/s)
   a.run_len = c->run_len > 0 ? c->run_len : (n >= 8 * 12288 ? 8 : 4);
   a.grouped = c->grouped;
-  {
-    static const int dbg = getenv("BPR_DEBUG") ? atoi(getenv("BPR_DEBUG")) : 0;
-    a.dbg = dbg;
-  }
   a.au = c->au; a.ai = c->ai; a.an = c->an; a.lr = c->opt.lr;
   a.iw = ItemWeights{c->w_accept, c->w_alias};
   a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
-  if (c->hot_H > 0 && a.dbg != 1) {
+  if (sampler != BPR_NEG_GIVEN) {
+    if (int rc = heavy_build_impl(c)) return rc;
+    a.heavy_off = c->heavy_off;
+    a.heavy_bits = c->heavy_bits;
+    a.heavy_T = c->heavy_T;
+  }
+  if (c->hot_H > 0) {
     a.hot_slot = c->hot_slot;
     a.hot_delta = c->hot_delta;
     a.hot_H = c->hot_H;
     a.hot_rmask = c->hot_R - 1;
   }
-  // Deferred positives apply to launches that are (a prefix of) one chunk of the current plan:
-  // the by-positive order of exactly these triples is known.  Any other launch updates the
-  // positive rows immediately.
-  PosPassArgs pp;
-  bool defer = false;
-  if (c->defer_pos != 0 && c->plan_perm_valid && a.dbg == 0 && users >= c->plan_users &&
-      users < c->plan_users + c->plan_n) {
-    const int64_t off = users - c->plan_users;
-    const int64_t chunk_end = std::min(c->plan_n, (off / c->plan_chunk + 1) * c->plan_chunk);
-    // a prefix would need the chunk's order filtered: whole chunks only
-    defer = pos == c->plan_pos + off && off % c->plan_chunk == 0 && off + n == chunk_end &&
-            c->d % 4 == 0;
-    if (defer) {
-      if (c->wbuf_cap < n) {
-        BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
-        hipFree(c->wbuf);
-        c->wbuf = nullptr;
-        c->wbuf_cap = 0;
-        const int64_t cap = std::max(n, c->plan_chunk);
-        BPR_HIP_CHECK(hipMalloc(&c->wbuf, sizeof(float) * cap));
-        c->wbuf_cap = cap;
-      }
-      a.wbuf = c->wbuf;
-      a.defer = c->defer_pos;
-      memset(&pp, 0, sizeof(pp));
-      pp.P = c->P; pp.Q = c->Q;
-      pp.users = c->plan_users_bypos + off; pp.pos = c->plan_pos_sorted + off;
-      pp.perm = c->plan_perm + off;
-      pp.wbuf = c->wbuf;
-      pp.hot_slot = a.hot_slot;
-      pp.n = (int32_t)n; pp.off = (int32_t)off; pp.d = c->d;
-      pp.pad_item = c->pad_item; pp.mode = c->defer_pos;
-      pp.lr = c->opt.lr;
-    }
-  }
-  return launch_stream(c, a, sampler, max_inflight, out_scalars, defer ? &pp : nullptr);
+  return launch_stream(c, a, sampler, max_inflight, out_scalars);
 }
 
 int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t B,
@@ -929,21 +930,11 @@ int bpr_set_hot_rows(bpr_ctx* c, int32_t hot_rows, int32_t replicas) {
   return BPR_OK;
 }
 
-int bpr_set_defer_positives(bpr_ctx* c, int32_t mode) {
-  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_defer_positives: ctx is NULL");
-  if (mode < 0 || mode > 2)
-    return fail(BPR_ERR_INVALID, "bpr_set_defer_positives: mode must be 0 (off), 1 (rows outside "
-                                 "the hot block) or 2 (every positive row)");
-  c->defer_pos = mode;
-  if (mode == 0) c->plan_perm_valid = false;
-  return BPR_OK;
-}
-
 int bpr_set_stream_opts(bpr_ctx* c, int32_t grouped_by_user, int32_t run_len) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: ctx is NULL");
-  if (run_len < 0 || run_len > 30)
-    return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: run_len must be 0 (by launch size) or in [1, 30] (one lane of a "
-                                 "32-lane group per triple of the run, plus two neighbours)");
+  if (run_len < 0 || run_len > 24)
+    return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: run_len must be 0 (by launch size) or in [1, 24] (one lane of a "
+                                 "32-lane group per triple of the run and of its look-ahead, plus the predecessor)");
   c->grouped = grouped_by_user != 0;
   c->run_len = run_len;
   return BPR_OK;

@@ -15,7 +15,7 @@ from revisit_bpr import native
 from revisit_bpr.native import (MODE_STREAM, MODE_STRICT, NEG_ADAPTIVE, NEG_GIVEN, NEG_UNIFORM,
                                 OPT_ADAM, OPT_MOMENTUM, OPT_RMSPROP, OPT_SGD)
 
-__all__ = ["Engine", "resolve_reg_alphas", "MODE_STREAM", "MODE_STRICT", "NEG_ADAPTIVE",
+__all__ = ["Engine", "MaskedStream", "cu_mask", "resolve_reg_alphas", "MODE_STREAM", "MODE_STRICT", "NEG_ADAPTIVE",
            "NEG_GIVEN", "NEG_UNIFORM", "OPT_ADAM", "OPT_MOMENTUM", "OPT_RMSPROP", "OPT_SGD"]
 
 
@@ -56,6 +56,47 @@ def alias_table(weights: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         p[l_] -= 1.0 - p[s_]
         (small if p[l_] < 1.0 else large).append(l_)
     return torch.from_numpy(accept), torch.from_numpy(alias)
+
+
+def cu_mask(first: int, count: int, total: int = 256) -> list[int]:
+    """32-bit words of a CU mask with bits [first, first + count) set.  On MI300-class parts the
+    driver deals the mask bits round-robin over the XCDs (bit i -> XCD i % 8), so a contiguous bit
+    range takes the same number of CUs from every XCD."""
+    if not (0 <= first and 0 < count and first + count <= total):
+        raise ValueError("CU range out of bounds")
+    words = [0] * ((total + 31) // 32)
+    for b in range(first, first + count):
+        words[b // 32] |= 1 << (b % 32)
+    return words
+
+
+class MaskedStream:
+    """A HIP stream restricted to a set of CUs (hipExtStreamCreateWithCUMask through
+    ``bpr_stream_create``); `.torch` is the same stream as a torch.cuda.ExternalStream.  The split
+    refresh sorts on one while the STREAM kernel runs on the complementary one."""
+
+    def __init__(self, device: torch.device, mask_words: Optional[list[int]]) -> None:
+        self._lib = native.load()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        out = ctypes.c_void_p()
+        if mask_words:
+            arr = (ctypes.c_uint32 * len(mask_words))(*mask_words)
+            native.check(self._lib.bpr_stream_create(idx, arr, len(mask_words), ctypes.byref(out)))
+        else:
+            native.check(self._lib.bpr_stream_create(idx, None, 0, ctypes.byref(out)))
+        self.ptr = out.value
+        self.torch = torch.cuda.ExternalStream(self.ptr, device=torch.device("cuda", idx))
+
+    def close(self) -> None:
+        if getattr(self, "ptr", None):
+            self._lib.bpr_stream_destroy(ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -183,8 +224,32 @@ class Engine:
         return out
 
     def adaptive_refresh(self) -> None:
+        """AdaptiveSampler.update_stats: snapshot of the item table as of now, in stream order."""
         self._sync_stream()
         native.check(self._lib.bpr_adaptive_refresh(self._ctx))
+
+    def adaptive_refresh_begin(self) -> None:
+        """Split refresh, first half: the snapshot's keys are cut from the item table NOW (stream
+        order) and sorted on the side stream while this stream keeps working; the samplers keep
+        reading the previous snapshot until `adaptive_refresh_commit`."""
+        self._sync_stream()
+        native.check(self._lib.bpr_adaptive_refresh_begin(self._ctx))
+
+    def adaptive_refresh_commit(self) -> None:
+        """Split refresh, second half: launches after this call read the snapshot cut by the last
+        `adaptive_refresh_begin` (this stream waits for the side stream's sort)."""
+        self._sync_stream()
+        native.check(self._lib.bpr_adaptive_refresh_commit(self._ctx))
+
+    def refresh_pending(self) -> bool:
+        out = ctypes.c_int32(0)
+        native.check(self._lib.bpr_adaptive_refresh_pending(self._ctx, ctypes.byref(out)))
+        return bool(out.value)
+
+    def set_side_stream(self, stream: Optional["MaskedStream"]) -> None:
+        """The stream the split refresh sorts on (None: a plain stream owned by the library)."""
+        self._keep["side_stream"] = stream
+        native.check(self._lib.bpr_set_side_stream(self._ctx, None if stream is None else stream.ptr))
 
     def sample_adaptive(self, users: torch.Tensor, p: float, seed: int, offset: int = 0,
                         return_draws: bool = False):
@@ -340,12 +405,6 @@ class Engine:
 
     def set_stream_opts(self, grouped_by_user: bool, run_len: int = 0) -> None:
         native.check(self._lib.bpr_set_stream_opts(self._ctx, int(grouped_by_user), run_len))
-
-    def set_defer_positives(self, mode: int) -> None:
-        """STREAM: apply the positive rows' updates once per chunk in an item-major second pass
-        (0 off, 1 rows outside the hot block, 2 every positive row); takes effect at the next
-        plan_epoch and for launches over whole chunks of that plan."""
-        native.check(self._lib.bpr_set_defer_positives(self._ctx, int(mode)))
 
     def set_hot_rows(self, hot_rows: int = 256, replicas: int = 1) -> None:
         """Replica delta rows for the most popular item rows in STREAM mode (0 = off); takes

@@ -22,16 +22,26 @@ class StreamTrainer:
                  adaptive_p: float = 0.01, batch_size: int = 256, seed: int = 13,
                  max_inflight: Optional[int] = None, run_len: int = 0, rank: int = 0,
                  item_sync=None, sync_every: int = 1, world: Optional[int] = None,
-                 defer_positives: Optional[int] = None) -> None:
+                 refresh_lag: float = 0.0, refresh_split: int = 1, refresh_cus: int = 0) -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
         adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302.
-        `defer_positives` (extension, default off): 1 / 2 = positive rows take their summed update
-        once per chunk in an item-major pass (``bpr_set_defer_positives``): ~12 % faster steps at
-        the ML-20M shape, within 0.001 nDCG@100 of the per-triple stream at the reference's
-        lr = 1e-3 but NOT at aggressive learning rates."""
+
+        Snapshot schedule of the adaptive sampler (extensions; the defaults are the reference's
+        ``update_stats`` every period, neg_samplers.py:122-132):
+          refresh_split k   the period is cut into k launches and the snapshot retaken before each;
+          refresh_lag       0: the snapshot is sorted between launches (the launch waits for it).
+                            1: the snapshot a launch reads was cut BEFORE the previous launch and
+                               sorted beside it (`adaptive_refresh_begin` / `_commit`): its age runs
+                               from one to two launches instead of zero to one, nothing waits.
+                            0 < f < 1: a launch is cut at 1 - f; the next launch's snapshot is taken
+                               there and sorted beside the remainder.
+          refresh_cus n     n > 0: the sort runs on a stream masked to n of the chip's CUs and the
+                            STREAM kernel on the complementary mask (0: unmasked side stream)."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
             raise ValueError("users / items must be int32 device tensors")
+        if not 0.0 <= refresh_lag <= 1.0 or refresh_split < 1:
+            raise ValueError("refresh_lag must be in [0, 1], refresh_split >= 1")
         self.model = model
         self.engine = model.engine()
         self.users, self.items = users.contiguous(), items.contiguous()
@@ -48,13 +58,19 @@ class StreamTrainer:
         # and the item reconciliation keep their single-GPU cadence
         if world is None:
             world = item_sync.world if item_sync is not None else 1
-        self.chunk = max(1, min(every * batch_size // max(world, 1), self.n))
+        self.chunk = max(1, min(every * batch_size // (max(world, 1) * refresh_split), self.n))
         U = self.engine.U
         # staleness budget: at most ~U/4 triples in flight against one parameter cut
         self.max_inflight = max(64, U // 4) if max_inflight is None else max_inflight
         self.engine.set_stream_opts(True, run_len)
-        if defer_positives is not None:
-            self.engine.set_defer_positives(defer_positives)
+        self.refresh_lag = float(refresh_lag) if self.sampler == eng.NEG_ADAPTIVE else 0.0
+        self._main = self._side = None
+        if self.refresh_lag > 0.0 and refresh_cus > 0:
+            total = torch.cuda.get_device_properties(users.device).multi_processor_count
+            self._side = eng.MaskedStream(users.device, eng.cu_mask(0, refresh_cus, total))
+            self._main = eng.MaskedStream(users.device,
+                                          eng.cu_mask(refresh_cus, total - refresh_cus, total))
+            self.engine.set_side_stream(self._side)
         self.seed, self.rank = seed, rank
         self.epoch = 0
         self.drawn = 0
@@ -68,7 +84,42 @@ class StreamTrainer:
         if item_sync is not None:
             self.rounds = item_sync.max_over_ranks(self.rounds)
 
+    def _launch(self, lo: int, hi: int) -> None:
+        self.engine.train_stream(self._pu[lo:hi], self._pi[lo:hi], sampler=self.sampler,
+                                 adaptive_p=self.adaptive_p, seed=self.seed,
+                                 offset=(self.rank << 40) + self.drawn,
+                                 max_inflight=self.max_inflight, scalars=self._scalars)
+        self.drawn += hi - lo
+
+    def _chunk(self, lo: int, hi: int) -> None:
+        e, lag = self.engine, self.refresh_lag
+        if self.sampler != eng.NEG_ADAPTIVE:
+            return self._launch(lo, hi)
+        if lag == 0.0:
+            e.adaptive_refresh()
+            return self._launch(lo, hi)
+        if e.refresh_pending():
+            e.adaptive_refresh_commit()  # the snapshot cut during / before the previous launch
+        else:
+            e.adaptive_refresh()         # first launch: nothing in flight yet
+        cut = lo if lag >= 1.0 else min(hi, lo + max(1, int(round((1.0 - lag) * (hi - lo)))))
+        if cut > lo:
+            self._launch(lo, cut)
+        e.adaptive_refresh_begin()
+        if cut < hi:
+            self._launch(cut, hi)
+
     def train_epoch(self) -> dict:
+        if self._main is not None:  # the whole epoch on the CU-masked stream
+            cur = torch.cuda.current_stream(self.users.device)
+            self._main.torch.wait_stream(cur)
+            with torch.cuda.stream(self._main.torch):
+                out = self._train_epoch()
+            cur.wait_stream(self._main.torch)
+            return out
+        return self._train_epoch()
+
+    def _train_epoch(self) -> dict:
         e = self.engine
         e.plan_epoch(self.users, self.items, self.chunk, self.seed + self.epoch,
                      out=(self._pu, self._pi))
@@ -77,13 +128,7 @@ class StreamTrainer:
             lo = k * self.chunk
             hi = min(lo + self.chunk, self.n)
             if lo < hi:
-                if self.sampler == eng.NEG_ADAPTIVE:
-                    e.adaptive_refresh()
-                e.train_stream(self._pu[lo:hi], self._pi[lo:hi], sampler=self.sampler,
-                               adaptive_p=self.adaptive_p, seed=self.seed,
-                               offset=(self.rank << 40) + self.drawn,
-                               max_inflight=self.max_inflight, scalars=self._scalars)
-                self.drawn += hi - lo
+                self._chunk(lo, hi)
             if self.item_sync is not None and (k + 1) % self.sync_every == 0:
                 self.item_sync.step()
         if self.item_sync is not None:

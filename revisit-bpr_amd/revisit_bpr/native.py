@@ -60,6 +60,12 @@ SIGNATURES = {
     "bpr_bind_opt_state": (c_int, [c_void_p] + [c_void_p] * 6),
     "bpr_sample_uniform": (c_int, [c_void_p, c_void_p, c_int64, c_uint64, c_uint64, c_void_p]),
     "bpr_adaptive_refresh": (c_int, [c_void_p]),
+    "bpr_adaptive_refresh_begin": (c_int, [c_void_p]),
+    "bpr_adaptive_refresh_commit": (c_int, [c_void_p]),
+    "bpr_adaptive_refresh_pending": (c_int, [c_void_p, POINTER(c_int32)]),
+    "bpr_set_side_stream": (c_int, [c_void_p, c_void_p]),
+    "bpr_stream_create": (c_int, [c_int, c_void_p, c_int32, POINTER(c_void_p)]),
+    "bpr_stream_destroy": (c_int, [c_void_p]),
     "bpr_sample_adaptive": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_uint64, c_uint64,
                                     c_void_p, c_void_p, c_void_p]),
     "bpr_adaptive_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -88,7 +94,6 @@ SIGNATURES = {
     "bpr_item_fold_delta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64,
                                     c_void_p]),
     "bpr_set_hot_rows": (c_int, [c_void_p, c_int32, c_int32]),
-    "bpr_set_defer_positives": (c_int, [c_void_p, c_int32]),
     "bpr_plan_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_void_p,
                                c_void_p]),
     "bpr_flush_lazy": (c_int, [c_void_p]),

@@ -8,7 +8,8 @@ oracle likewise; STRICT (`bpr_train_strict`) stands in for them: it IS the refer
 loop — held to the oracle / the reference's golden vectors to 1e-5 by tests/test_gpu_parity.py and,
 at this very shape, by tests/test_gpu_baseline_configs.py.  Compared with it:
 
-  * STREAM (fused SGD kernel, asynchronous updates) — SGD, adaptive sampling;
+  * STREAM (fused SGD kernel, asynchronous updates) — SGD, adaptive sampling, with the reference's
+    snapshot schedule and with the overlapped (lagged) ones;
   * BATCHED STREAM (virtual mini-batches, one dense optimizer step per row and batch) — SGD and
     Adam(0.1, 0.999) (configs/RQ3/time-split/ada-sampling-adam.yaml.j2:169-175), adaptive sampling.
 
@@ -62,7 +63,7 @@ def metrics(model, t):
     return out
 
 
-def run(data, t, mode, make_opt, epochs, seed):
+def run(data, t, mode, make_opt, epochs, seed, **schedule):
     from revisit_bpr.fast import BatchedStreamTrainer, StreamTrainer, StrictTrainer
 
     model = fresh_model(data)
@@ -72,7 +73,7 @@ def run(data, t, mode, make_opt, epochs, seed):
         tr = StrictTrainer(model, opt, *args, sampler="adaptive", adaptive_p=P_GEO, batch_size=B, seed=seed)
     elif mode == "stream":
         tr = StreamTrainer(model, *args, lr=opt.param_groups[0]["lr"], sampler="adaptive",
-                           adaptive_p=P_GEO, batch_size=B, seed=seed)
+                           adaptive_p=P_GEO, batch_size=B, seed=seed, **schedule)
     else:
         tr = BatchedStreamTrainer(model, opt, *args, sampler="adaptive", adaptive_p=P_GEO, batch_size=B,
                                   seed=seed)
@@ -109,6 +110,12 @@ def test_sgd_stream_and_batched_stream_match_strict_at_ml20m_scale(problem):
     assert strict[:, -1, 0].mean() > 0.3  # the model learns (untrained: 0.002)
     stream = np.stack([run(data, t, "stream", make_opt, epochs, s) for s in SEEDS])
     compare("STREAM", strict, stream, epochs)
+    # the overlapped snapshot schedules of the adaptive sampler: the sort runs
+    # beside the previous launch on its own CU set, so the snapshot is one launch older
+    for label, schedule in (("STREAM[lag1]", dict(refresh_lag=1.0, refresh_cus=64)),
+                            ("STREAM[split2-lag1]", dict(refresh_lag=1.0, refresh_split=2, refresh_cus=64))):
+        lagged = np.stack([run(data, t, "stream", make_opt, epochs, s, **schedule) for s in SEEDS])
+        compare(label, strict, lagged, epochs)
     batched = np.stack([run(data, t, "batched", make_opt, epochs, s) for s in SEEDS])
     compare("BATCHED-sgd", strict, batched, epochs)
 
@@ -121,32 +128,3 @@ def test_adam_batched_stream_matches_strict_at_ml20m_scale(problem):
     assert strict[:, -1, 0].mean() > 0.3
     batched = np.stack([run(data, t, "batched", make_opt, epochs, s) for s in SEEDS])
     compare("BATCHED-adam", strict, batched, epochs)
-
-
-def test_deferred_positives_track_the_stream_at_the_reference_lr(problem):
-    """Opt-in `defer_positives=2` (positive rows updated once per chunk) against
-    the per-triple STREAM at the reference's lr = 1e-3 (configs/RQ2/neg-sampling/
-    ada-sampling-ml-20m.yaml.j2:152), 60 epochs, three seeds: nDCG@100 within 0.005 on the way up
-    (profiles/defer_positives_study_lr0.001_r02.txt: -0.0014 at epoch 50, -0.0008 at the plateau;
-    at lr = 0.05 the approximation costs 0.012 — which is why it is off by default)."""
-    from revisit_bpr.fast import StreamTrainer
-
-    data, t = problem
-    res = {}
-    for mode in (0, 2):
-        vals = []
-        for seed in (1, 2, 3):
-            model = fresh_model(data)
-            tr = StreamTrainer(model, t["users"], t["items"], t["indptr"], t["indices"], lr=1e-3,
-                               sampler="adaptive", adaptive_p=P_GEO, batch_size=B, seed=seed,
-                               defer_positives=mode)
-            for _ in range(60):
-                stats = tr.train_epoch()
-            assert stats["triples"] == data.nnz
-            vals.append(metrics(model, t)["ndcg@100"])
-        res[mode] = np.array(vals)
-    diff = res[2].mean() - res[0].mean()
-    print(f"deferred positives, lr 1e-3, epoch 60: nDCG@100 {res[2].mean():.4f} vs {res[0].mean():.4f} "
-          f"diff {diff:+.4f}")
-    assert res[0].mean() > 0.15  # the model is learning (untrained: 0.002)
-    assert abs(diff) <= 0.005, diff

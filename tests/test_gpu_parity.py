@@ -837,125 +837,279 @@ def test_refresh_follows_a_moving_table(I, d):
     check()
 
 
-# ---- STREAM with deferred positives (bpr_set_defer_positives) -------------------------------------
-def _hot_flags(items, I, H):
-    """The H most popular training positives (row 0 excluded) — None when the boundary is a tie."""
-    cnt = np.bincount(items, minlength=I).astype(np.int64)
-    cnt[0] = -1
-    by = np.argsort(-cnt, kind="stable")
-    if cnt[by[H - 1]] == cnt[by[H]]:
-        return None
-    f = np.zeros(I, np.uint8)
-    f[by[:H]] = 1
-    return f
-
-
-@pytest.mark.parametrize("d,run_len,mode,sampler,n_chunks", [
-    (128, 8, 2, 0, 1), (128, 8, 2, 1, 3), (128, 5, 1, 1, 2), (256, 8, 2, 2, 2), (200, 4, 1, 0, 1),
-    (64, 8, 2, 1, 1), (32, 8, 1, 0, 2), (512, 4, 2, 1, 1), (1024, 3, 1, 0, 1), (100, 8, 2, 0, 1)])
-def test_stream_deferred_positives_sequential_equals_oracle(d, run_len, mode, sampler, n_chunks):
-    """One group walks each planned chunk (max_inflight = 1): user and negative rows move per
-    triple, sigma(-x) is parked, and the item-major pass then gives every positive row its summed
-    update — the oracle's restatement of exactly that, chunk by chunk.  mode 1 keeps the rows of
-    the hot block immediate; rows whose triples straddle a run of the second pass take atomic
-    adds, the others a plain read-modify-write."""
-    from revisit_bpr.datasets import synthetic
-
-    data = synthetic.generate(150, 90, 1500, median_per_user=8, seed=d + run_len)
-    rng = np.random.default_rng(d)
-    P = ((rng.random((data.num_users, d)) - 0.5) * 0.5).astype(np.float32)
-    Q = ((rng.random((data.num_items, d)) - 0.5) * 0.5).astype(np.float32)
+# ---- run boundaries that bend to user boundaries (k_stream, `look`) --------------------------------
+def _tail_problem(d, seed, run_len):
+    """A user-grouped chunk whose users have every length from 1 to 3 run lengths, so nominal run
+    boundaries cut users with tails of every size around the look-ahead (<=, ==, > 6)."""
+    rng = np.random.default_rng(seed)
+    lens = np.concatenate([np.arange(1, 3 * run_len + 2), rng.integers(1, 3 * run_len, 120)])
+    rng.shuffle(lens)
+    U, I = len(lens) + 1, 400
+    users = np.repeat(np.arange(1, U), lens).astype(np.int32)
+    pos = np.concatenate([rng.choice(np.arange(1, I), size=k, replace=False) for k in lens]).astype(np.int32)
+    indptr = np.zeros(U + 1, np.int64)
+    indptr[2:] = np.cumsum(lens)
+    order = np.lexsort((pos, users))
+    indices = pos[order].astype(np.int32)
+    P = ((rng.random((U, d)) - 0.5) * 0.5).astype(np.float32)
+    Q = ((rng.random((I, d)) - 0.5) * 0.5).astype(np.float32)
     P[0] = 0
     Q[0] = 0
+    return P, Q, indptr, indices, users, pos
+
+
+@pytest.mark.parametrize("look", [None, 0, 2])
+@pytest.mark.parametrize("d,run_len", [(64, 8), (128, 8), (128, 4), (32, 24), (256, 8), (256, 5), (100, 7)])
+def test_stream_bent_runs_sequential_equals_b1_sgd(d, run_len, look, monkeypatch):
+    """One group walks the grouped chunk (max_inflight = 1): whatever the run length and the
+    look-ahead, every triple is processed exactly once and in stream order — the oracle's B = 1
+    stream — whether a user's tail is finished by the run that started it (plain store) or cut
+    (atomic delta)."""
+    if look is not None:
+        monkeypatch.setenv("BPR_STREAM_LOOK", str(look))
+    P, Q, indptr, indices, users, pos = _tail_problem(d, 7 * d + run_len, run_len)
+    n = len(users)
     reg = (0.01, 0.02, 0.03)
-    H = 8
-    imm = None
-    if mode == 1:
-        while imm is None:
-            H += 1
-            imm = _hot_flags(data.items, data.num_items, H)
     e = make_engine(P, Q, None, reg)
-    e.bind_seen_csr(dev(data.indptr), dev(data.indices))
+    e.bind_seen_csr(dev(indptr), dev(indices))
     e.set_optimizer(kind=0, lr=0.05)
     e.set_stream_opts(True, run_len)
-    e.set_hot_rows(H, 1)
-    e.set_defer_positives(mode)
-    chunk = -(-data.nnz // n_chunks)
-    pu, pp = e.plan_epoch(dev(data.users), dev(data.items), chunk=chunk, seed=3)
-    u_np, p_np = pu.cpu().numpy(), pp.cpu().numpy()
-    negs = torch.zeros_like(pu)
-    if sampler == 0:
-        given = rng.integers(1, data.num_items, data.nnz).astype(np.int32)
-        negs = dev(given)
+    negs = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    sc = torch.zeros(4, device="cuda")
+    e.train_stream(dev(users), dev(pos), sampler=1, neg=negs, seed=11, max_inflight=1, scalars=sc)
     Po, Qo = P.copy(), Q.copy()
-    neg_o = negs.cpu().numpy().copy()
-    for lo in range(0, data.nnz, chunk):
-        hi = min(lo + chunk, data.nnz)
-        sigma = order = None
-        if sampler == 2:
-            e.adaptive_refresh()
-            QT, sigma = oracle.adaptive_stats(Qo)
-            order = oracle.adaptive_order(QT)
-        sc = torch.zeros(4, device="cuda")
-        e.train_stream(pu[lo:hi], pp[lo:hi], sampler=sampler, neg=negs[lo:hi], adaptive_p=0.1,
-                       seed=11, offset=lo, max_inflight=1, scalars=sc)
-        no = neg_o[lo:hi].copy()
-        sco = oracle.train_stream_seq_deferred(
-            Po, Qo, None, u_np[lo:hi], p_np[lo:hi], no, sampler, 0.05, reg, adaptive_p=0.1,
-            sigma=sigma, order=order, indptr=data.indptr, indices=data.indices, seed=11, offset=lo,
-            immediate=imm)
-        neg_o[lo:hi] = no
-        same = np.array_equal(negs[lo:hi].cpu().numpy(), no)
-        if sampler != 2:
-            assert same
-        if not same:  # an adaptive pick flipped on an fp32 bin edge: the trajectories part here
-            assert (negs[lo:hi].cpu().numpy() == no).mean() > 0.97
-            return
-        assert close(e.P.cpu().numpy(), Po, 1e-5), (lo, maxerr(e.P.cpu().numpy(), Po))
-        assert close(e.Q.cpu().numpy(), Qo, 1e-5), (lo, maxerr(e.Q.cpu().numpy(), Qo))
-        assert close(sc.cpu().numpy()[:3], sco[:3], 1e-4)
+    neg_o = np.zeros(n, np.int32)
+    sco = oracle.train_stream_seq(Po, Qo, None, users, pos, neg_o, 1, 0.05, reg, indptr=indptr,
+                                  indices=indices, seed=11)
+    assert np.array_equal(negs.cpu().numpy(), neg_o)
+    assert int(round(float(sc[3]))) == n
+    assert close(e.P.cpu().numpy(), Po, 1e-5), maxerr(e.P.cpu().numpy(), Po)
+    assert close(e.Q.cpu().numpy(), Qo, 1e-5), maxerr(e.Q.cpu().numpy(), Qo)
+    assert close(sc.cpu().numpy()[:3], sco[:3], 1e-4)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_stream_deferred_positives_full_concurrency(mode):
-    """Full chip, given negatives, lr -> 0 limit: with deferred positives the tables land within
-    second order in lr of the immediate-update run (same triples, same negatives), every positive
-    row moved, and a launch that is NOT a whole chunk of the plan falls back to immediate updates."""
-    from revisit_bpr.datasets import synthetic
+@pytest.mark.parametrize("d,run_len", [(128, 8), (64, 4), (256, 8), (32, 24), (128, 1)])
+def test_stream_bent_runs_partition_the_chunk_at_full_concurrency(d, run_len):
+    """Full chip, given negatives, lr -> 0 limit.  Neighbouring groups decide who owns a user's
+    tail without talking; if they ever disagreed a triple would be walked twice or not at all.
+    Every triple's user row must therefore move by exactly its first-order update: P equals the
+    oracle's summed-gradient step up to O(lr^2), the kernel counts n triples, and a given negative
+    makes the result independent of the sampler."""
+    P, Q, indptr, indices, users, pos = _tail_problem(d, 3 * d + run_len, run_len)
+    n = len(users)
+    rng = np.random.default_rng(1)
+    neg = rng.integers(1, Q.shape[0], n).astype(np.int32)
+    lr = 1e-4
+    e = make_engine(P, Q, None, (0.0, 0.0, 0.0))
+    e.set_optimizer(kind=0, lr=lr)
+    e.set_stream_opts(True, run_len)
+    sc = torch.zeros(4, device="cuda")
+    e.train_stream(dev(users), dev(pos), sampler=0, neg=dev(neg), scalars=sc)
+    assert int(round(float(sc[3]))) == n
+    Po, Qo = P.copy(), Q.copy()
+    oracle.step_sgd_sparse(Po, Qo, None, users, pos, neg, lr, (0.0, 0.0, 0.0))  # one summed step
+    # row by row: a user with a single triple must not drown next to one with seventy
+    for got, want, start in ((e.P.cpu().numpy(), Po, P), (e.Q.cpu().numpy(), Qo, Q)):
+        moved = np.abs(want - start).max(axis=1)
+        err = np.abs(got - want).max(axis=1)
+        assert moved.max() > 0
+        assert np.all(err <= 0.1 * moved + 1e-7), (float((err / (moved + 1e-12)).max()))
 
-    data = synthetic.generate(4000, 1500, 120000, median_per_user=20, seed=9)
-    d = 128
-    rng = np.random.default_rng(0)
-    P0 = ((rng.random((data.num_users, d)) - 0.5) / d * 8).astype(np.float32)
-    Q0 = ((rng.random((data.num_items, d)) - 0.5) / d * 8).astype(np.float32)
-    P0[0] = 0
+
+# ---- split refresh (bpr_adaptive_refresh_begin / _commit) -------------------------------------------
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("I,d", [(20109, 128), (3001, 32), (45000, 16)])
+def test_split_refresh_snapshots_the_table_at_begin(I, d, masked):
+    """begin cuts the keys in stream order, the sort runs on the side stream (optionally on a
+    CU-masked one), commit swaps: the samplers read the OLD snapshot until commit and, after it,
+    exactly the order of the table as it was at begin — whatever happened to the table since."""
+    from revisit_bpr import engine as eng
+
+    rng = np.random.default_rng(I + d)
+    Q0 = rng.normal(0, 0.1, (I, d)).astype(np.float32)
     Q0[0] = 0
-    given = dev(rng.integers(1, data.num_items, data.nnz).astype(np.int32))
-    res = []
-    for m in (0, mode):
-        e = make_engine(P0, Q0, None, (0.001, 0.001, 0.001))
-        e.bind_seen_csr(dev(data.indptr), dev(data.indices))
-        e.set_optimizer(kind=0, lr=0.002)
-        e.set_stream_opts(True, 8)
-        e.set_defer_positives(m)
-        pu, pp = e.plan_epoch(dev(data.users), dev(data.items), chunk=40000, seed=4)
-        for lo in range(0, data.nnz, 40000):
-            e.train_stream(pu[lo:lo + 40000], pp[lo:lo + 40000], sampler=0, neg=given[lo:lo + 40000])
-        res.append((e.P.cpu().numpy(), e.Q.cpu().numpy()))
-    (Pa, Qa), (Pd, Qd) = res
-    step = np.abs(Qa - Q0).max()
-    assert step > 0
-    assert np.abs(Qd - Qa).max() < 0.05 * step, np.abs(Qd - Qa).max() / step
-    assert np.abs(Pd - Pa).max() < 0.05 * np.abs(Pa - P0).max()
-    touched = np.unique(data.items)
-    assert (np.abs(Qd - Q0)[touched].max(axis=1) > 0).all()
-    # half a chunk: not deferred (the plan's by-positive order covers whole chunks), still correct
-    e = make_engine(P0, Q0, None, (0.001, 0.001, 0.001))
-    e.bind_seen_csr(dev(data.indptr), dev(data.indices))
-    e.set_optimizer(kind=0, lr=0.002)
+    P = np.zeros((8, d), np.float32)
+    e = make_engine(P, Q0)
+    if masked:
+        side = eng.MaskedStream(e.device, eng.cu_mask(0, 64))
+        e.set_side_stream(side)
+    e.adaptive_refresh()
+    order0, sigma0 = (t.clone() for t in e.adaptive_snapshot())
+    Q1 = (Q0 + rng.normal(0, 0.05, (I, d))).astype(np.float32)
+    Q1[0] = 0
+    e.Q.copy_(torch.from_numpy(Q1).cuda())
+    assert not e.refresh_pending()
+    e.adaptive_refresh_begin()
+    assert e.refresh_pending()
+    e.Q.mul_(-3.0)  # the table moves on while the sort runs
+    o_mid, s_mid = e.adaptive_snapshot()
+    assert torch.equal(o_mid, order0) and torch.equal(s_mid, sigma0)
+    with pytest.raises(Exception):
+        e.adaptive_refresh_begin()  # one split refresh at a time
+    e.adaptive_refresh_commit()
+    assert not e.refresh_pending()
+    order1, sigma1 = e.adaptive_snapshot()
+    QT, sig = oracle.adaptive_stats(Q1)
+    assert np.array_equal(order1.cpu().numpy(), oracle.adaptive_order(QT))
+    assert close(sigma1.cpu().numpy(), sig, 1e-5)
+    with pytest.raises(Exception):
+        e.adaptive_refresh_commit()  # nothing pending
+    e.adaptive_refresh()  # the synchronous call still works and sees the table as it is now
+    QT2, _ = oracle.adaptive_stats(e.Q.cpu().numpy())
+    assert np.array_equal(e.adaptive_snapshot()[0].cpu().numpy(), oracle.adaptive_order(QT2))
+
+
+@pytest.mark.parametrize("lag", [1.0, 0.4])
+def test_split_refresh_pipeline_sequential_equals_oracle(lag):
+    """The StreamTrainer's lagged schedule, one group at a time (max_inflight = 1), against the
+    oracle walking the same triples with the snapshot the schedule prescribes: cut at `begin`,
+    in force from `commit`."""
+    d, U, I, n, chunk = 256, 50, 120, 600, 200
+    P, Q, indptr, indices, users, pos, _ = rand_problem(U, I, d, 25, seed=11, B=n)
+    P *= 8
+    Q *= 8
+    reg = (0.01, 0.02, 0.03)
+    e = make_engine(P, Q, None, reg)
+    e.bind_seen_csr(dev(indptr), dev(indices))
+    e.set_optimizer(kind=0, lr=0.05)
+    negs = torch.zeros(n, dtype=torch.int32, device="cuda")
+    u_d, p_d = dev(users), dev(pos)
+    Po, Qo = P.copy(), Q.copy()
+    neg_o = np.zeros(n, np.int32)
+
+    def snap():
+        QT, sigma = oracle.adaptive_stats(Qo)
+        return sigma, oracle.adaptive_order(QT)
+
+    def both(lo, hi, cur):
+        e.train_stream(u_d[lo:hi], p_d[lo:hi], sampler=2, neg=negs[lo:hi], adaptive_p=0.1, seed=9,
+                       offset=lo, max_inflight=1)
+        oracle.train_stream_seq(Po, Qo, None, users[lo:hi], pos[lo:hi], neg_o[lo:hi], 2, 0.05, reg,
+                                adaptive_p=0.1, sigma=cur[0], order=cur[1], indptr=indptr,
+                                indices=indices, seed=9, offset=lo)
+
+    cur = pend = None
+    for lo in range(0, n, chunk):
+        hi = lo + chunk
+        if pend is None:
+            e.adaptive_refresh()
+            cur = snap()
+        else:
+            e.adaptive_refresh_commit()
+            cur = pend
+        cut = lo if lag >= 1.0 else lo + int(round((1.0 - lag) * chunk))
+        if cut > lo:
+            both(lo, cut, cur)
+        e.adaptive_refresh_begin()
+        pend = snap()
+        both(cut, hi, cur)
+    got = negs.cpu().numpy()
+    assert (got == neg_o).mean() > 0.97
+    if np.array_equal(got, neg_o):
+        assert close(e.P.cpu().numpy(), Po, 2e-5), maxerr(e.P.cpu().numpy(), Po)
+        assert close(e.Q.cpu().numpy(), Qo, 2e-5)
+
+
+# ---- heavy users: precomputed seen bitmaps in HBM -------------------------------------------------
+@pytest.mark.parametrize("seen,heavy_t", [("", None), ("list", None), ("", "-1"), ("", "40"), ("list", "600")])
+@pytest.mark.parametrize("d", [64, 256])
+def test_stream_heavy_users_pick_like_the_oracle(d, seen, heavy_t, monkeypatch):
+    """Users with more than 256 seen items read "seen?" from their precomputed bitmap in HBM, the
+    others from the LDS structure built at the user change: a chunk that mixes both (and switches
+    between them inside a run) must draw exactly the oracle's uniform negatives and — up to fp32
+    bin-edge flips — its adaptive ones, whatever the threshold."""
+    if seen:
+        monkeypatch.setenv("BPR_SEEN", seen)
+    if heavy_t is not None:
+        monkeypatch.setenv("BPR_HEAVY_T", heavy_t)
+    rng = np.random.default_rng(d)
+    U, I, n = 300, 2500, 12000
+    lens = np.where(rng.random(U) < 0.3, rng.integers(257, 1500, U), rng.integers(0, 120, U))
+    lens[0] = 0
+    rows = [np.sort(rng.choice(np.arange(1, I), size=int(k), replace=False)).astype(np.int32) for k in lens]
+    indptr = np.zeros(U + 1, np.int64)
+    indptr[1:] = np.cumsum(lens)
+    indices = np.concatenate(rows)
+    P = (rng.normal(0, 0.3, (U, d))).astype(np.float32)
+    Q = (rng.normal(0, 0.3, (I, d))).astype(np.float32)
+    P[0] = 0
+    Q[0] = 0
+    users = np.sort(rng.integers(1, U, n)).astype(np.int32)  # grouped by user
+    pos = rng.integers(1, I, n).astype(np.int32)
+    e = make_engine(P, Q, None, (0.01, 0.01, 0.01))
+    e.bind_seen_csr(dev(indptr), dev(indices))
+    e.set_optimizer(kind=0, lr=0.0)
     e.set_stream_opts(True, 8)
-    e.set_defer_positives(mode)
-    pu, pp = e.plan_epoch(dev(data.users), dev(data.items), chunk=40000, seed=4)
-    for lo in range(0, data.nnz, 20000):
-        e.train_stream(pu[lo:lo + 20000], pp[lo:lo + 20000], sampler=0, neg=given[lo:lo + 20000])
-    assert np.abs(e.Q.cpu().numpy() - Qa).max() < 0.05 * step
+    e.adaptive_refresh()
+    QT, sigma = oracle.adaptive_stats(Q)
+    order = oracle.adaptive_order(QT)
+    for sampler in (1, 2):
+        negs = torch.zeros(n, dtype=torch.int32, device="cuda")
+        e.train_stream(dev(users), dev(pos), sampler=sampler, neg=negs, adaptive_p=0.02, seed=5, offset=7)
+        got = negs.cpu().numpy()
+        if sampler == 1:
+            assert np.array_equal(got, oracle.sample_uniform(indptr, indices, I, users, seed=5, offset=7))
+        else:
+            want, _, _ = oracle.sample_adaptive(P, sigma, order, indptr, indices, users, 0.02, seed=5,
+                                                offset=7)
+            assert (got == want).mean() > 0.995, (got == want).mean()
+        for t in range(0, n, 61):
+            assert got[t] != 0 and got[t] not in indices[indptr[users[t]]:indptr[users[t] + 1]]
+    # a second CSR bound to the same engine: the bitmaps are rebuilt, not reused
+    indices2 = indices.copy()
+    for u in range(1, U):
+        k = int(lens[u])
+        if k:
+            indices2[indptr[u]:indptr[u + 1]] = np.sort(rng.choice(np.arange(1, I), size=k, replace=False))
+    e.bind_seen_csr(dev(indptr), dev(indices2))
+    negs = torch.zeros(n, dtype=torch.int32, device="cuda")
+    e.train_stream(dev(users), dev(pos), sampler=1, neg=negs, seed=5, offset=7)
+    assert np.array_equal(negs.cpu().numpy(),
+                          oracle.sample_uniform(indptr, indices2, I, users, seed=5, offset=7))
+
+
+# ---- uniform sampler: exact pick when rejection cannot succeed ------------------------------------
+@pytest.mark.parametrize("seen", ["", "csr", "list"])
+@pytest.mark.parametrize("d", [32, 256])
+def test_uniform_sampler_user_who_has_seen_nearly_everything(d, seen, monkeypatch):
+    """UniformSampler.sample (neg_samplers.py:31-37) always returns an unseen item, however few
+    are left.  A user with 3 unseen items out of 60,000 defeats 4,096 rejection rounds almost
+    surely (0.815 probability); the exact rank pick takes over and never returns the pad item."""
+    if seen:
+        monkeypatch.setenv("BPR_SEEN", seen)
+    I, U = 60_001, 6
+    rng = np.random.default_rng(d)
+    unseen = {1: [5, 30_000, 60_000], 2: [1, 2, 3], 3: [59_998, 59_999, 60_000], 4: [777]}
+    rows = []
+    for u in range(U):
+        if u in unseen:
+            rows.append(np.setdiff1d(np.arange(1, I), unseen[u]).astype(np.int32))
+        elif u == 5:
+            rows.append(np.arange(1, I, dtype=np.int32))  # nothing left: item 0, as documented
+        else:
+            rows.append(np.zeros(0, np.int32))
+    indptr = np.zeros(U + 1, np.int64)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows)
+    P = rng.normal(0, 0.1, (U, d)).astype(np.float32)
+    Q = rng.normal(0, 0.1, (I, d)).astype(np.float32)
+    e = make_engine(P, Q)
+    e.bind_seen_csr(dev(indptr), dev(indices))
+    users = np.tile(np.arange(1, U, dtype=np.int32), 40)
+    got = e.sample_uniform(dev(users), seed=3, offset=50).cpu().numpy()
+    want = oracle.sample_uniform(indptr, indices, I, users, seed=3, offset=50)
+    assert np.array_equal(got, want)
+    for u, items in unseen.items():
+        picks = got[users == u]
+        assert set(picks.tolist()) <= set(items) and len(set(picks.tolist())) == len(items)
+    assert (got[users == 5] == 0).all()
+    # the same inside a STREAM launch (lr = 0: the tables stay put)
+    e.set_optimizer(kind=0, lr=0.0)
+    pos = np.array([unseen.get(int(u), [1])[0] for u in users], np.int32)
+    keep = users != 5
+    su, sp = np.sort(users[keep]), pos[keep][np.argsort(users[keep], kind="stable")]
+    e.set_stream_opts(True, 8)
+    negs = torch.zeros(len(su), dtype=torch.int32, device="cuda")
+    e.train_stream(dev(su), dev(sp), sampler=1, neg=negs, seed=3, offset=50)
+    assert np.array_equal(negs.cpu().numpy(),
+                          oracle.sample_uniform(indptr, indices, I, su, seed=3, offset=50))

@@ -225,41 +225,29 @@ def test_stream_seq_equals_b1_steps(golden_dir):
     assert close(P, P2, 1e-6) and close(Q, Q2, 1e-6) and close(b, b2, 1e-6)
 
 
-def test_stream_seq_deferred_positives(golden_dir):
-    """orc_train_stream_seq_deferred (the product's bpr_set_defer_positives in its sequential
-    limit; no reference counterpart): with every row flagged `immediate` it IS the plain stream;
-    with none, user and negative rows move per triple while each positive row takes
-    q_i += lr (sum_t w_t p_u(t) - n_i a_i q_i) once, after the chunk — restated here in numpy."""
-    g, reg, _ = load(golden_dir, "math_13_uin_nobias")
-    u, i, j = i32(g["users0"]), i32(g["pos0"]), i32(g["neg0"])
-    lr = 0.05
-    P, Q = g["P0"].copy(), g["Q0"].copy()
-    P1, Q1 = P.copy(), Q.copy()
-    oracle.train_stream_seq(P, Q, None, u, i, j, oracle.NEG_GIVEN, lr, reg)
-    oracle.train_stream_seq_deferred(P1, Q1, None, u, i, j, oracle.NEG_GIVEN, lr, reg,
-                                     immediate=np.ones(len(Q), np.uint8))
-    assert np.array_equal(P, P1) and np.array_equal(Q, Q1)
-    P2, Q2 = g["P0"].astype(np.float64), g["Q0"].astype(np.float64)
-    w = np.zeros(len(u))
-    for t in range(len(u)):
-        p, qi, qj = P2[u[t]].copy(), Q2[i[t]].copy(), Q2[j[t]].copy()
-        w[t] = 1.0 / (1.0 + np.exp(p @ (qi - qj)))
-        if u[t] != 0:
-            P2[u[t]] = p - lr * (-w[t] * (qi - qj) + reg[0] * p)
-        if j[t] != 0:
-            Q2[j[t]] = qj - lr * (w[t] * p + reg[2] * qj)
-    for it in np.unique(i):
-        if it == 0:
-            continue
-        ts = np.nonzero(i == it)[0]
-        Q2[it] += lr * ((w[ts, None] * P2[u[ts]]).sum(0) - len(ts) * reg[1] * Q2[it])
-    P3, Q3 = g["P0"].copy(), g["Q0"].copy()
-    oracle.train_stream_seq_deferred(P3, Q3, None, u, i, j, oracle.NEG_GIVEN, lr, reg)
-    assert close(P3, P2, 2e-6) and close(Q3, Q2, 2e-6)
-    assert not close(Q3, Q, 1e-6)  # (it is a different algorithm from the per-triple stream)
+def test_uniform_sampler_exact_pick_when_rejection_fails():
+    """A user who has seen all but a handful of items: 4,096 rejection candidates fail almost
+    surely, and the pick falls back to the r-th unseen item by rank — always an unseen item, as the
+    reference's multinomial over the masked weights (neg_samplers.py:31-37); item 0 only when nothing
+    is left (the reference would raise)."""
+    I = 50_001
+    unseen = {1: [7, 25_000, 50_000], 2: [3], 3: []}
+    rows = [np.zeros(0, np.int32)] + [np.setdiff1d(np.arange(1, I), unseen[u]).astype(np.int32)
+                                      for u in (1, 2, 3)]
+    indptr = np.zeros(5, np.int64)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows)
+    users = np.tile(np.array([1, 2, 3], np.int32), 30)
+    neg = oracle.sample_uniform(indptr, indices, I, users, seed=5, offset=0)
+    assert set(neg[users == 1].tolist()) == set(unseen[1])
+    assert set(neg[users == 2].tolist()) == {3}
+    assert (neg[users == 3] == 0).all()
+    # the literal definition: weights 1 on unseen items -> every unseen item equally likely
+    many = oracle.sample_uniform(indptr, indices, I, np.full(3000, 1, np.int32), seed=6, offset=0)
+    share = np.array([(many == it).mean() for it in unseen[1]])
+    assert np.all(np.abs(share - 1 / 3) < 0.04), share
 
 
-# ---- metrics ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["wide", "narrow"])
 def test_metrics_match_reference(golden_dir, name):
     g = np.load(golden_dir / "metrics.npz")
