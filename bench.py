@@ -46,25 +46,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 ATOMIC_LINES_PEAK = 9.5e9
 # default snapshot schedule of the adaptive sampler: the one the parity gates hold
 # (tests/test_gpu_e2e_parity.py, tests/test_gpu_fullscale_parity.py)
-SCHEDULE = {"refresh_lag": 0.0, "refresh_split": 1, "refresh_cus": 0}
+SCHEDULE = {"refresh_lag": 1.0, "refresh_split": 1, "refresh_cus": 64}
 
 
-def cut_user_pieces(users, L, look, grouped):
+def cut_user_pieces(users, L, grouped):
     """Number of atomic user-row adds of one STREAM launch over `users` (device int32, grouped by
-    user): k_stream cuts a user at a nominal run boundary b (a multiple of L) when the user's
-    triples continue for more than `look` triples past b; every piece of a cut user is one atomic
-    row add, uncut users are stored plainly."""
+    user): k_stream cuts a user wherever a run boundary (a multiple of L) falls inside its triples;
+    every piece of a cut user is one atomic row add, uncut users are stored plainly."""
     n = users.numel()
     if not grouped:
         return float(-(-n // L))  # every run flushes its users atomically (lower bound: one each)
     b = torch.arange(L, n, L, device=users.device)
     if b.numel() == 0:
         return 0.0
-    same = users[b - 1] == users[b]
-    far = b + look
-    cont = same & (far < n) & (users[torch.clamp(far, max=n - 1)] == users[b])
-    cut_users = users[b[cont]]
-    return float(cont.sum().item() + torch.unique(cut_users).numel())
+    cut = users[b - 1] == users[b]
+    return float(cut.sum().item() + torch.unique(users[b[cut]]).numel())
 
 
 def parse_args():
@@ -333,7 +329,9 @@ def main():
     given_neg = (torch.randint(1, I, (chunk,), device=dev, dtype=torch.int32)
                  if sampler == eng.NEG_GIVEN else None)  # measurement aid only
 
-    def launch(k: int, lo: int, hi: int, base: int):
+    fused = lag >= 1.0 and world == 1  # the launch's epilogue cuts the next snapshot's keys
+
+    def launch(k: int, lo: int, hi: int, base: int, cut: bool = False):
         if batched:
             e.train_stream_batched(users[lo:hi], items[lo:hi], args.batch_size,
                                    sampler=sampler, neg=given_neg, adaptive_p=args.adaptive_p,
@@ -344,7 +342,7 @@ def main():
                            neg=None if given_neg is None else given_neg[:hi - lo],
                            adaptive_p=args.adaptive_p, seed=seed,
                            offset=(rank << 40) + k * chunk + (lo - base),
-                           max_inflight=args.max_inflight, scalars=scalars)
+                           max_inflight=args.max_inflight, scalars=scalars, cut=cut)
 
     def step(k: int):
         c = k % n_chunks
@@ -369,7 +367,7 @@ def main():
                 launch(k, lo, cut, lo)
             e.adaptive_refresh_begin()
             if cut < lo + chunk:
-                launch(k, cut, lo + chunk, lo)
+                launch(k, cut, lo + chunk, lo, cut=fused)
         if sync is not None and (k + 1) % args.sync_every == 0:
             if batched:
                 e.flush_items()
@@ -385,18 +383,12 @@ def main():
     on_main = torch.cuda.stream(main_stream.torch) if main_stream is not None else contextlib.nullcontext()
     q_before = Q.double().sum().item(), Q.abs().double().sum().item()
     torch.cuda.synchronize()
-    # The timed region is K consecutive steps.  An epoch is n_chunks steps and starts with a
-    # bpr_plan_epoch; the step counter is started so that the timed region CONTAINS an epoch
-    # boundary whenever K < n_chunks (so the plan is timed at least at its amortised share).
+    # The timed region is K consecutive steps in their natural order (step k = chunk k mod n_chunks;
+    # an epoch = n_chunks steps and starts with a bpr_plan_epoch).  With the driver's short regions
+    # no epoch boundary may fall inside: the plan is then timed separately (after the region) and
+    # its amortised share — K / n_chunks plans — is ADDED to the measured time, never subtracted.
     k0 = 0
-    if args.steps < n_chunks:
-        k0 = (n_chunks - (args.warmup + 1) - args.steps // 2) % n_chunks
     with on_main:
-        if k0 % n_chunks != 0:  # the warm-up starts inside an epoch: plan that epoch first
-            if batched:
-                e.shuffle_epoch(src_users, src_items, seed + k0 // n_chunks, out=(users, items))
-            else:
-                e.plan_epoch(src_users, src_items, chunk, seed + k0 // n_chunks, out=(users, items))
         for k in range(k0, k0 + args.warmup + 1):
             step(k)
         barrier()
@@ -416,7 +408,18 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         barrier()
+        # the epoch plan, timed on its own (3 calls; it does not touch the model)
+        tp = time.perf_counter()
+        for r in range(3):
+            if batched:
+                e.shuffle_epoch(src_users, src_items, seed + 1000 + r, out=(users, items))
+            else:
+                e.plan_epoch(src_users, src_items, chunk, seed + 1000 + r, out=(users, items))
+        torch.cuda.synchronize()
+        plan_ms = (time.perf_counter() - tp) * 1e3 / 3
     plans_timed = sum(1 for k in range(first, first + args.steps) if k % n_chunks == 0)
+    dt_measured = dt
+    dt += max(0.0, args.steps / n_chunks - plans_timed) * plan_ms * 1e-3
     kernel_ms, launches = e.timing_read()
     e.timing_enable(False)
     if world > 1:
@@ -437,8 +440,7 @@ def main():
     user_atomic_rows = 0.0
     if not batched:
         L = args.run_len if args.run_len > 0 else (8 if chunk >= 8 * 12288 else 4)
-        look = max(0, min(6, L - 1, (32 if d <= 128 else 64) - 2 - L))
-        user_atomic_rows = cut_user_pieces(users[:chunk], L, look, not args.ungrouped) / chunk
+        user_atomic_rows = cut_user_pieces(users[:chunk], L, not args.ungrouped) / chunk
 
     opt_desc = {"sgd": f"SGD lr={args.lr}", "momentum": f"SGD(momentum 0.9) lr={args.lr}",
                 "adam": f"Adam lr={args.lr} betas={tuple(args.betas)}",
@@ -486,8 +488,11 @@ def main():
                                f"{split} launch(es) per refresh period, sort masked to {cus} CUs)"),
                 "triples_per_step_per_gpu": chunk,
                 "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus},
-                "plan_epochs_in_timed_region": plans_timed,
                 "steps_per_epoch": n_chunks,
+                "plan_epoch": {"ms": plan_ms, "inside_timed_region": plans_timed,
+                               "amortised_share_added_ms_per_step":
+                                   max(0.0, args.steps / n_chunks - plans_timed) * plan_ms / args.steps,
+                               "ms_per_step_measured": dt_measured * 1e3 / args.steps},
                 "parallelism": f"user-sharded x{world}, item table replicated, async delta "
                                f"all-reduce every {args.sync_every} step(s)" if world > 1 else "single GPU",
                 "mean_bpr_loss": float(sc[0] / max(sc[3], 1.0)),

@@ -227,6 +227,15 @@ int bpr_train_strict(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int
 int bpr_train_stream(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
                      int64_t n, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
                      int64_t max_inflight, float* out_scalars);
+/* The same launch, whose epilogue ALSO cuts the keys of the next adaptive snapshot from the item
+ * table as the launch leaves it — the first half of bpr_adaptive_refresh_begin, done in the pass
+ * that folds the hot rows (one kernel and one kernel boundary less between two launches).  The
+ * next bpr_adaptive_refresh_begin then only queues the sort, provided the item table was not
+ * touched in between: every ctx call that moves it drops the cut, but writes the library cannot
+ * see (bpr_item_fold*, the caller's own kernels) must not happen there.  n must be > 0. */
+int bpr_train_stream_cut(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
+                         int64_t n, int32_t sampler, float adaptive_p, uint64_t seed,
+                         uint64_t offset, int64_t max_inflight, float* out_scalars);
 
 /* BATCHED STREAM — the single-launch throughput path for every optimizer kind (SGD, momentum /
  * Nesterov, Adam, RMSprop; configs/RQ3/time-split/ada-sampling-adam.yaml.j2:169-175 and 14 of the
@@ -254,13 +263,11 @@ int bpr_shuffle_epoch(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_
 
 /* STREAM options.  grouped_by_user = 1 promises that inside every chunk handed to
  * bpr_train_stream the triples of a user are contiguous (the output of bpr_plan_epoch): a user
- * whose triples are all walked by one group is then owned by that wavefront group for the whole
- * launch and its row is written back with a plain store; with 0 (default) every user-row update
- * is an atomic add.  run_len = nominal number of consecutive triples one group walks with the
- * user row held in registers: 1..24, or 0 (default) = chosen per launch — 8 once that makes
- * >= 12 k groups, 4 for smaller launches (they would leave the chip idle).  Run boundaries bend
- * to user boundaries: a user that crosses a nominal boundary with at most min(6, run_len - 1)
- * triples on the far side is finished by the run that started it. */
+ * whose triples all fall in one run of `run_len` consecutive triples is then owned by one
+ * wavefront group for the whole launch and its row is written back with a plain store; with 0
+ * (default) every user-row update is an atomic add.  run_len = consecutive triples one
+ * group walks with the user row held in registers: 1..30, or 0 (default) = chosen per launch —
+ * 8 once that makes >= 12 k groups, 4 for smaller launches (they would leave the chip idle). */
 int bpr_set_stream_opts(bpr_ctx* ctx, int32_t grouped_by_user, int32_t run_len);
 
 /* Hot item rows.  On popularity-skewed data the STREAM kernel is limited by fp32 atomics queueing

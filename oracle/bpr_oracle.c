@@ -432,19 +432,26 @@ static void adaptive_draw(const float* p, int32_t d, const float* sigma, int64_t
                           float geo_p, uint64_t seed, uint64_t t, int32_t* factor, int32_t* rank) {
   uint32_t rf = draw(seed, t, 0u, 1u, 0);
   uint32_t rg = draw(seed, t, 0u, 1u, 1);
-  /* factor ~ Categorical(|p_uf|·σ_f)  (neg_samplers.py:84-88) by inverse CDF */
+  /* factor ~ Categorical(|p_uf|·σ_f)  (neg_samplers.py:84-88) by inverse CDF.  The reference hands
+   * the weights to torch.multinomial; any enumeration of the factors gives the same distribution,
+   * and a draw only has to be reproducible between this oracle and the product.  The product's
+   * wavefront group holds factor f in lane f mod G (G = 32 lanes for d <= 128, else 64), so its
+   * CDF runs lane by lane: factors are enumerated in the order (f mod G, f div G). */
+  const int32_t G = d <= 128 ? 32 : 64;
   double total = 0.0;
-  for (int32_t f = 0; f < d; ++f) total += (double)(fabsf(p[f]) * sigma[f]);
+  for (int32_t l = 0; l < G; ++l)
+    for (int32_t f = l; f < d; f += G) total += (double)(fabsf(p[f]) * sigma[f]);
   float uf = (float)(rf >> 8) * (1.0f / 16777216.0f);
   double thr = (double)uf * (double)(float)total;
   double cum = 0.0;
   int32_t fsel = -1, last_pos = 0;
-  for (int32_t f = 0; f < d; ++f) {
-    float wf = fabsf(p[f]) * sigma[f];
-    cum += (double)wf;
-    if (wf > 0.0f) last_pos = f;
-    if (fsel < 0 && cum > thr && wf > 0.0f) fsel = f;
-  }
+  for (int32_t l = 0; l < G; ++l)
+    for (int32_t f = l; f < d; f += G) {
+      float wf = fabsf(p[f]) * sigma[f];
+      cum += (double)wf;
+      if (wf > 0.0f) last_pos = f;
+      if (fsel < 0 && cum > thr && wf > 0.0f) fsel = f;
+    }
   if (fsel < 0) fsel = last_pos;
   /* r ~ Geometric(p) on {1,2,…} (:90-93), clamped to the number of unseen items (:94) */
   float ug = (float)((rg >> 8) + 1u) * (1.0f / 16777216.0f);

@@ -55,11 +55,14 @@ struct bpr_ctx {
   int32_t* order_alloc[2] = {nullptr, nullptr};
   float* sigma_buf[2] = {nullptr, nullptr};
   int snap_front = 0;
-  float* keysT = nullptr;    // [d, I] transposed item table (the keys of the running sort)
+  float* keysT = nullptr;    // [d, I] transposed item table: the keys the NEXT cut writes / the
+  float* keysT_buf[2] = {nullptr, nullptr};  // sort queued last reads (two buffers: a cut never
+  int keys_w = 0;                            // waits for the sort still reading the other one)
   float* keys_sorted = nullptr;  // 2 x [d, I] uint64 composite sort keys (in | out)
   int32_t* ids_in = nullptr;
   int32_t* seg_offsets = nullptr;  // [d+1]
-  double* sig_acc = nullptr;       // [d, 2] shifted sum / sum of squares per factor
+  double* sig_acc = nullptr;       // [d, 2] shifted sum / sum of squares per factor (of keysT)
+  double* sig_acc_buf[2] = {nullptr, nullptr};
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   bool have_snapshot = false;
@@ -69,6 +72,10 @@ struct bpr_ctx {
   bool side_owned = false;
   hipEvent_t ev_keys = nullptr, ev_sorted = nullptr;
   bool refresh_pending = false;
+  // bpr_train_stream_cut: the launch's epilogue already cut the next snapshot's keys (keysT); the
+  // next bpr_adaptive_refresh_begin only queues the sort.  Any call that moves the item table
+  // afterwards clears it.
+  bool keys_cut = false;
   // private scratch — epoch planner
   uint64_t* plan_keys = nullptr;
   uint64_t* plan_keys_sorted = nullptr;
@@ -110,6 +117,7 @@ struct bpr_ctx {
 namespace bpr {
 void set_error(const std::string& msg);
 int refresh_impl(bpr_ctx* c, bool split);  // bpr_refresh.hip: split = sort on c->side, no swap
+int refresh_alloc(bpr_ctx* c);             // bpr_refresh.hip: the snapshot buffers (idempotent)
 int refresh_commit_impl(bpr_ctx* c);        // bpr_refresh.hip
 void refresh_free(bpr_ctx* c);      // bpr_refresh.hip
 void side_free(bpr_ctx* c);         // bpr_refresh.hip

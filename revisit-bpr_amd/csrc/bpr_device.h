@@ -391,51 +391,50 @@ __device__ __forceinline__ AdaptiveDraw sample_adaptive(
     const int32_t* __restrict__ order, int64_t I, const Seen& seen, int64_t n_seen,
     const AdaptiveRandoms& rnd, int lane) {
   const int gl = lane & (G - 1);
-  // ---- factor ~ Categorical(|p_uf|·σ_f)  (neg_samplers.py:84-88): inverse CDF in factor order
-  // f = e*G + gl, i.e. chunk e after chunk e-1, lanes in order inside a chunk.  Two passes over the
-  // chunks — total first, then the search — so that only one chunk's weights are live at a time
-  // (the scans are a handful of DPP adds; registers, not VALU cycles, are what this kernel lacks).
-  float total = 0.f;
+  // ---- factor ~ Categorical(|p_uf|·σ_f)  (neg_samplers.py:84-88) by inverse CDF, lane by lane:
+  // the factors are enumerated in the order (lane, chunk) = (f mod G, f div G) — any enumeration
+  // gives the same distribution, and this one needs ONE scan over the lanes' sums instead of a
+  // scan per chunk (the per-chunk version was ~100 of the kernel's ~290 VALU instructions per
+  // wave-iteration, and instruction issue is what the sampler costs on a chip that is otherwise
+  // waiting for its atomics).  The oracle enumerates the same way.
+  float w[E];
+  float lane_sum = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int f = e * G + gl;
-    const float w = (f < d) ? fabsf(p[e]) * sigma[e] : 0.f;
-    total += group_last<G>(group_scan_incl<G>(w), lane);
+    w[e] = (f < d) ? fabsf(p[e]) * sigma[e] : 0.f;
+    lane_sum += w[e];
   }
+  const float incl = group_scan_incl<G>(lane_sum);
+  const float total = group_last<G>(incl, lane);
   const float thr = rnd.uf * total;
-  // first factor with weight whose inclusive CDF exceeds thr; psel = my element of its chunk
-  // (tracked here with static indices: a select chain over p[] after the fact is turned into a
-  // dynamically indexed private array by the compiler, which moves p[] to scratch memory)
-  int fsel = -1;
-  float psel = p[0];
-  float carry = 0.f;
+  // the first lane whose inclusive sum exceeds thr holds the factor; inside it, the first chunk
+  // whose running sum does.  thr rounded up to (or past) the total: the last factor with weight of
+  // this enumeration.  (Static indices throughout: a dynamically indexed p[] would be moved to
+  // scratch memory by the compiler.)
+  const int lsel = group_first<G>(wave_ballot(lane_sum > 0.f && incl > thr), lane);
+  const int llast = group_last_set<G>(wave_ballot(lane_sum > 0.f), lane);
+  float cum = incl - lane_sum;
+  int e_first = -1, e_last = 0;
+  float p_first = p[0], p_last = p[0];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const int f = e * G + gl;
-    const float w = (f < d) ? fabsf(p[e]) * sigma[e] : 0.f;
-    const float incl = group_scan_incl<G>(w);
-    const int first = group_first<G>(wave_ballot(w > 0.f && carry + incl > thr), lane);
-    const bool take = fsel < 0 && first >= 0;
-    fsel = take ? e * G + first : fsel;
-    psel = take ? p[e] : psel;
-    carry += group_last<G>(incl, lane);
+    cum += w[e];
+    const bool pos = w[e] > 0.f;
+    const bool take = e_first < 0 && pos && cum > thr;
+    e_first = take ? e : e_first;
+    p_first = take ? p[e] : p_first;
+    e_last = pos ? e : e_last;
+    p_last = pos ? p[e] : p_last;
   }
-  if (fsel < 0) {  // thr rounded up to the total: the last factor with weight (0 if there is none)
-    fsel = 0;
-    psel = p[0];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int f = e * G + gl;
-      const float w = (f < d) ? fabsf(p[e]) * sigma[e] : 0.f;
-      const int last = group_last_set<G>(wave_ballot(w > 0.f), lane);
-      if (last >= 0) {
-        fsel = e * G + last;
-        psel = p[e];
-      }
-    }
-  }
+  const bool first_ok = lsel >= 0 && e_first >= 0;
+  const int e_loc = first_ok ? e_first : e_last;
+  const float p_loc = first_ok ? p_first : p_last;
+  const int src = lsel >= 0 ? lsel : (llast >= 0 ? llast : 0);
+  const int fsel = group_bcast<G>(e_loc, src, lane) * G + src;
+  const float psel = group_bcast<G>(p_loc, src, lane);
   // ---- the user's factor value decides the orientation (:96-100)
-  const float pv = group_bcast<G>(psel, fsel & (G - 1), lane);
+  const float pv = psel;
   const int32_t n_unseen = (int32_t)((I - 1) - n_seen);
   const int32_t r = min(rnd.r, n_unseen);
   const bool from_top = pv > 0.f;

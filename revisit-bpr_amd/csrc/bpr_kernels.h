@@ -150,23 +150,97 @@ __global__ __launch_bounds__(256) void k_stream_epilogue(const EpilogueArgs a) {
   }
 }
 
+// The same epilogue with the CUT of the next adaptive snapshot in one pass (bpr_train_stream_cut):
+// every element of the item table is read once anyway to be transposed into the snapshot's key
+// buffer T [d, I]; rows of the hot block take their delta on the way (Q += delta, delta = 0).  Block
+// (0, 0) of the extra row gridDim.y - 1 sums the loss statistics.  Replaces k_stream_epilogue +
+// k_transpose (bpr_refresh.hip) and one kernel boundary between two STREAM launches.
+struct EpilogueCutArgs {
+  const float* partials;
+  float* out;
+  float* Q;
+  float* delta;
+  const int32_t* hot_slot;  // NULL = no hot block
+  float* T;
+  double* sig_acc;
+  int32_t n_blocks, H, R, d, I;
+};
+
+__global__ __launch_bounds__(256) void k_stream_epilogue_cut(const EpilogueCutArgs a) {
+  if (blockIdx.y == gridDim.y - 1) {  // the statistics row
+    if (blockIdx.x != 0) return;
+    for (int k = threadIdx.x; k < 2 * a.d; k += 256) a.sig_acc[k] = 0.0;  // (as k_transpose does)
+    if (a.out == nullptr) return;
+    __shared__ double red[256][4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < a.n_blocks; b += 256)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += (double)a.partials[(int64_t)b * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
+      __syncthreads();
+    }
+    if (threadIdx.x < 4) a.out[threadIdx.x] += (float)red[0][threadIdx.x];
+    return;
+  }
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t i0 = (int64_t)blockIdx.x * 32;
+  const int f0 = blockIdx.y * 32;
+  const int d = a.d;
+  const int64_t hd = (int64_t)a.H * d;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int64_t i = i0 + ty + r;
+    const int f = f0 + tx;
+    float v = 0.f;
+    if (i < a.I && f < d) {
+      v = a.Q[i * d + f];
+      const int32_t s = a.hot_slot != nullptr ? a.hot_slot[i] : -1;
+      if (s >= 0) {
+        float sum = 0.f;
+        for (int rep = 0; rep < a.R; ++rep) {
+          float* p = a.delta + rep * hd + (int64_t)s * d + f;
+          sum += *p;
+          *p = 0.f;
+        }
+        v += sum;
+        a.Q[i * d + f] = v;
+      }
+    }
+    tile[ty + r][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int f = f0 + ty + r;
+    const int64_t i = i0 + tx;
+    if (f < d && i < a.I) a.T[(int64_t)f * a.I + i] = tile[tx][ty + r];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // STREAM: the throughput kernel.
 //
-// The chunk [0, n) is cut into runs of nominally `run_len` consecutive triples; group g walks run
-// g, g+NG, …  While consecutive triples share the user, the user row lives in registers (read once,
-// written once).  When the chunk is grouped by user (bpr_plan_epoch) a user whose triples are all
-// walked by one group is owned exclusively by that group for the whole launch → plain store, no
-// atomics and no cross-XCD coherence question.  Run boundaries bend to user boundaries: a user that
-// crosses a nominal boundary with at most `look` triples on the far side is FINISHED by the run
-// that started it (both neighbours evaluate the same rule on the same ids, so they agree without
-// talking); only users with a longer tail are cut, and a cut user gets the groups' accumulated
-// deltas added atomically instead.  Item rows are shared by everybody → one full-line fp32 atomic
-// add per 128 B of row.
+// The chunk [0, n) is cut into runs of `run_len` consecutive triples; group g walks run g, g+NG, …
+// While consecutive triples share the user, the user row lives in registers (read once, written
+// once).  When the chunk is grouped by user (bpr_plan_epoch) a user whose triples all fall inside
+// one run is owned exclusively by that group for the whole launch → plain store, no atomics and no
+// cross-XCD coherence question; a user whose triples straddle a run boundary gets the group's
+// accumulated delta added atomically instead.  Item rows are shared by everybody → one full-line
+// fp32 atomic add per 128 B of row.
+// (r3: runs whose boundaries bend to user boundaries — a user's short tail finished by the run that
+// started it — were built, held to the oracle, and measured: 0.5 line-atomics per triple fewer,
+// but the two groups of a wave then walk ranges of different length in lockstep, and the kernel
+// got SLOWER, 0.224 -> 0.236 ms per chunk with the adaptive sampler, 0.2003 vs 0.2008 ms with
+// given negatives: profiles/r03_sweep_late_atomics.txt, r03_sweep_kstream_v1.txt.  Not kept.)
 // ---------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) uint32_t bpr_smem[];
-
-constexpr int STREAM_LOOK_MAX = 6;
 
 // kernel arguments of k_stream only (kept small: every field costs SGPRs for the whole kernel)
 struct StreamArgs {
@@ -184,7 +258,7 @@ struct StreamArgs {
   uint64_t seed, offset;
   int32_t n, I, d;
   int32_t pad_user, pad_item;
-  int32_t run_len, look, grouped, bm_words;
+  int32_t run_len, grouped, bm_words;
   int32_t gpw_active;  // groups of a wave that work (G = 32: 2; 1 = one triple at a time, tests)
   float au, ai, an, lr, inv_log1mp;
   // hot item rows: updates of row i with hot_slot[i] = s >= 0 go to the replica delta row
@@ -228,18 +302,6 @@ struct SigmaLds {
   __device__ __forceinline__ float operator[](int e) const { return s[e * G + gl]; }
 };
 
-// max / min over the groups of a wave of a group-uniform value
-template <int G>
-__device__ __forceinline__ int wave_max_groups(int v) {
-  if constexpr (G == 64) return v;
-  return max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
-}
-template <int G>
-__device__ __forceinline__ int wave_min_groups(int v) {
-  if constexpr (G == 64) return v;
-  return min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
-}
-
 // FULL: d == G*E (32, 64, 128, 256, 512, 1024) — every `f < d` predicate folds away.
 // (occupancy: the adaptive sampler over the staged-list structure needs a few registers more than
 // 5 waves per SIMD leave; measured on MI355X, 4 and 5 waves run the kernel equally fast — it is not
@@ -258,8 +320,6 @@ void k_stream(const StreamArgs a) {
   const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
   const int d = FULL ? G * E : a.d;
   const int L = a.run_len;
-  const int LOOK = a.look;
-  const int VIEW = L + LOOK + 1;  // <= G - 1 (launcher): lanes 0..VIEW-1 hold the view
   const int n_runs = (a.n + L - 1) / L;
   const bool stats = a.partials != nullptr;
   float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
@@ -288,20 +348,19 @@ void k_stream(const StreamArgs a) {
     const int run = rbase + gw;
     const bool run_act = gw < gpw && run < n_runs;
     const int t0 = run_act ? run * L : 0;
-    const int cntw = run_act ? min(L, a.n - t0) : 0;  // triples of the nominal window
-    // ---- run prologue: ONE coalesced load brings the ids of the whole view (lane k holds triple
-    // t0+k, k < VIEW; lane G-1 the predecessor) and one more the users' CSR bounds, so the
-    // per-triple dependent chain starts at the row gathers instead of at the ids.
+    const int t1 = run_act ? min(t0 + L, a.n) : 0;
+    // ---- run prologue: ONE coalesced load brings the ids of the whole run (lane k holds triple
+    // t0+k; lane L the successor, lane G-1 the predecessor) and one more the users' CSR bounds,
+    // so the per-triple dependent chain starts at the row gathers instead of at the ids.
     int32_t my_u = 0, my_i = 0, my_si = -1;
     int64_t my_lo = 0;
     int32_t my_cnt = 0;  // the user's seen items: indices[my_lo .. my_lo + my_cnt)
-    bool in_view;
     {
       const int tk = (gl == G - 1) ? t0 - 1 : t0 + gl;
-      in_view = run_act && gl < VIEW && tk < a.n;
-      const bool pred = run_act && gl == G - 1 && tk >= 0;
-      if (in_view || pred) my_u = a.users[tk];
-      if (in_view) {
+      const bool in_run = run_act && gl < L && tk < t1;
+      const bool neighbour = run_act && ((gl == L && tk < a.n) || (gl == G - 1 && tk >= 0));
+      if (in_run || neighbour) my_u = a.users[tk];
+      if (in_run) {
         my_i = a.pos[tk];
         if (a.hot_slot != nullptr) my_si = a.hot_slot[my_i];
         if constexpr (SAMPLER != NEG_GIVEN) {
@@ -310,31 +369,21 @@ void k_stream(const StreamArgs a) {
         }
       }
     }
-    // the model-independent draws of the view's triples, all at once (lane k = triple t0+k)
+    // the model-independent draws of the run's triples, all at once (lane k = triple t0+k)
     AdaptiveRandoms my_rnd = {0.f, 0};
     if constexpr (SAMPLER == NEG_ADAPTIVE) {
       my_rnd = adaptive_randoms(a.seed, a.offset + (uint64_t)(t0 + gl), a.inv_log1mp,
                                 (int64_t)(a.I - 1) - (int64_t)my_cnt);
     }
-    // uniform: the first Philox block (candidates 0..3) of every triple of the view, all at once
+    // uniform: the first Philox block (candidates 0..3) of every triple of the run, all at once
     u32x4 my_w = {0u, 0u, 0u, 0u};
     if constexpr (SAMPLER == NEG_UNIFORM) {
       const uint64_t tc = a.offset + (uint64_t)(t0 + gl);
       my_w = philox4x32_10((uint32_t)tc, (uint32_t)(tc >> 32), 0u, PURPOSE_UNIFORM,
                            (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
     }
-    // ---- which triples are mine: [lead, hi) of the view.  k_b = number of triples from a nominal
-    // boundary b on that continue the user of triple b-1; k_b <= LOOK: the LEFT run finishes them.
     const int32_t prev_u = (run_act && t0 > 0) ? group_bcast<G>(my_u, G - 1, lane) : -1;
-    const int32_t last_u = cntw > 0 ? group_bcast<G>(my_u, cntw - 1, lane) : -1;
-    int t_prev = group_first<G>(wave_ballot(gl < VIEW && (!in_view || my_u != prev_u)), lane);
-    int t_next = group_first<G>(wave_ballot(gl >= cntw && gl < VIEW && (!in_view || my_u != last_u)),
-                                lane);
-    t_prev = t_prev < 0 ? VIEW : t_prev;
-    t_next = t_next < 0 ? VIEW : t_next - cntw;
-    const int lead = (prev_u >= 0 && t_prev <= LOOK) ? t_prev : 0;
-    const bool tail_mine = t_next <= LOOK;  // my last user ends with my last triple
-    const int hi = run_act ? cntw + (tail_mine ? t_next : 0) : 0;
+    const int32_t next_u = (run_act && t1 < a.n) ? group_bcast<G>(my_u, t1 - t0, lane) : -1;
     int32_t cur_u = -1;
     bool cur_starts_inside = false;
     // pl = live user row (memory value + this group's pending updates dp)
@@ -344,11 +393,9 @@ void k_stream(const StreamArgs a) {
 
     float x_mine = 0.f;  // statistics: logit of step gl of this run
     bool x_have = false;
-    const int step_lo = wave_min_groups<G>(run_act ? lead : VIEW);
-    const int step_hi = wave_max_groups<G>(hi);
-    for (int step = step_lo; step < step_hi; ++step) {
+    for (int step = 0; step < L; ++step) {
       const int t = t0 + step;
-      const bool act = step >= lead && step < hi;
+      const bool act = run_act && t < t1;
       const int tt = act ? t : (a.n - 1);
       const int32_t u = group_bcast<G>(my_u, step, lane);
       const int32_t i = group_bcast<G>(my_i, step, lane);
@@ -406,10 +453,7 @@ void k_stream(const StreamArgs a) {
           }
         }
         cur_u = u;
-        // a user whose first triple is mine: it begins past my first triple, or my first triple
-        // is not a continuation (lead > 0: the view's triple `lead` is by construction the first
-        // of its user; lead == 0: the chunk's first triple, or the predecessor's user differs)
-        cur_starts_inside = (step > lead) || (lead > 0) || (t == 0) || (prev_u != u);
+        cur_starts_inside = (step > 0) || (t == 0) || (prev_u != u);
       }
 
       int32_t j;
@@ -519,7 +563,8 @@ void k_stream(const StreamArgs a) {
     // ---- end of run: flush the last user
     if (run_act && cur_u >= 0 && cur_u != a.pad_user) {
       float* row = a.P + (uint32_t)cur_u * (uint32_t)d;
-      if (a.grouped && cur_starts_inside && tail_mine) {
+      const bool ends_inside = (t1 == a.n) || (next_u != cur_u);
+      if (a.grouped && cur_starts_inside && ends_inside) {
         store_row<G, E>(row, pl, d, gl);
       } else {
         atomic_add_row<G, E>(row, dp, d, gl);

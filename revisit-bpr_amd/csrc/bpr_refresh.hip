@@ -298,10 +298,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_runs(
 }
 
 template <int ITEMS>
-static void launch_sort_sub(bpr_ctx* c, hipStream_t st, int32_t* order, float* sigma, int sub,
-                            int64_t len, float* keysA, int32_t* idsA) {
-  hipLaunchKernelGGL((k_sort_sub<ITEMS>), dim3(sub, c->d), dim3(1024), 0, st, c->keysT, c->I, len,
-                     order, keysA, idsA, sigma, c->sig_acc);
+static void launch_sort_sub(bpr_ctx* c, hipStream_t st, const float* keysT, double* sig_acc,
+                            int32_t* order, float* sigma, int sub, int64_t len, float* keysA,
+                            int32_t* idsA) {
+  hipLaunchKernelGGL((k_sort_sub<ITEMS>), dim3(sub, c->d), dim3(1024), 0, st, keysT, c->I, len,
+                     order, keysA, idsA, sigma, sig_acc);
 }
 
 // composite sort key: (factor << 32) | ~orderable(value)  → ascending sort = per-factor descending
@@ -437,11 +438,6 @@ __global__ void k_item_hist(const int32_t* __restrict__ pos, int64_t n, int64_t 
     const int32_t it = pos[k];
     if (it >= 0 && it < I) atomicAdd(&counts[it], 1u);
   }
-}
-__global__ void k_iota32(int32_t* __restrict__ ids, int64_t I) {
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < I;
-       k += (int64_t)gridDim.x * blockDim.x)
-    ids[k] = (int32_t)k;
 }
 void hot_free(bpr_ctx* c) {
   hipFree(c->hot_slot);
@@ -659,12 +655,17 @@ void refresh_free(bpr_ctx* c) {
     c->order_alloc[k] = nullptr;
     c->sigma_buf[k] = nullptr;
   }
-  hipFree(c->keysT);
+  for (int k = 0; k < 2; ++k) {
+    hipFree(c->keysT_buf[k]);
+    hipFree(c->sig_acc_buf[k]);
+    c->keysT_buf[k] = nullptr;
+    c->sig_acc_buf[k] = nullptr;
+  }
   hipFree(c->keys_sorted);
   hipFree(c->ids_in);
   hipFree(c->seg_offsets);
-  hipFree(c->sig_acc);
   c->sig_acc = nullptr;
+  c->keys_cut = false;
   hipFree(c->sort_tmp);
   c->order = nullptr;
   c->sigma = nullptr;
@@ -692,7 +693,7 @@ void side_free(bpr_ctx* c) {  // bpr_ctx_destroy: the split refresh's events and
 // (bpr_adaptive_refresh_begin): the sort runs on c->side behind an event, the caller's stream goes
 // on — typically with the next STREAM launch, which is bound by the L2 atomic units and leaves the
 // CUs mostly idle — and refresh_commit_impl (bpr_adaptive_refresh_commit) orders the swap.
-int refresh_impl(bpr_ctx* c, bool split) {
+int refresh_alloc(bpr_ctx* c) {
   const int64_t I = c->I;
   const int d = c->d;
   const int64_t n = (int64_t)d * I;
@@ -704,41 +705,61 @@ int refresh_impl(bpr_ctx* c, bool split) {
     set_error("bpr_adaptive_refresh: need at least 3 item rows");
     return BPR_ERR_INVALID;
   }
+  if (c->order_alloc[0] != nullptr) return BPR_OK;
+  for (int k = 0; k < 2; ++k) {
+    BPR_HIP_CHECK(hipMalloc(&c->order_alloc[k], sizeof(int32_t) * (n + 2 * BPR_ORDER_PAD)));
+    BPR_HIP_CHECK(hipMemsetAsync(c->order_alloc[k], 0, sizeof(int32_t) * (n + 2 * BPR_ORDER_PAD),
+                                 c->stream));
+    BPR_HIP_CHECK(hipMalloc(&c->sigma_buf[k], sizeof(float) * d));
+  }
+  c->snap_front = 0;
+  c->order = c->order_alloc[0] + BPR_ORDER_PAD;
+  c->sigma = c->sigma_buf[0];
+  for (int k = 0; k < 2; ++k) {
+    BPR_HIP_CHECK(hipMalloc(&c->keysT_buf[k], sizeof(float) * n));
+    BPR_HIP_CHECK(hipMalloc(&c->sig_acc_buf[k], sizeof(double) * 2 * d));
+  }
+  c->keys_w = 0;
+  c->keysT = c->keysT_buf[0];
+  c->sig_acc = c->sig_acc_buf[0];
+  BPR_HIP_CHECK(hipMalloc(&c->keys_sorted, sizeof(uint64_t) * 2 * n));  // composite keys in|out
+  BPR_HIP_CHECK(hipMalloc(&c->ids_in, sizeof(int32_t) * n));
+  BPR_HIP_CHECK(hipMalloc(&c->seg_offsets, sizeof(int32_t) * (d + 1)));
+  hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, c->stream, c->ids_in, c->seg_offsets, I, d);
+  size_t bytes = 0;
+  uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
+  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k64, k64 + n, c->ids_in,
+                                                   c->order, (int)n, 0, 64, c->stream));
+  BPR_HIP_CHECK(hipMalloc(&c->sort_tmp, bytes > 0 ? bytes : 16));
+  c->sort_tmp_bytes = bytes;
+  return BPR_OK;
+}
+
+int refresh_impl(bpr_ctx* c, bool split) {
   if (c->refresh_pending) {
     set_error("bpr_adaptive_refresh: a split refresh is pending (bpr_adaptive_refresh_commit first)");
     return BPR_ERR_INVALID;
   }
-  if (c->order_alloc[0] == nullptr) {
-    for (int k = 0; k < 2; ++k) {
-      BPR_HIP_CHECK(hipMalloc(&c->order_alloc[k], sizeof(int32_t) * (n + 2 * BPR_ORDER_PAD)));
-      BPR_HIP_CHECK(hipMemsetAsync(c->order_alloc[k], 0, sizeof(int32_t) * (n + 2 * BPR_ORDER_PAD),
-                                   c->stream));
-      BPR_HIP_CHECK(hipMalloc(&c->sigma_buf[k], sizeof(float) * d));
-    }
-    c->snap_front = 0;
-    c->order = c->order_alloc[0] + BPR_ORDER_PAD;
-    c->sigma = c->sigma_buf[0];
-    BPR_HIP_CHECK(hipMalloc(&c->keysT, sizeof(float) * n));
-    BPR_HIP_CHECK(hipMalloc(&c->keys_sorted, sizeof(uint64_t) * 2 * n));  // composite keys in|out
-    BPR_HIP_CHECK(hipMalloc(&c->ids_in, sizeof(int32_t) * n));
-    BPR_HIP_CHECK(hipMalloc(&c->seg_offsets, sizeof(int32_t) * (d + 1)));
-    BPR_HIP_CHECK(hipMalloc(&c->sig_acc, sizeof(double) * 2 * d));
-    hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, c->stream, c->ids_in, c->seg_offsets, I,
-                       d);
-    size_t bytes = 0;
-    uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
-    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k64, k64 + n, c->ids_in,
-                                                     c->order, (int)n, 0, 64, c->stream));
-    BPR_HIP_CHECK(hipMalloc(&c->sort_tmp, bytes > 0 ? bytes : 16));
-    c->sort_tmp_bytes = bytes;
-  }
+  if (int rc = refresh_alloc(c)) return rc;
+  const int64_t I = c->I;
+  const int d = c->d;
+  const int64_t n = (int64_t)d * I;
   const int back = c->have_snapshot ? (c->snap_front ^ 1) : c->snap_front;
   int32_t* const order = c->order_alloc[back] + BPR_ORDER_PAD;
   float* const sigma = c->sigma_buf[back];
-  // ---- cut
-  dim3 tgrid((unsigned)((I + 31) / 32), (unsigned)((d + 31) / 32));
-  hipLaunchKernelGGL(k_transpose, tgrid, dim3(256), 0, c->stream, c->Q, c->keysT, I, d,
-                     c->sig_acc);
+  // ---- cut (unless the last STREAM launch's epilogue did it: bpr_train_stream_cut)
+  if (!c->keys_cut) {
+    dim3 tgrid((unsigned)((I + 31) / 32), (unsigned)((d + 31) / 32));
+    hipLaunchKernelGGL(k_transpose, tgrid, dim3(256), 0, c->stream, c->Q, c->keysT, I, d,
+                       c->sig_acc);
+  }
+  c->keys_cut = false;
+  // the sort reads the buffers just cut; the next cut goes to the other pair
+  const float* const keysT = c->keysT;
+  double* const sig_acc = c->sig_acc;
+  c->keys_w ^= 1;
+  c->keysT = c->keysT_buf[c->keys_w];
+  c->sig_acc = c->sig_acc_buf[c->keys_w];
   hipStream_t st = c->stream;
   if (split) {
     if (c->side == nullptr) {
@@ -777,29 +798,29 @@ int refresh_impl(bpr_ctx* c, bool split) {
     float* keysB = reinterpret_cast<float*>(idsA + n);
     int32_t* idsB = reinterpret_cast<int32_t*>(keysB + n);
     const int items = (int)((len + 1023) / 1024);
-    if (items <= 6) launch_sort_sub<6>(c, st, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 10) launch_sort_sub<10>(c, st, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 12) launch_sort_sub<12>(c, st, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 16) launch_sort_sub<16>(c, st, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 20) launch_sort_sub<20>(c, st, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 24) launch_sort_sub<24>(c, st, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 28) launch_sort_sub<28>(c, st, order, sigma, sub, len, keysA, idsA);
-    else launch_sort_sub<36>(c, st, order, sigma, sub, len, keysA, idsA);
+    if (items <= 6) launch_sort_sub<6>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 10) launch_sort_sub<10>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 12) launch_sort_sub<12>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 16) launch_sort_sub<16>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 20) launch_sort_sub<20>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 24) launch_sort_sub<24>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 28) launch_sort_sub<28>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else launch_sort_sub<36>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
     int64_t run = len;
     for (int level = sub; level > 1; level /= 2, run *= 2) {
       const int last = level == 2;
       const int tiles_per_pair = (int)((2 * run + MERGE_TILE - 1) / MERGE_TILE);
       const unsigned mgrid = (unsigned)(((I + 2 * run - 1) / (2 * run)) * tiles_per_pair);
       hipLaunchKernelGGL(k_merge_runs, dim3(mgrid, d), dim3(MERGE_THREADS), 0, st, keysA, idsA, I,
-                         run, tiles_per_pair, keysB, last ? order : idsB, last, sigma, c->sig_acc);
+                         run, tiles_per_pair, keysB, last ? order : idsB, last, sigma, sig_acc);
       std::swap(keysA, keysB);
       std::swap(idsA, idsB);
     }
     BPR_HIP_CHECK(hipGetLastError());
   } else {
-    hipLaunchKernelGGL(k_sigma, dim3(d), dim3(256), 0, st, c->keysT, I, sigma);
+    hipLaunchKernelGGL(k_sigma, dim3(d), dim3(256), 0, st, keysT, I, sigma);
     uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
-    hipLaunchKernelGGL(k_compose_keys, dim3(2048), dim3(256), 0, st, c->keysT, k64, n, I);
+    hipLaunchKernelGGL(k_compose_keys, dim3(2048), dim3(256), 0, st, keysT, k64, n, I);
     int key_bits = 32;
     while ((1 << (key_bits - 32)) < d) ++key_bits;
     size_t bytes = c->sort_tmp_bytes;

@@ -228,6 +228,7 @@ int bpr_train_stream_batched(bpr_ctx* c, const int32_t* users, const int32_t* po
                              int64_t n, int64_t B, int32_t sampler, float adaptive_p,
                              uint64_t seed, uint64_t offset, int64_t max_inflight,
                              float* out_scalars) {
+  if (c != nullptr) c->keys_cut = false;
   if (int rc = check_triples(c, "bpr_train_stream_batched", users, pos, n)) return rc;
   if (int rc = check_sampler(c, "bpr_train_stream_batched", sampler, adaptive_p, neg, n)) return rc;
   if (B < 1) return fail(BPR_ERR_INVALID, "bpr_train_stream_batched: B must be >= 1");

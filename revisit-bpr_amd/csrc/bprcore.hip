@@ -219,19 +219,14 @@ static int launch_triples(bpr_ctx* c, TripleArgs a, bool timed) {
 // in flight).  A cap below one 256-thread block shrinks the block (whole waves), so
 // max_inflight = 1 at G = 64 really is ONE wave walking the stream sequentially.
 static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_groups,
-                         float* out_scalars) {
+                         float* out_scalars, bool cut) {
   if (a.n <= 0) return BPR_OK;
+  if (cut)
+    if (int rc = refresh_alloc(c)) return rc;
   return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
     constexpr int G = T::G, E = T::E;
     const int64_t n_runs = (a.n + a.run_len - 1) / a.run_len;
-    // look-ahead of the run boundaries (k_stream): the view of a run — run_len + look + 1 triples
-    // and the predecessor — is held one triple per lane of the group
-    a.look = std::max(0, std::min({STREAM_LOOK_MAX, a.run_len - 1, G - 2 - a.run_len}));
-    {
-      const char* le = getenv("BPR_STREAM_LOOK");  // tests / measurements: 0 = nominal runs
-      if (le != nullptr) a.look = std::max(0, std::min(a.look, atoi(le)));
-    }
     unsigned block = 256;
     a.gpw_active = 64 / G;
     if (cap_groups > 0 && cap_groups * G < 256) {
@@ -301,7 +296,19 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       else with_seen(integral_constant<int, NEG_ADAPTIVE>{});
     }
     const bool hot = a.hot_slot != nullptr;
-    if (out_scalars != nullptr || hot) {
+    if (cut) {
+      // the epilogue also cuts the next snapshot's keys (k_stream_epilogue_cut) — into the key
+      // buffer the split refresh that may still be sorting does NOT read (bpr_ctx.h keysT_buf)
+      EpilogueCutArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.partials = a.partials; ea.n_blocks = (int)grid; ea.out = out_scalars;
+      ea.Q = c->Q; ea.delta = c->hot_delta; ea.hot_slot = hot ? c->hot_slot : nullptr;
+      ea.T = c->keysT; ea.sig_acc = c->sig_acc;
+      ea.H = hot ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d; ea.I = (int32_t)c->I;
+      dim3 eg((unsigned)((c->I + 31) / 32), (unsigned)((c->d + 31) / 32) + 1u);
+      hipLaunchKernelGGL(k_stream_epilogue_cut, eg, dim3(256), 0, c->stream, ea);
+      c->keys_cut = true;
+    } else if (out_scalars != nullptr || hot) {
       EpilogueArgs ea;
       memset(&ea, 0, sizeof(ea));
       ea.partials = a.partials; ea.n_blocks = (int)grid; ea.out = out_scalars;
@@ -433,6 +440,7 @@ int bpr_bind_tables(bpr_ctx* c, float* P, int64_t U, float* Q, int64_t I, int32_
     if (int rc = vs_leave(c)) return rc;  // pending steps belong to the tables bound so far
   }
   c->P = P; c->Q = Q; c->bias = item_bias;
+  c->keys_cut = false;
   c->U = U; c->I = I; c->d = d;
   c->pad_user = pad_user; c->pad_item = pad_item;
   c->G = d <= 128 ? 32 : 64;
@@ -701,6 +709,7 @@ int bpr_forward_grad(bpr_ctx* c, const int32_t* users, const int32_t* pos, const
 
 int bpr_apply(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_apply")) return rc;
+  c->keys_cut = false;
   if (int rc = check_opt_state(c, "bpr_apply")) return rc;
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (int rc = ensure_strict_scratch(c)) return rc;
@@ -754,10 +763,11 @@ int bpr_get_grad(bpr_ctx* c, float* gP, float* gQ, float* gbias) {
   return BPR_OK;
 }
 
-int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t n,
-                     int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
-                     int64_t max_inflight, float* out_scalars) {
+static int train_stream_impl(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg,
+                             int64_t n, int32_t sampler, float adaptive_p, uint64_t seed,
+                             uint64_t offset, int64_t max_inflight, float* out_scalars, bool cut) {
   if (int rc = check_triples(c, "bpr_train_stream", users, pos, n)) return rc;
+  c->keys_cut = false;  // the item table moves
   if (int rc = check_sampler(c, "bpr_train_stream", sampler, adaptive_p, neg, n)) return rc;
   if (c->opt_kind != BPR_OPT_SGD)
     return fail(BPR_ERR_UNSUPPORTED,
@@ -801,7 +811,24 @@ int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32
     a.hot_H = c->hot_H;
     a.hot_rmask = c->hot_R - 1;
   }
-  return launch_stream(c, a, sampler, max_inflight, out_scalars);
+  return launch_stream(c, a, sampler, max_inflight, out_scalars, cut);
+}
+
+int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t n,
+                     int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
+                     int64_t max_inflight, float* out_scalars) {
+  return train_stream_impl(c, users, pos, neg, n, sampler, adaptive_p, seed, offset, max_inflight,
+                           out_scalars, false);
+}
+
+int bpr_train_stream_cut(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg,
+                         int64_t n, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
+                         int64_t max_inflight, float* out_scalars) {
+  if (n <= 0)
+    return fail(BPR_ERR_INVALID, "bpr_train_stream_cut: needs a non-empty launch (the cut rides "
+                                 "on its epilogue)");
+  return train_stream_impl(c, users, pos, neg, n, sampler, adaptive_p, seed, offset, max_inflight,
+                           out_scalars, true);
 }
 
 int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t B,
@@ -932,9 +959,9 @@ int bpr_set_hot_rows(bpr_ctx* c, int32_t hot_rows, int32_t replicas) {
 
 int bpr_set_stream_opts(bpr_ctx* c, int32_t grouped_by_user, int32_t run_len) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: ctx is NULL");
-  if (run_len < 0 || run_len > 24)
-    return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: run_len must be 0 (by launch size) or in [1, 24] (one lane of a "
-                                 "32-lane group per triple of the run and of its look-ahead, plus the predecessor)");
+  if (run_len < 0 || run_len > 30)
+    return fail(BPR_ERR_INVALID, "bpr_set_stream_opts: run_len must be 0 (by launch size) or in [1, 30] (one lane of a "
+                                 "32-lane group per triple of the run, plus two neighbours)");
   c->grouped = grouped_by_user != 0;
   c->run_len = run_len;
   return BPR_OK;
@@ -951,6 +978,7 @@ int bpr_plan_epoch(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, i
 
 int bpr_flush_lazy(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_flush_lazy")) return rc;
+  c->keys_cut = false;
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->vs_active) return vs_flush(c, true, true);  // batched STREAM bookkeeping is live
   return strict_flush_impl(c);
@@ -958,6 +986,7 @@ int bpr_flush_lazy(bpr_ctx* c) {
 
 int bpr_flush_items(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_flush_items")) return rc;
+  c->keys_cut = false;
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->vs_active) return vs_flush(c, false, true);
   if (c->opt_kind == BPR_OPT_SGD || c->GP == nullptr || c->step == 0) return BPR_OK;

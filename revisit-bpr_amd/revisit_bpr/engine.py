@@ -347,17 +347,19 @@ class Engine:
 
     def train_stream(self, users, pos, sampler: int = NEG_UNIFORM, neg: Optional[torch.Tensor] = None,
                      adaptive_p: float = 0.01, seed: int = 0, offset: int = 0,
-                     max_inflight: int = 0, scalars: Optional[torch.Tensor] = None) -> None:
+                     max_inflight: int = 0, scalars: Optional[torch.Tensor] = None,
+                     cut: bool = False) -> None:
         """STREAM mode over users/pos (int32, on device) in one launch; `scalars` (if given) is
-        added to."""
+        added to.  cut=True: the launch's epilogue also cuts the keys of the next adaptive snapshot
+        (``bpr_train_stream_cut``) — the next `adaptive_refresh_begin` only queues the sort."""
         self._sync_stream()
         if users.dtype != torch.int32 or pos.dtype != torch.int32:
             raise ValueError("train_stream takes int32 id tensors (no hidden copies on the hot path)")
         if sampler == NEG_GIVEN and neg is None:
             raise ValueError("sampler NEG_GIVEN needs `neg`")
-        native.check(self._lib.bpr_train_stream(self._ctx, users.data_ptr(), pos.data_ptr(),
-                                                _ptr(neg), users.numel(), sampler, adaptive_p, seed,
-                                                offset, max_inflight, _ptr(scalars)))
+        fn = self._lib.bpr_train_stream_cut if cut else self._lib.bpr_train_stream
+        native.check(fn(self._ctx, users.data_ptr(), pos.data_ptr(), _ptr(neg), users.numel(),
+                        sampler, adaptive_p, seed, offset, max_inflight, _ptr(scalars)))
 
     def train_strict(self, users, pos, batch_size: int, sampler: int = NEG_UNIFORM,
                      neg: Optional[torch.Tensor] = None, adaptive_p: float = 0.01, seed: int = 0,

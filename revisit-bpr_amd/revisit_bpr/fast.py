@@ -84,11 +84,11 @@ class StreamTrainer:
         if item_sync is not None:
             self.rounds = item_sync.max_over_ranks(self.rounds)
 
-    def _launch(self, lo: int, hi: int) -> None:
+    def _launch(self, lo: int, hi: int, cut: bool = False) -> None:
         self.engine.train_stream(self._pu[lo:hi], self._pi[lo:hi], sampler=self.sampler,
                                  adaptive_p=self.adaptive_p, seed=self.seed,
                                  offset=(self.rank << 40) + self.drawn,
-                                 max_inflight=self.max_inflight, scalars=self._scalars)
+                                 max_inflight=self.max_inflight, scalars=self._scalars, cut=cut)
         self.drawn += hi - lo
 
     def _chunk(self, lo: int, hi: int) -> None:
@@ -98,8 +98,12 @@ class StreamTrainer:
         if lag == 0.0:
             e.adaptive_refresh()
             return self._launch(lo, hi)
+        # with one launch per snapshot (lag 1) and nothing touching the item table between two
+        # launches (no item reconciliation) the keys of the NEXT snapshot are cut by the epilogue
+        # of this launch: `begin` then only queues the sort
+        fused = lag >= 1.0 and self.item_sync is None
         if e.refresh_pending():
-            e.adaptive_refresh_commit()  # the snapshot cut during / before the previous launch
+            e.adaptive_refresh_commit()  # the snapshot cut before the previous launch
         else:
             e.adaptive_refresh()         # first launch: nothing in flight yet
         cut = lo if lag >= 1.0 else min(hi, lo + max(1, int(round((1.0 - lag) * (hi - lo)))))
@@ -107,7 +111,7 @@ class StreamTrainer:
             self._launch(lo, cut)
         e.adaptive_refresh_begin()
         if cut < hi:
-            self._launch(cut, hi)
+            self._launch(cut, hi, cut=fused)
 
     def train_epoch(self) -> dict:
         if self._main is not None:  # the whole epoch on the CU-masked stream

@@ -837,10 +837,10 @@ def test_refresh_follows_a_moving_table(I, d):
     check()
 
 
-# ---- run boundaries that bend to user boundaries (k_stream, `look`) --------------------------------
+# ---- run boundaries against user boundaries (k_stream) ----------------------------------------------
 def _tail_problem(d, seed, run_len):
-    """A user-grouped chunk whose users have every length from 1 to 3 run lengths, so nominal run
-    boundaries cut users with tails of every size around the look-ahead (<=, ==, > 6)."""
+    """A user-grouped chunk whose users have every length from 1 to 3 run lengths, so run
+    boundaries cut users at every offset (a user inside one run: plain store; cut: atomic delta)."""
     rng = np.random.default_rng(seed)
     lens = np.concatenate([np.arange(1, 3 * run_len + 2), rng.integers(1, 3 * run_len, 120)])
     rng.shuffle(lens)
@@ -858,15 +858,11 @@ def _tail_problem(d, seed, run_len):
     return P, Q, indptr, indices, users, pos
 
 
-@pytest.mark.parametrize("look", [None, 0, 2])
 @pytest.mark.parametrize("d,run_len", [(64, 8), (128, 8), (128, 4), (32, 24), (256, 8), (256, 5), (100, 7)])
-def test_stream_bent_runs_sequential_equals_b1_sgd(d, run_len, look, monkeypatch):
-    """One group walks the grouped chunk (max_inflight = 1): whatever the run length and the
-    look-ahead, every triple is processed exactly once and in stream order — the oracle's B = 1
-    stream — whether a user's tail is finished by the run that started it (plain store) or cut
-    (atomic delta)."""
-    if look is not None:
-        monkeypatch.setenv("BPR_STREAM_LOOK", str(look))
+def test_stream_runs_sequential_equals_b1_sgd(d, run_len):
+    """One group walks the grouped chunk (max_inflight = 1): whatever the run length, every triple
+    is processed exactly once and in stream order — the oracle's B = 1 stream — whether a user
+    lies inside a run (plain store) or is cut by a run boundary (atomic delta)."""
     P, Q, indptr, indices, users, pos = _tail_problem(d, 7 * d + run_len, run_len)
     n = len(users)
     reg = (0.01, 0.02, 0.03)
@@ -889,12 +885,10 @@ def test_stream_bent_runs_sequential_equals_b1_sgd(d, run_len, look, monkeypatch
 
 
 @pytest.mark.parametrize("d,run_len", [(128, 8), (64, 4), (256, 8), (32, 24), (128, 1)])
-def test_stream_bent_runs_partition_the_chunk_at_full_concurrency(d, run_len):
-    """Full chip, given negatives, lr -> 0 limit.  Neighbouring groups decide who owns a user's
-    tail without talking; if they ever disagreed a triple would be walked twice or not at all.
-    Every triple's user row must therefore move by exactly its first-order update: P equals the
-    oracle's summed-gradient step up to O(lr^2), the kernel counts n triples, and a given negative
-    makes the result independent of the sampler."""
+def test_stream_runs_partition_the_chunk_at_full_concurrency(d, run_len):
+    """Full chip, given negatives, lr -> 0 limit.  Every triple is walked exactly once whoever
+    owns its user: every row moves by exactly its first-order update — P and Q equal the oracle's
+    summed-gradient step up to O(lr^2), row by row — and the kernel counts n triples."""
     P, Q, indptr, indices, users, pos = _tail_problem(d, 3 * d + run_len, run_len)
     n = len(users)
     rng = np.random.default_rng(1)
@@ -959,8 +953,8 @@ def test_split_refresh_snapshots_the_table_at_begin(I, d, masked):
     assert np.array_equal(e.adaptive_snapshot()[0].cpu().numpy(), oracle.adaptive_order(QT2))
 
 
-@pytest.mark.parametrize("lag", [1.0, 0.4])
-def test_split_refresh_pipeline_sequential_equals_oracle(lag):
+@pytest.mark.parametrize("lag,fused", [(1.0, False), (1.0, True), (0.4, False)])
+def test_split_refresh_pipeline_sequential_equals_oracle(lag, fused):
     """The StreamTrainer's lagged schedule, one group at a time (max_inflight = 1), against the
     oracle walking the same triples with the snapshot the schedule prescribes: cut at `begin`,
     in force from `commit`."""
@@ -983,7 +977,7 @@ def test_split_refresh_pipeline_sequential_equals_oracle(lag):
 
     def both(lo, hi, cur):
         e.train_stream(u_d[lo:hi], p_d[lo:hi], sampler=2, neg=negs[lo:hi], adaptive_p=0.1, seed=9,
-                       offset=lo, max_inflight=1)
+                       offset=lo, max_inflight=1, cut=fused)
         oracle.train_stream_seq(Po, Qo, None, users[lo:hi], pos[lo:hi], neg_o[lo:hi], 2, 0.05, reg,
                                 adaptive_p=0.1, sigma=cur[0], order=cur[1], indptr=indptr,
                                 indices=indices, seed=9, offset=lo)

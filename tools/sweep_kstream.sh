@@ -3,7 +3,6 @@
 cd "$(dirname "$0")/.."
 run() { python bench.py --no-cpu-baseline --steps 94 --warmup 10 "$@" 2>&1 | python -c "
 import sys, json, os
-tag = ' '.join('%s=%s' % (k, os.environ[k]) for k in ('BPR_HEAVY_T', 'BPR_HOT_NAIVE', 'BPR_STREAM_LOOK') if k in os.environ)
 for l in sys.stdin:
     if l.startswith('{'):
         j = json.loads(l); r = j['roofline']
@@ -12,11 +11,11 @@ for l in sys.stdin:
 else:
     print(tag, ' '.join(sys.argv[1:]), 'FAILED')
 " "$@"; }
-export BPR_STREAM_LOOK=0
+
 for t in -1 128 256 512; do BPR_HEAVY_T=$t run; BPR_HEAVY_T=$t run --sampler uniform; done
 for h in 256 1024 2048 4096; do run --hot-rows $h --sampler given; BPR_HOT_NAIVE=1 run --hot-rows $h --sampler given; done
 for h in 1024 2048; do run --hot-rows $h; done
-export BPR_STREAM_LOOK=6
+
 run; run --hot-rows 1024; run --hot-rows 1024 --sampler given
-export BPR_STREAM_LOOK=0
+
 for c in 224 192 160; do run --main-cus $c --sampler given; run --main-cus $c; done

@@ -15,7 +15,6 @@ else:
 run --refresh-lag 0
 run --refresh-lag 0 --sampler given
 run --refresh-lag 0 --sampler uniform
-BPR_STREAM_LOOK=0 run --refresh-lag 0
 for cus in 0 32 48 64 96 128; do run --refresh-lag 1 --refresh-cus $cus; done
 for cus in 0 64 96 128; do run --refresh-lag 1 --refresh-split 2 --refresh-cus $cus; done
 for cus in 64 96; do run --refresh-lag 0.4 --refresh-cus $cus; done
