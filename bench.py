@@ -85,6 +85,12 @@ def parse_args():
     ap.add_argument("--batch-size", type=int, default=256,
                     help="reference batch size; only sets the refresh period I·ln(I)/B batches")
     ap.add_argument("--sync-every", type=int, default=1, help="item all-reduce period in steps (N>1)")
+    ap.add_argument("--cadence", choices=["job", "rank"], default="job",
+                    help="N>1: 'job' = every rank advances refresh period / N triples per step, so the "
+                         "snapshot refresh and the item reconciliation happen every I ln I triples of the "
+                         "WHOLE job (the cadence the multi-rank parity runs validate: "
+                         "tests/test_gpu_multirank_parity.py, DESIGN.md §7); 'rank' = a full period per "
+                         "rank and step (loses 0.016 nDCG at 4 ranks on the parity set)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink users/actions (debug)")
     ap.add_argument("--max-inflight", type=int, default=0)
     ap.add_argument("--time-every", type=int, default=8,
@@ -306,7 +312,8 @@ def main():
     # one launch, each grouped by user (the STREAM kernel keeps the user row in registers)
     every = max(1, int(I * math.log(I) / args.batch_size))  # example.py:302
     period = min(every * args.batch_size, data.nnz)
-    chunk = max(1, period // split)
+    ranks_per_period = world if args.cadence == "job" else 1
+    chunk = max(1, period // (split * ranks_per_period))
     n_chunks = max(1, data.nnz // chunk)
     src_users = torch.from_numpy(data.users).to(dev)
     src_items = torch.from_numpy(data.items).to(dev)
@@ -488,6 +495,9 @@ def main():
                                f"{split} launch(es) per refresh period, sort masked to {cus} CUs)"),
                 "triples_per_step_per_gpu": chunk,
                 "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus},
+                "cadence": (f"{args.cadence}: one snapshot refresh + item reconciliation per "
+                            f"{chunk * world if args.cadence == 'job' else chunk} triples of the "
+                            f"{'whole job' if args.cadence == 'job' else 'rank'}") if world > 1 else "single GPU",
                 "steps_per_epoch": n_chunks,
                 "plan_epoch": {"ms": plan_ms, "inside_timed_region": plans_timed,
                                "amortised_share_added_ms_per_step":

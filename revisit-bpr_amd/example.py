@@ -75,9 +75,19 @@ def strict_epoch(model, optimizer, sampler, users, items, seen_pad, batch_size, 
 @click.option("--seed", type=int, default=13, show_default=True)
 @click.option("--lr", type=float, default=0.00943667980759196, show_default=True)
 @click.option("--sampling-prob", type=float, default=1 / 700, show_default=True)
-@click.option("--mode", type=click.Choice(["stream", "strict"]), default="stream", show_default=True)
+@click.option("--mode", type=click.Choice(["stream", "batched", "strict"]), default="stream", show_default=True,
+              help="stream: fused SGD launches (StreamTrainer); batched: one launch per refresh period with "
+                   "virtual mini-batches, any --optimizer (BatchedStreamTrainer); strict: the reference's "
+                   "batch loop")
+@click.option("--optimizer", "opt_name", type=click.Choice(["sgd", "adam", "rmsprop", "nesterov"]),
+              default="sgd", show_default=True, help="batched / strict modes (stream is plain SGD)")
+@click.option("--refresh-lag", type=float, default=0.0, show_default=True,
+              help="stream mode: 1 = the adaptive snapshot is sorted beside the previous launch "
+                   "(StreamTrainer refresh_lag); 0 = the reference's schedule")
+@click.option("--refresh-cus", type=int, default=64, show_default=True,
+              help="stream mode with --refresh-lag > 0: CUs the snapshot sort is masked to")
 def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batch_size, epochs,
-         seed, lr, sampling_prob, mode):
+         seed, lr, sampling_prob, mode, opt_name, refresh_lag, refresh_cus):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s | %(message)s")
     if not torch.cuda.is_available():
         raise SystemExit("example.py needs an MI355X (no CPU path)")
@@ -111,7 +121,33 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
          for k in ("users", "items", "indptr", "indices", "eval_users", "eval_indptr", "eval_items")}
     metrics = build_metrics()
     every = int(num_items * math.log(num_items) / batch_size)
-    if mode == "stream":
+
+    def make_optimizer():
+        p = model.parameters()
+        return {"sgd": lambda: torch.optim.SGD(p, lr=lr),
+                "adam": lambda: torch.optim.Adam(p, lr=lr, betas=(0.1, 0.999)),  # ada-sampling-adam.yaml.j2:175
+                "rmsprop": lambda: torch.optim.RMSprop(p, lr=lr, alpha=0.9),
+                "nesterov": lambda: torch.optim.SGD(p, lr=lr, momentum=0.9, nesterov=True)}[opt_name]()
+
+    if mode == "stream" and opt_name != "sgd":
+        raise SystemExit("--mode stream is the fused SGD kernel; use --mode batched for --optimizer " + opt_name)
+    if mode == "batched":
+        from revisit_bpr.fast import BatchedStreamTrainer
+
+        users_t, items_t, sync = t["users"], t["items"], None
+        if world > 1:
+            from revisit_bpr.distributed import ItemSync, balanced_user_shards, owner_of
+
+            bounds = balanced_user_shards(data.indptr, world)
+            mine = torch.from_numpy(owner_of(data.users, bounds) == rank).to(dev)
+            users_t, items_t = users_t[mine].contiguous(), items_t[mine].contiguous()
+            f = model.logits_model.get_features()
+            sync = ItemSync([f["item"].data] + ([f["item_bias"].data] if f["item_bias"] is not None else []))
+        trainer = BatchedStreamTrainer(model, make_optimizer(), users_t, items_t, t["indptr"], t["indices"],
+                                       sampler="adaptive", adaptive_p=sampling_prob, batch_size=batch_size,
+                                       seed=seed, rank=rank, item_sync=sync)
+        run_epoch = trainer.train_epoch
+    elif mode == "stream":
         users_t, items_t, sync = t["users"], t["items"], None
         if world > 1:  # this rank trains the triples of its own user range only
             from revisit_bpr.distributed import ItemSync, balanced_user_shards, owner_of
@@ -123,7 +159,8 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
             sync = ItemSync([f["item"].data] + ([f["item_bias"].data] if f["item_bias"] is not None else []))
         trainer = StreamTrainer(model, users_t, items_t, t["indptr"], t["indices"], lr=lr,
                                 sampler="adaptive", adaptive_p=sampling_prob,
-                                batch_size=batch_size, seed=seed, rank=rank, item_sync=sync)
+                                batch_size=batch_size, seed=seed, rank=rank, item_sync=sync,
+                                refresh_lag=refresh_lag, refresh_cus=refresh_cus if refresh_lag > 0 else 0)
         run_epoch = trainer.train_epoch
     elif world > 1:  # reference mini-batches per user shard, item table reconciled by ItemSync
         from revisit_bpr.distributed import ItemSync, balanced_user_shards, owner_of
@@ -133,7 +170,7 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
         mine = torch.from_numpy(owner_of(data.users, bounds) == rank).to(dev)
         f = model.logits_model.get_features()
         sync = ItemSync([f["item"].data] + ([f["item_bias"].data] if f["item_bias"] is not None else []))
-        optimizer = torch.optim.SGD(model.parameters(), lr=lr)
+        optimizer = make_optimizer()
         trainer = StrictTrainer(model, optimizer, t["users"][mine].contiguous(),
                                 t["items"][mine].contiguous(), t["indptr"], t["indices"],
                                 sampler="adaptive", adaptive_p=sampling_prob, batch_size=batch_size,
@@ -141,7 +178,7 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
         run_epoch = trainer.train_epoch
     else:
         model.bind_seen_csr(t["indptr"], t["indices"])
-        optimizer = torch.optim.SGD(model.parameters(), lr=lr)
+        optimizer = make_optimizer()
         gen = torch.Generator(device=dev).manual_seed(seed)
         sampler = AdaptiveSampler(model, num_items=num_items, sampling_prob=sampling_prob,
                                   every=every, neg_gen=gen)
@@ -166,6 +203,8 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
                 lo_r, hi_r = int(bounds[r]), int(bounds[r + 1])
                 if hi_r > lo_r:
                     dist.broadcast(P[lo_r:hi_r], src=r)
+        if mode != "stream":
+            model.sync()  # lazily-updated rows -> "now" before the tables are read
         if t["eval_users"].numel() and rank == 0:
             model.eval()
             f = model.logits_model.get_features()

@@ -35,6 +35,14 @@ from revisit_bpr.modules import AdaptiveSampler, UniformSampler  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
 USERS, ITEMS, ACTIONS, D, B, EPOCHS, LR = 4000, 1500, 120_000, 32, 256, 12, 0.05
+# E2E_SET=cfg1: the same protocol at BASELINE configs[0] size (10 k users x 5 k items, 500 k actions,
+# d = 32, B = 256): `E2E_SET=cfg1 make_golden_e2e.py cfg1 <kind>_<seed> ...` writes one
+# e2e_cfg1_<kind>_<seed>.json per run, `E2E_SET=cfg1 make_golden_e2e.py merge cfg1` folds them into
+# e2e_cfg1_reference.json.  The dataset is not stored (it is our generator's, seeded): the fixture
+# carries its checksum.
+CFG1 = os.environ.get("E2E_SET") == "cfg1"
+if CFG1:
+    USERS, ITEMS, ACTIONS, EPOCHS = 10_000, 5_000, 500_000, 8
 REG = {"user": 0.0016, "item": 0.0001, "neg": 0.00375}
 INIT_SEED, ORDER_SEED = 13, 13
 SAMPLER_SEEDS = [1, 2, 3, 4, 5]
@@ -153,7 +161,52 @@ def main_opt(name, only):
               flush=True)
 
 
+def cfg1_data():
+    return synthetic.generate_latent(USERS, ITEMS, ACTIONS, factors=8, strength=1.5,
+                                     median_per_user=25, min_per_user=5, seed=7, eval_users=2000)
+
+
+def data_checksum(data):
+    import hashlib
+    h = hashlib.sha256()
+    for a in (data.users, data.items, data.indptr, data.indices, data.eval_users, data.eval_indptr,
+              data.eval_items):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def main_cfg1(args):
+    torch.set_num_threads(1)
+    if args[:1] == ["merge"]:
+        data = cfg1_data()
+        res = {"config": {"users": USERS, "items": ITEMS, "actions": ACTIONS, "train_triples": int(data.nnz),
+                          "d": D, "B": B, "epochs": EPOCHS, "lr": LR, "reg": REG, "init_seed": INIT_SEED,
+                          "order_seed": ORDER_SEED, "adaptive_p": ADAPTIVE_P,
+                          "eval_users": int(len(data.eval_users)), "generator": "synthetic.generate_latent("
+                          "10000, 5000, 500000, factors=8, strength=1.5, median_per_user=25, min_per_user=5, "
+                          "seed=7, eval_users=2000)", "data_sha256": data_checksum(data)}, "runs": {}}
+        for f in sorted(OUT.glob("e2e_cfg1_*_*.json")):
+            if f.name == "e2e_cfg1_reference.json":
+                continue
+            j = json.loads(f.read_text())
+            res["runs"][f.stem[len("e2e_cfg1_"):]] = j
+            f.unlink()
+        (OUT / "e2e_cfg1_reference.json").write_text(json.dumps(res, indent=1))
+        print(sorted(res["runs"]))
+        return
+    data = cfg1_data()
+    seen_all = padded_seen(data, np.arange(data.num_users))
+    for kind, s in [(k, int(v)) for k, v in (r.split("_") for r in args)]:
+        t0 = time.time()
+        curve = run(data, seen_all, kind, s)
+        (OUT / f"e2e_cfg1_{kind}_{s}.json").write_text(json.dumps(
+            {"ndcg@100": [c[0] for c in curve], "recall@20": [c[1] for c in curve]}, indent=1))
+        print("cfg1", kind, s, f"{time.time() - t0:.0f}s", [round(c[0], 4) for c in curve], flush=True)
+
+
 def main():
+    if CFG1:
+        return main_cfg1(sys.argv[2:] if sys.argv[1:2] == ["cfg1"] else sys.argv[1:])
     if sys.argv[1:2] == ["merge"]:
         return merge(sys.argv[2])
     if sys.argv[1:2] and sys.argv[1] in OPT_KW:

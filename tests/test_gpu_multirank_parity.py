@@ -16,13 +16,16 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 
 
-@pytest.mark.parametrize("kind", ["uniform", "adaptive"])
-def test_two_rank_training_matches_reference_curves(golden_dir, kind):
+@pytest.mark.parametrize("kind,mode", [("uniform", "stream"), ("adaptive", "stream"),
+                                       ("adaptive", "stream-lag")])
+def test_two_rank_training_matches_reference_curves(golden_dir, kind, mode):
+    """mode stream-lag: the overlapped snapshot schedule (sort beside the previous launch, CU-masked
+    streams) with the item reconciliation between the launches."""
     env = dict(os.environ, BPR_DIST_BACKEND="gloo")
-    port = {"uniform": "29631", "adaptive": "29632"}[kind]
+    port = {"uniform": "29631", "adaptive": "29632"}[kind] if mode == "stream" else "29634"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "tools" / "parity_multi.py"),
-           kind, "1,2,3,4,5"]
+           kind, "1,2,3,4,5", mode]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     runs = [json.loads(line) for line in res.stdout.splitlines() if line.startswith("{")]
@@ -78,6 +81,29 @@ def test_two_rank_adam_training_matches_single_process():
     print("\n".join(report))
     assert ok, "\n".join(report)
     assert np.mean([r["ndcg@100"][-1] for r in two]) > 0.4  # it learned
+
+
+def test_two_rank_batched_adam_matches_single_process():
+    """BASELINE config 5 on its THROUGHPUT path: BatchedStreamTrainer (one launch per refresh
+    period, virtual mini-batches, torch.optim.Adam semantics) on two user shards with the item table
+    reconciled by ItemSync every period, against the same trainer on one rank (itself held to the
+    reference's Adam curves by tests/test_gpu_e2e_parity.py).  Local Adam: the plateau must agree."""
+    one = _run_parity_multi(1, ["adaptive", "1,2,3,4,5", "batched-adam"], "0")
+    two = _run_parity_multi(2, ["adaptive", "1,2,3,4,5", "batched-adam"], "29635")
+    assert len(one) == 5 and len(two) == 5 and all(r["world"] == 2 for r in two)
+    report, ok = [], True
+    for key in ("ndcg@100", "recall@20"):
+        for epoch in (-2, -1):
+            a = np.array([r[key][epoch] for r in one])
+            b = np.array([r[key][epoch] for r in two])
+            se = math.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+            tol = 0.003 + 2 * se
+            report.append(f"batched adam 2 ranks vs 1 {key} epoch {epoch}: {b.mean():.4f} vs {a.mean():.4f} "
+                          f"diff {b.mean() - a.mean():+.4f} tol {tol:.4f}")
+            ok &= abs(b.mean() - a.mean()) <= tol
+    print("\n".join(report))
+    assert ok, "\n".join(report)
+    assert np.mean([r["ndcg@100"][-1] for r in two]) > 0.4
 
 
 def test_item_sync_fused_step_equals_finish_then_start():

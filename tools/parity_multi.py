@@ -16,7 +16,7 @@ import torch.distributed as dist  # noqa: E402
 
 from revisit_bpr.distributed import ItemSync, balanced_user_shards, owner_of  # noqa: E402
 from revisit_bpr.evaluation import evaluate_topk  # noqa: E402
-from revisit_bpr.fast import StreamTrainer, StrictTrainer  # noqa: E402
+from revisit_bpr.fast import BatchedStreamTrainer, StreamTrainer, StrictTrainer  # noqa: E402
 from revisit_bpr.models import BPR  # noqa: E402
 from revisit_bpr.models.bpr import MF  # noqa: E402
 
@@ -24,7 +24,9 @@ from revisit_bpr.models.bpr import MF  # noqa: E402
 def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "uniform"
     seeds = [int(s) for s in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2", "3"])]
-    mode = sys.argv[3] if len(sys.argv) > 3 else "stream"  # "stream" (SGD) | "adam" (STRICT, Adam)
+    # "stream" (SGD, fused kernel) | "stream-lag" (the same with the overlapped snapshot schedule) |
+    # "adam" / "sgd" (STRICT mini-batches) | "batched-adam" (single-launch Adam: BASELINE configs[4])
+    mode = sys.argv[3] if len(sys.argv) > 3 else "stream"
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -59,7 +61,13 @@ def main():
                                     torch.nn.Embedding(I, cfg["d"], padding_idx=0))).to(dev)
         f = model.logits_model.get_features()
         sync = ItemSync([f["item"].data]) if world > 1 else None
-        if mode in ("adam", "sgd"):
+        if mode == "batched-adam":
+            opt = torch.optim.Adam(model.parameters(), lr=float(os.environ.get("BPR_ADAM_LR", "0.002")))
+            tr = BatchedStreamTrainer(model, opt, t["users"][mine].contiguous(),
+                                      t["items"][mine].contiguous(), t["indptr"], t["indices"],
+                                      sampler=kind, adaptive_p=cfg["adaptive_p"], batch_size=cfg["B"],
+                                      seed=seed, rank=rank, item_sync=sync)
+        elif mode in ("adam", "sgd"):
             opt = (torch.optim.Adam(model.parameters(), lr=float(os.environ.get("BPR_ADAM_LR", "0.002")))
                    if mode == "adam" else torch.optim.SGD(model.parameters(), lr=cfg["lr"]))
             tr = StrictTrainer(model, opt, t["users"][mine].contiguous(), t["items"][mine].contiguous(),
@@ -69,7 +77,8 @@ def main():
             tr = StreamTrainer(model, t["users"][mine].contiguous(), t["items"][mine].contiguous(),
                                t["indptr"], t["indices"], lr=cfg["lr"], sampler=kind,
                                adaptive_p=cfg["adaptive_p"], batch_size=cfg["B"], seed=seed, rank=rank,
-                               item_sync=sync)
+                               item_sync=sync,
+                               **({"refresh_lag": 1.0, "refresh_cus": 64} if mode == "stream-lag" else {}))
         curve = []
         for _ in range(cfg["epochs"]):
             tr.train_epoch()
@@ -78,7 +87,7 @@ def main():
                     lo, hi = int(bounds[r]), int(bounds[r + 1])
                     if hi > lo:
                         dist.broadcast(f["user"].data[lo:hi], src=r)
-            if mode in ("adam", "sgd"):
+            if mode in ("adam", "sgd", "batched-adam"):
                 model.sync()  # bring lazily-updated rows to "now" before reading the tables
             if rank == 0:
                 m = evaluate_topk(f["user"].data, f["item"].data, None, t["eval_users"], t["eval_indptr"],
