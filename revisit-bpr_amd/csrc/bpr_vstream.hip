@@ -61,7 +61,8 @@ static VOpt vopt(const bpr_ctx* c) {
       o.kmax = ratio < 1.0 ? (int)ceil(log(1e-8) / log(ratio)) : 1 << 20;
       const bool no_closed = getenv("BPR_NO_ADAM_CLOSED") != nullptr;  // tests compare both routes
       const double zmax = b1 / pow(b2, 0.5 * VADAM_SERIES);
-      if (!no_closed && zmax < 0.999 && o.kmax >= 16 && o.kmax < (1 << 20)) {
+      o.closed_min = o.kmax >= 64 ? 16 : 3;
+      if (!no_closed && zmax < 0.999 && o.kmax >= 4 && o.kmax < (1 << 20)) {
         for (int j = 0; j < VADAM_SERIES; ++j) {
           const double lz = log(b1) - 0.5 * (j + 1) * log(b2), z = exp(lz);
           o.zc[j] = (float)(z / (1.0 - z));
