@@ -90,7 +90,11 @@ def parse_args():
                          "snapshot refresh and the item reconciliation happen every I ln I triples of the "
                          "WHOLE job (the cadence the multi-rank parity runs validate: "
                          "tests/test_gpu_multirank_parity.py, DESIGN.md §7); 'rank' = a full period per "
-                         "rank and step (loses 0.016 nDCG at 4 ranks on the parity set)")
+                         "rank and step (measured unsafe: at the full ML-20M shape 4 ranks DIVERGE at lr 0.05, "
+                         "profiles/r03_cadence_study.txt)")
+    ap.add_argument("--shard-refresh", action="store_true",
+                    help="N>1, --refresh-lag 0: every rank sorts d/N factors of the snapshot and an all-gather "
+                         "shares them (Engine.adaptive_refresh_sharded)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink users/actions (debug)")
     ap.add_argument("--max-inflight", type=int, default=0)
     ap.add_argument("--time-every", type=int, default=8,
@@ -362,7 +366,10 @@ def main():
         if sampler != eng.NEG_ADAPTIVE:
             launch(k, lo, lo + chunk, lo)
         elif lag == 0.0:
-            e.adaptive_refresh()  # batched: brings the item rows to "now" first
+            if args.shard_refresh and world > 1 and not batched:
+                e.adaptive_refresh_sharded(rank, world)
+            else:
+                e.adaptive_refresh()  # batched: brings the item rows to "now" first
             launch(k, lo, lo + chunk, lo)
         else:  # the same schedule as fast.StreamTrainer._chunk
             if e.refresh_pending():

@@ -154,6 +154,17 @@ int bpr_adaptive_refresh_begin(bpr_ctx* ctx);
 int bpr_adaptive_refresh_commit(bpr_ctx* ctx);
 /* *pending_host (HOST pointer) = 1 while a split refresh awaits its commit. */
 int bpr_adaptive_refresh_pending(bpr_ctx* ctx, int32_t* pending_host);
+/* The refresh SHARDED over the ranks of a multi-GPU job: every rank holds a replica of the item
+ * table, so instead of every rank sorting all d columns (an Amdahl term: the sort does not shrink
+ * with the number of ranks) rank r sorts columns [f_lo, f_hi) only — _part cuts the keys and
+ * sorts those columns into the BACK snapshot —, the caller gathers every rank's columns into the
+ * back snapshot of every rank (order [d, I] int32 and sigma [d] fp32: _snapshot_ptrs hands out the
+ * device pointers, back != 0 for the back snapshot; an all-gather over RCCL in
+ * revisit_bpr/distributed.py) and _publish makes it the snapshot the samplers read.  All in the ctx
+ * stream's order.  The reference has no multi-device sampler to mirror. */
+int bpr_adaptive_refresh_part(bpr_ctx* ctx, int32_t f_lo, int32_t f_hi);
+int bpr_adaptive_refresh_publish(bpr_ctx* ctx);
+int bpr_adaptive_snapshot_ptrs(bpr_ctx* ctx, int32_t back, void** order_host, void** sigma_host);
 /* The side stream of the split refresh (a hipStream_t of the ctx's device; NULL = a plain
  * non-blocking stream created by the library on first use).  The caller keeps ownership. */
 int bpr_set_side_stream(bpr_ctx* ctx, void* hip_stream);

@@ -72,6 +72,7 @@ struct bpr_ctx {
   bool side_owned = false;
   hipEvent_t ev_keys = nullptr, ev_sorted = nullptr;
   bool refresh_pending = false;
+  bool part_pending = false;  // bpr_adaptive_refresh_part: this rank's columns are sorted, publish pending
   // bpr_train_stream_cut: the launch's epilogue already cut the next snapshot's keys (keysT); the
   // next bpr_adaptive_refresh_begin only queues the sort.  Any call that moves the item table
   // afterwards clears it.
@@ -116,7 +117,8 @@ struct bpr_ctx {
 
 namespace bpr {
 void set_error(const std::string& msg);
-int refresh_impl(bpr_ctx* c, bool split);  // bpr_refresh.hip: split = sort on c->side, no swap
+int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi);  // bpr_refresh.hip: split = sort on c->side, no swap
+int refresh_publish_impl(bpr_ctx* c);       // bpr_refresh.hip
 int refresh_alloc(bpr_ctx* c);             // bpr_refresh.hip: the snapshot buffers (idempotent)
 int refresh_commit_impl(bpr_ctx* c);        // bpr_refresh.hip
 void refresh_free(bpr_ctx* c);      // bpr_refresh.hip

@@ -298,10 +298,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_runs(
 }
 
 template <int ITEMS>
-static void launch_sort_sub(bpr_ctx* c, hipStream_t st, const float* keysT, double* sig_acc,
+static void launch_sort_sub(bpr_ctx* c, hipStream_t st, int nf, const float* keysT, double* sig_acc,
                             int32_t* order, float* sigma, int sub, int64_t len, float* keysA,
                             int32_t* idsA) {
-  hipLaunchKernelGGL((k_sort_sub<ITEMS>), dim3(sub, c->d), dim3(1024), 0, st, keysT, c->I, len,
+  hipLaunchKernelGGL((k_sort_sub<ITEMS>), dim3(sub, nf), dim3(1024), 0, st, keysT, c->I, len,
                      order, keysA, idsA, sigma, sig_acc);
 }
 
@@ -675,6 +675,7 @@ void refresh_free(bpr_ctx* c) {
   c->sort_tmp_bytes = 0;
   c->have_snapshot = false;
   c->refresh_pending = false;
+  c->part_pending = false;
 }
 
 void side_free(bpr_ctx* c) {  // bpr_ctx_destroy: the split refresh's events and (if ours) stream
@@ -735,18 +736,29 @@ int refresh_alloc(bpr_ctx* c) {
   return BPR_OK;
 }
 
-int refresh_impl(bpr_ctx* c, bool split) {
-  if (c->refresh_pending) {
-    set_error("bpr_adaptive_refresh: a split refresh is pending (bpr_adaptive_refresh_commit first)");
+int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
+  if (c->refresh_pending || c->part_pending) {
+    set_error("bpr_adaptive_refresh: a split or sharded refresh is pending (bpr_adaptive_refresh_commit / "
+              "_publish first)");
     return BPR_ERR_INVALID;
   }
   if (int rc = refresh_alloc(c)) return rc;
+  if (f_lo < 0 || f_hi > c->d || f_lo >= f_hi) {
+    set_error("bpr_adaptive_refresh_part: need 0 <= f_lo < f_hi <= d");
+    return BPR_ERR_INVALID;
+  }
   const int64_t I = c->I;
   const int d = c->d;
   const int64_t n = (int64_t)d * I;
+  // f_lo .. f_hi: the factors (columns) this call sorts — all of them, or this rank's share of a
+  // refresh sharded over the ranks of a multi-GPU job (bpr_adaptive_refresh_part: the caller
+  // gathers the other columns into the back snapshot and publishes it)
+  const bool part = f_lo != 0 || f_hi != d;
+  const int nf = f_hi - f_lo;
+  const int64_t foff = (int64_t)f_lo * I;
   const int back = c->have_snapshot ? (c->snap_front ^ 1) : c->snap_front;
-  int32_t* const order = c->order_alloc[back] + BPR_ORDER_PAD;
-  float* const sigma = c->sigma_buf[back];
+  int32_t* const order = c->order_alloc[back] + BPR_ORDER_PAD + foff;
+  float* const sigma = c->sigma_buf[back] + f_lo;
   // ---- cut (unless the last STREAM launch's epilogue did it: bpr_train_stream_cut)
   if (!c->keys_cut) {
     dim3 tgrid((unsigned)((I + 31) / 32), (unsigned)((d + 31) / 32));
@@ -755,8 +767,8 @@ int refresh_impl(bpr_ctx* c, bool split) {
   }
   c->keys_cut = false;
   // the sort reads the buffers just cut; the next cut goes to the other pair
-  const float* const keysT = c->keysT;
-  double* const sig_acc = c->sig_acc;
+  const float* const keysT = c->keysT + foff;
+  double* const sig_acc = c->sig_acc + 2 * f_lo;
   c->keys_w ^= 1;
   c->keysT = c->keysT_buf[c->keys_w];
   c->sig_acc = c->sig_acc_buf[c->keys_w];
@@ -788,7 +800,7 @@ int refresh_impl(bpr_ctx* c, bool split) {
   int sub = 1;
   while (sub < 4 && (I + sub - 1) / sub > 1024 * 36) sub *= 2;
   if (!split)
-    while (sub < 4 && d * sub < 256 && I / (2 * sub) >= 5000) sub *= 2;
+    while (sub < 4 && nf * sub < 256 && I / (2 * sub) >= 5000) sub *= 2;
   if (force_sub == 1 || force_sub == 2 || force_sub == 4) sub = force_sub;
   int64_t len = (I + sub - 1) / sub;
   len = (len + 15) / 16 * 16;
@@ -797,36 +809,41 @@ int refresh_impl(bpr_ctx* c, bool split) {
     int32_t* idsA = reinterpret_cast<int32_t*>(keysA + n);
     float* keysB = reinterpret_cast<float*>(idsA + n);
     int32_t* idsB = reinterpret_cast<int32_t*>(keysB + n);
+    keysA += foff; idsA += foff; keysB += foff; idsB += foff;  // (the kernels index columns from 0)
     const int items = (int)((len + 1023) / 1024);
-    if (items <= 6) launch_sort_sub<6>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 10) launch_sort_sub<10>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 12) launch_sort_sub<12>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 16) launch_sort_sub<16>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 20) launch_sort_sub<20>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 24) launch_sort_sub<24>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 28) launch_sort_sub<28>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else launch_sort_sub<36>(c, st, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    if (items <= 6) launch_sort_sub<6>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 10) launch_sort_sub<10>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 12) launch_sort_sub<12>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 16) launch_sort_sub<16>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 20) launch_sort_sub<20>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 24) launch_sort_sub<24>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else if (items <= 28) launch_sort_sub<28>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    else launch_sort_sub<36>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
     int64_t run = len;
     for (int level = sub; level > 1; level /= 2, run *= 2) {
       const int last = level == 2;
       const int tiles_per_pair = (int)((2 * run + MERGE_TILE - 1) / MERGE_TILE);
       const unsigned mgrid = (unsigned)(((I + 2 * run - 1) / (2 * run)) * tiles_per_pair);
-      hipLaunchKernelGGL(k_merge_runs, dim3(mgrid, d), dim3(MERGE_THREADS), 0, st, keysA, idsA, I,
+      hipLaunchKernelGGL(k_merge_runs, dim3(mgrid, nf), dim3(MERGE_THREADS), 0, st, keysA, idsA, I,
                          run, tiles_per_pair, keysB, last ? order : idsB, last, sigma, sig_acc);
       std::swap(keysA, keysB);
       std::swap(idsA, idsB);
     }
     BPR_HIP_CHECK(hipGetLastError());
-  } else {
-    hipLaunchKernelGGL(k_sigma, dim3(d), dim3(256), 0, st, keysT, I, sigma);
+  } else {  // device-wide sort: always every column (a sharded refresh is merely redundant here)
+    hipLaunchKernelGGL(k_sigma, dim3(d), dim3(256), 0, st, keysT - foff, I, sigma - f_lo);
     uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
-    hipLaunchKernelGGL(k_compose_keys, dim3(2048), dim3(256), 0, st, keysT, k64, n, I);
+    hipLaunchKernelGGL(k_compose_keys, dim3(2048), dim3(256), 0, st, keysT - foff, k64, n, I);
     int key_bits = 32;
     while ((1 << (key_bits - 32)) < d) ++key_bits;
     size_t bytes = c->sort_tmp_bytes;
     BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp, bytes, k64, k64 + n, c->ids_in,
-                                                     order, (int)n, 0, key_bits, st));
+                                                     order - foff, (int)n, 0, key_bits, st));
     BPR_HIP_CHECK(hipGetLastError());
+  }
+  if (part) {  // the caller fills the other columns and publishes (refresh_publish_impl)
+    c->part_pending = true;
+    return BPR_OK;
   }
   if (split) {
     BPR_HIP_CHECK(hipEventRecord(c->ev_sorted, c->side));
@@ -837,6 +854,20 @@ int refresh_impl(bpr_ctx* c, bool split) {
   c->order = order;
   c->sigma = sigma;
   c->have_snapshot = true;
+  return BPR_OK;
+}
+
+int refresh_publish_impl(bpr_ctx* c) {
+  if (!c->part_pending) {
+    set_error("bpr_adaptive_refresh_publish: no sharded refresh is pending");
+    return BPR_ERR_INVALID;
+  }
+  const int back = c->have_snapshot ? (c->snap_front ^ 1) : c->snap_front;
+  c->snap_front = back;
+  c->order = c->order_alloc[back] + BPR_ORDER_PAD;
+  c->sigma = c->sigma_buf[back];
+  c->have_snapshot = true;
+  c->part_pending = false;
   return BPR_OK;
 }
 

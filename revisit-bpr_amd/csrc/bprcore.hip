@@ -580,7 +580,7 @@ int bpr_adaptive_refresh(bpr_ctx* c) {
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->vs_active)  // batched STREAM: the snapshot must see the item rows as of "now"
     if (int rc = vs_flush(c, false, true)) return rc;
-  return refresh_impl(c, false);
+  return refresh_impl(c, false, 0, c->d);
 }
 
 int bpr_adaptive_refresh_begin(bpr_ctx* c) {
@@ -588,13 +588,39 @@ int bpr_adaptive_refresh_begin(bpr_ctx* c) {
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->vs_active)
     if (int rc = vs_flush(c, false, true)) return rc;
-  return refresh_impl(c, true);
+  return refresh_impl(c, true, 0, c->d);
 }
 
 int bpr_adaptive_refresh_commit(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_adaptive_refresh_commit")) return rc;
   BPR_HIP_CHECK(hipSetDevice(c->device));
   return refresh_commit_impl(c);
+}
+
+int bpr_adaptive_refresh_part(bpr_ctx* c, int32_t f_lo, int32_t f_hi) {
+  if (int rc = check_bound(c, "bpr_adaptive_refresh_part")) return rc;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (c->vs_active)
+    if (int rc = vs_flush(c, false, true)) return rc;
+  return refresh_impl(c, false, f_lo, f_hi);
+}
+
+int bpr_adaptive_refresh_publish(bpr_ctx* c) {
+  if (int rc = check_bound(c, "bpr_adaptive_refresh_publish")) return rc;
+  return refresh_publish_impl(c);
+}
+
+int bpr_adaptive_snapshot_ptrs(bpr_ctx* c, int32_t back, void** order_host, void** sigma_host) {
+  if (int rc = check_bound(c, "bpr_adaptive_snapshot_ptrs")) return rc;
+  if (order_host == nullptr || sigma_host == nullptr)
+    return fail(BPR_ERR_INVALID, "bpr_adaptive_snapshot_ptrs: NULL argument");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = refresh_alloc(c)) return rc;
+  const int front = c->snap_front;
+  const int which = back ? (c->have_snapshot ? front ^ 1 : front) : front;
+  *order_host = (void*)(c->order_alloc[which] + BPR_ORDER_PAD);
+  *sigma_host = (void*)c->sigma_buf[which];
+  return BPR_OK;
 }
 
 int bpr_adaptive_refresh_pending(bpr_ctx* c, int32_t* pending_host) {

@@ -84,6 +84,10 @@ class ItemSync:
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    @property
+    def rank(self) -> int:
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
     def max_over_ranks(self, value: int) -> int:
         """MAX of a host integer over the group (e.g. chunks per epoch: ranks whose shard holds
         fewer chunks must still take part in every reconciliation, or the collectives of different

@@ -22,7 +22,8 @@ class StreamTrainer:
                  adaptive_p: float = 0.01, batch_size: int = 256, seed: int = 13,
                  max_inflight: Optional[int] = None, run_len: int = 0, rank: int = 0,
                  item_sync=None, sync_every: int = 1, world: Optional[int] = None,
-                 refresh_lag: float = 0.0, refresh_split: int = 1, refresh_cus: int = 0) -> None:
+                 refresh_lag: float = 0.0, refresh_split: int = 1, refresh_cus: int = 0,
+                 shard_refresh: bool = False) -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
         adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302.
@@ -37,7 +38,10 @@ class StreamTrainer:
                             0 < f < 1: a launch is cut at 1 - f; the next launch's snapshot is taken
                                there and sorted beside the remainder.
           refresh_cus n     n > 0: the sort runs on a stream masked to n of the chip's CUs and the
-                            STREAM kernel on the complementary mask (0: unmasked side stream)."""
+                            STREAM kernel on the complementary mask (0: unmasked side stream).
+          shard_refresh     several ranks (item_sync): every rank sorts d / world factors and an
+                            all-gather shares the orders (Engine.adaptive_refresh_sharded) instead
+                            of every rank sorting all of them; refresh_lag 0 only."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
             raise ValueError("users / items must be int32 device tensors")
         if not 0.0 <= refresh_lag <= 1.0 or refresh_split < 1:
@@ -64,6 +68,9 @@ class StreamTrainer:
         self.max_inflight = max(64, U // 4) if max_inflight is None else max_inflight
         self.engine.set_stream_opts(True, run_len)
         self.refresh_lag = float(refresh_lag) if self.sampler == eng.NEG_ADAPTIVE else 0.0
+        self.shard_refresh = bool(shard_refresh) and item_sync is not None and item_sync.world > 1
+        if self.shard_refresh and self.refresh_lag != 0.0:
+            raise ValueError("shard_refresh needs refresh_lag = 0")
         self._main = self._side = None
         if self.refresh_lag > 0.0 and refresh_cus > 0:
             total = torch.cuda.get_device_properties(users.device).multi_processor_count
@@ -96,7 +103,10 @@ class StreamTrainer:
         if self.sampler != eng.NEG_ADAPTIVE:
             return self._launch(lo, hi)
         if lag == 0.0:
-            e.adaptive_refresh()
+            if self.shard_refresh:
+                e.adaptive_refresh_sharded(self.item_sync.rank, self.item_sync.world, self.item_sync.group)
+            else:
+                e.adaptive_refresh()
             return self._launch(lo, hi)
         # with one launch per snapshot (lag 1) and nothing touching the item table between two
         # launches (no item reconciliation) the keys of the NEXT snapshot are cut by the epilogue

@@ -63,6 +63,9 @@ SIGNATURES = {
     "bpr_adaptive_refresh_begin": (c_int, [c_void_p]),
     "bpr_adaptive_refresh_commit": (c_int, [c_void_p]),
     "bpr_adaptive_refresh_pending": (c_int, [c_void_p, POINTER(c_int32)]),
+    "bpr_adaptive_refresh_part": (c_int, [c_void_p, c_int32, c_int32]),
+    "bpr_adaptive_refresh_publish": (c_int, [c_void_p]),
+    "bpr_adaptive_snapshot_ptrs": (c_int, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_void_p)]),
     "bpr_set_side_stream": (c_int, [c_void_p, c_void_p]),
     "bpr_stream_create": (c_int, [c_int, c_void_p, c_int32, POINTER(c_void_p)]),
     "bpr_stream_destroy": (c_int, [c_void_p]),

@@ -17,12 +17,14 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 @pytest.mark.parametrize("kind,mode", [("uniform", "stream"), ("adaptive", "stream"),
-                                       ("adaptive", "stream-lag")])
+                                       ("adaptive", "stream-lag"), ("adaptive", "stream-shard")])
 def test_two_rank_training_matches_reference_curves(golden_dir, kind, mode):
     """mode stream-lag: the overlapped snapshot schedule (sort beside the previous launch, CU-masked
-    streams) with the item reconciliation between the launches."""
+    streams) with the item reconciliation between the launches; stream-shard: every rank sorts half
+    of the snapshot's factors, an all-gather shares them."""
     env = dict(os.environ, BPR_DIST_BACKEND="gloo")
-    port = {"uniform": "29631", "adaptive": "29632"}[kind] if mode == "stream" else "29634"
+    port = {"uniform": "29631", "adaptive": "29632"}[kind] if mode == "stream" else \
+        {"stream-lag": "29634", "stream-shard": "29636"}[mode]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "tools" / "parity_multi.py"),
            kind, "1,2,3,4,5", mode]

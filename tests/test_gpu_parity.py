@@ -953,6 +953,40 @@ def test_split_refresh_snapshots_the_table_at_begin(I, d, masked):
     assert np.array_equal(e.adaptive_snapshot()[0].cpu().numpy(), oracle.adaptive_order(QT2))
 
 
+@pytest.mark.parametrize("I,d,parts", [(20109, 128, 2), (3001, 32, 4), (45000, 16, 2), (20109, 128, 8)])
+def test_sharded_refresh_parts_equal_the_full_sort(I, d, parts):
+    """bpr_adaptive_refresh_part sorts a slice of the factors into the back snapshot; all slices
+    together, published, are bit for bit the snapshot of the full refresh (multi-GPU: every rank
+    sorts one slice of its replica and an all-gather fills in the others)."""
+    rng = np.random.default_rng(I + d)
+    Q = rng.normal(0, 0.1, (I, d)).astype(np.float32)
+    Q[0] = 0
+    e = make_engine(np.zeros((8, d), np.float32), Q)
+    e.adaptive_refresh()
+    want_o, want_s = (t.clone() for t in e.adaptive_snapshot())
+    e.Q.mul_(-1.5)  # the front snapshot now differs from what a refresh would give
+    per = d // parts
+    back_o, back_s = e._snapshot_views(back=True)
+    gathered_o, gathered_s = torch.empty_like(back_o), torch.empty_like(back_s)
+    from revisit_bpr import native
+
+    for r in range(parts):  # one "rank" after the other on this GPU: each call cuts + sorts a slice
+        native.check(e._lib.bpr_adaptive_refresh_part(e._ctx, r * per, (r + 1) * per))
+        gathered_o[r * per:(r + 1) * per] = back_o[r * per:(r + 1) * per]
+        gathered_s[r * per:(r + 1) * per] = back_s[r * per:(r + 1) * per]
+        if r < parts - 1:  # (a real rank publishes after the gather; here: drop the pending flag)
+            native.check(e._lib.bpr_adaptive_refresh_publish(e._ctx))
+            back_o, back_s = e._snapshot_views(back=True)
+    back_o.copy_(gathered_o)
+    back_s.copy_(gathered_s)
+    native.check(e._lib.bpr_adaptive_refresh_publish(e._ctx))
+    got_o, got_s = e.adaptive_snapshot()
+    QT, sig = oracle.adaptive_stats(e.Q.cpu().numpy())
+    assert np.array_equal(got_o.cpu().numpy(), oracle.adaptive_order(QT))
+    assert close(got_s.cpu().numpy(), sig, 1e-5)
+    assert not torch.equal(got_o, want_o)
+
+
 @pytest.mark.parametrize("lag,fused", [(1.0, False), (1.0, True), (0.4, False)])
 def test_split_refresh_pipeline_sequential_equals_oracle(lag, fused):
     """The StreamTrainer's lagged schedule, one group at a time (max_inflight = 1), against the

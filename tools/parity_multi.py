@@ -25,6 +25,7 @@ def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "uniform"
     seeds = [int(s) for s in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2", "3"])]
     # "stream" (SGD, fused kernel) | "stream-lag" (the same with the overlapped snapshot schedule) |
+    # "stream-shard" (the snapshot sort shared by the ranks + all-gather) |
     # "adam" / "sgd" (STRICT mini-batches) | "batched-adam" (single-launch Adam: BASELINE configs[4])
     mode = sys.argv[3] if len(sys.argv) > 3 else "stream"
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -78,7 +79,11 @@ def main():
                                t["indptr"], t["indices"], lr=cfg["lr"], sampler=kind,
                                adaptive_p=cfg["adaptive_p"], batch_size=cfg["B"], seed=seed, rank=rank,
                                item_sync=sync,
-                               **({"refresh_lag": 1.0, "refresh_cus": 64} if mode == "stream-lag" else {}))
+                               # BPR_CADENCE=rank: a full refresh period per rank and chunk (the
+                               # default divides the period by the number of ranks)
+                               **({"world": 1} if os.environ.get("BPR_CADENCE") == "rank" else {}),
+                               **({"refresh_lag": 1.0, "refresh_cus": 64} if mode == "stream-lag" else {}),
+                               **({"shard_refresh": True} if mode == "stream-shard" else {}))
         curve = []
         for _ in range(cfg["epochs"]):
             tr.train_epoch()
