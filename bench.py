@@ -47,6 +47,9 @@ ATOMIC_LINES_PEAK = 9.5e9
 # default snapshot schedule of the adaptive sampler: the one the parity gates hold
 # (tests/test_gpu_e2e_parity.py, tests/test_gpu_fullscale_parity.py)
 SCHEDULE = {"refresh_lag": 1.0, "refresh_split": 1, "refresh_cus": 64}
+# N > 1 (cadence "job": every rank's launch is 1/N of a refresh period, far shorter than the sort):
+# the snapshot is sorted between launches, every rank sorting d/N of its factors
+SCHEDULE_MULTI = {"refresh_lag": 0.0, "refresh_split": 1, "refresh_cus": 0}
 
 
 def cut_user_pieces(users, L, grouped):
@@ -92,9 +95,9 @@ def parse_args():
                          "tests/test_gpu_multirank_parity.py, DESIGN.md §7); 'rank' = a full period per "
                          "rank and step (measured unsafe: at the full ML-20M shape 4 ranks DIVERGE at lr 0.05, "
                          "profiles/r03_cadence_study.txt)")
-    ap.add_argument("--shard-refresh", action="store_true",
-                    help="N>1, --refresh-lag 0: every rank sorts d/N factors of the snapshot and an all-gather "
-                         "shares them (Engine.adaptive_refresh_sharded)")
+    ap.add_argument("--no-shard-refresh", action="store_true",
+                    help="N>1, --refresh-lag 0: every rank sorts ALL factors of the snapshot instead of d/N of "
+                         "them + an all-gather (Engine.adaptive_refresh_sharded, the default)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink users/actions (debug)")
     ap.add_argument("--max-inflight", type=int, default=0)
     ap.add_argument("--time-every", type=int, default=8,
@@ -307,9 +310,11 @@ def main():
     sampler = {"adaptive": eng.NEG_ADAPTIVE, "uniform": eng.NEG_UNIFORM, "given": eng.NEG_GIVEN}[args.sampler]
 
     # snapshot schedule of the adaptive sampler
-    lag = SCHEDULE["refresh_lag"] if args.refresh_lag is None else args.refresh_lag
-    split = SCHEDULE["refresh_split"] if args.refresh_split is None else args.refresh_split
-    cus = SCHEDULE["refresh_cus"] if args.refresh_cus is None else args.refresh_cus
+    sched = SCHEDULE if world == 1 else SCHEDULE_MULTI
+    lag = sched["refresh_lag"] if args.refresh_lag is None else args.refresh_lag
+    split = sched["refresh_split"] if args.refresh_split is None else args.refresh_split
+    cus = sched["refresh_cus"] if args.refresh_cus is None else args.refresh_cus
+    shard_refresh = world > 1 and lag == 0.0 and not args.no_shard_refresh
     if sampler != eng.NEG_ADAPTIVE or batched:
         lag, split, cus = 0.0, 1, 0
     # epoch order: bpr_plan_epoch = seeded pseudo-random partition of the triple list into chunks of
@@ -366,7 +371,7 @@ def main():
         if sampler != eng.NEG_ADAPTIVE:
             launch(k, lo, lo + chunk, lo)
         elif lag == 0.0:
-            if args.shard_refresh and world > 1 and not batched:
+            if shard_refresh and not batched:
                 e.adaptive_refresh_sharded(rank, world)
             else:
                 e.adaptive_refresh()  # batched: brings the item rows to "now" first
@@ -501,7 +506,8 @@ def main():
                             + ("" if lag == 0.0 else f" (snapshot sorted beside the launch: lag {lag:g}, "
                                f"{split} launch(es) per refresh period, sort masked to {cus} CUs)"),
                 "triples_per_step_per_gpu": chunk,
-                "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus},
+                "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus,
+                                     "sharded_over_ranks": bool(shard_refresh and not batched)},
                 "cadence": (f"{args.cadence}: one snapshot refresh + item reconciliation per "
                             f"{chunk * world if args.cadence == 'job' else chunk} triples of the "
                             f"{'whole job' if args.cadence == 'job' else 'rank'}") if world > 1 else "single GPU",

@@ -496,7 +496,8 @@ int bpr_set_optimizer(bpr_ctx* c, int32_t kind, const bpr_opt_params* params) {
 int bpr_bind_opt_state(bpr_ctx* c, float* m_P, float* v_P, float* m_Q, float* v_Q, float* m_bias,
                        float* v_bias) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_bind_opt_state: ctx is NULL");
-  if (c->vs_active && (c->mP != m_P || c->vP != v_P || c->mQ != m_Q || c->vQ != v_Q)) {
+  if (c->vs_active && (c->mP != m_P || c->vP != v_P || c->mQ != m_Q || c->vQ != v_Q ||
+                       c->mb != m_bias || c->vb != v_bias)) {
     BPR_HIP_CHECK(hipSetDevice(c->device));
     if (int rc = vs_leave(c)) return rc;  // finish with the state tensors bound so far
   }

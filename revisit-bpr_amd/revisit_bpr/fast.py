@@ -135,6 +135,7 @@ class StreamTrainer:
 
     def _train_epoch(self) -> dict:
         e = self.engine
+        self.model._reset_reg()
         e.plan_epoch(self.users, self.items, self.chunk, self.seed + self.epoch,
                      out=(self._pu, self._pi))
         self._scalars.zero_()

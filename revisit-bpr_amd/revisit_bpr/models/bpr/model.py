@@ -258,6 +258,15 @@ class Model(torch.nn.Module):
         self._bind_state(optimizer, kind)
         return kind
 
+    def _reset_reg(self) -> None:
+        """One item per triple again: a forward() with n items per row left alpha_user / n in the
+        engine (it would silently regularise the epoch drivers' user rows with it)."""
+        if self._reg_n != 1:
+            from revisit_bpr.engine import resolve_reg_alphas
+
+            self.engine().set_reg(*resolve_reg_alphas(self._reg_alphas))
+            self._reg_n = 1
+
     def train_strict(self, optimizer, users: torch.Tensor, items: torch.Tensor, batch_size: int,
                      sampler: int, adaptive_p: float = 0.0, seed: int = 0, offset: int = 0,
                      refresh_every: int = 0, scalars: Optional[torch.Tensor] = None) -> int:
@@ -268,6 +277,7 @@ class Model(torch.nn.Module):
         eng = self.engine()
         if self._pending:
             raise RuntimeError("a forward() is waiting for optimizer.step()")
+        self._reset_reg()
         groups = [g for g in optimizer.param_groups
                   if any(id(p) in _FUSED_PARAMS for p in g["params"])]
         if len(groups) != 1:
@@ -291,6 +301,7 @@ class Model(torch.nn.Module):
         any optimizer): triples of neighbouring batches run concurrently, so a gradient may see
         rows that are a few steps stale (bounded by `max_inflight`).  Returns the steps taken."""
         eng = self.engine()
+        self._reset_reg()
         if self._pending:
             raise RuntimeError("a forward() is waiting for optimizer.step()")
         groups = [g for g in optimizer.param_groups
@@ -352,8 +363,10 @@ class Model(torch.nn.Module):
             step = max(int(optimizer.state[prm]["step"]) for prm in self._fused_params())
             if kind == 1 and step == 0 and not created:
                 step = 1  # torch's SGD keeps no step: a present momentum_buffer means "not the first"
-            if step != eng.step_count:
-                eng.set_step(step)
+            # always: set_step also resets the per-row marks (lastP / lastQ, the batched stream's
+            # headers) — a checkpoint with the SAME step count loaded while rows were lazily behind
+            # (an in-process restore-best) must not replay their missed steps on the loaded state
+            eng.set_step(step)
         eng.bind_opt_state(mP, vP, mQ, vQ, mb, vb)
         self._state_sig = sig
 

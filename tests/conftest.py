@@ -36,7 +36,7 @@ def _has_gpu() -> bool:
 # must never sit behind a Monte-Carlo (seed-mean) test when the driver runs `pytest -x`.
 FILE_ORDER = ["test_abi", "test_oracle_golden", "test_native_io_cpu", "test_config_cpu", "test_distributed_cpu",
               "test_gpu_parity", "test_gpu_vstream", "test_gpu_api", "test_gpu_baseline_configs",
-              "test_gpu_fullsize", "test_gpu_config_run", "test_gpu_example",
+              "test_gpu_fullsize", "test_gpu_config_run", "test_gpu_example", "test_gpu_bench",
               # statistical (seed means against the reference's curves) — last
               "test_gpu_sampler_stats", "test_gpu_e2e_parity", "test_gpu_multirank_parity",
               "test_gpu_fullscale_parity"]
