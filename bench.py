@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 ATOMIC_LINES_PEAK = 9.5e9
 # default snapshot schedule of the adaptive sampler: the one the parity gates hold
 # (tests/test_gpu_e2e_parity.py, tests/test_gpu_fullscale_parity.py)
-SCHEDULE = {"refresh_lag": 1.0, "refresh_split": 1, "refresh_cus": 64}
+SCHEDULE = {"refresh_lag": 1.0, "refresh_split": 1, "refresh_cus": -1}  # -1: fast.auto_refresh_cus (64 here)
 # N > 1 (cadence "job": every rank's launch is 1/N of a refresh period, far shorter than the sort):
 # the snapshot is sorted between launches, every rank sorting d/N of its factors
 SCHEDULE_MULTI = {"refresh_lag": 0.0, "refresh_split": 1, "refresh_cus": 0}
@@ -112,7 +112,8 @@ def parse_args():
                     help="launches (= steps) per refresh period, snapshot retaken for each")
     ap.add_argument("--refresh-cus", type=int, default=None,
                     help="CUs (of 256) the side stream's sort is masked to; the STREAM kernel runs "
-                         "on the complementary mask (0: unmasked streams)")
+                         "on the complementary mask (0: unmasked streams; -1: by shape, "
+                         "fast.auto_refresh_cus — 64 for the ML-20M workload)")
     ap.add_argument("--main-cus", type=int, default=0,
                     help="measurement aid: run everything on a stream masked to the LAST N CUs")
     ap.add_argument("--hot-rows", type=int, default=None,
@@ -331,8 +332,11 @@ def main():
     if args.hot_rows is not None:
         e.set_hot_rows(args.hot_rows, args.hot_replicas)
     main_stream = side_stream = None
-    if lag > 0.0 and cus > 0:
+    if lag > 0.0 and cus != 0:
         total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        if cus < 0:
+            from revisit_bpr.fast import auto_refresh_cus
+            cus = auto_refresh_cus(I, d, chunk, total_cus)
         side_stream = eng.MaskedStream(dev, eng.cu_mask(0, cus, total_cus))
         main_stream = eng.MaskedStream(dev, eng.cu_mask(cus, total_cus - cus, total_cus))
         e.set_side_stream(side_stream)

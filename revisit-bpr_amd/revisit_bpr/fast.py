@@ -16,6 +16,24 @@ import torch
 from revisit_bpr import engine as eng
 
 
+def auto_refresh_cus(I: int, d: int, launch_triples: int, total_cus: int = 256) -> int:
+    """CUs for the side stream of the overlapped snapshot schedule: enough that the sort of I x d
+    keys finishes inside one STREAM launch, as few as possible because the launch loses them.
+    Calibrated on MI355X (profiles/shapes_r03.txt): the in-LDS column sort costs ~5.05 ns x CU per
+    key (1.3x when columns are split and merged: I > 36,864), a launch ~0.72 / 0.8 / 1.1 / 1.8 / 3.5 ns
+    per triple at d <= 32 / 64 / 128 / 256 / 512; measured optima: 64 CUs for ML-20M d=128, Yelp and
+    Netflix, 96 for MSD d=256."""
+    per_triple = 0.72e-6 if d <= 32 else 0.8e-6 if d <= 64 else 1.1e-6 if d <= 128 else \
+        1.8e-6 if d <= 256 else 3.5e-6 * d / 512
+    launch_ms = max(launch_triples, 1) * per_triple
+    sort_ms_cu = 5.05e-6 * I * d * (1.3 if I > 36864 else 1.0)
+    want = sort_ms_cu / (0.95 * launch_ms)
+    # multiples of 32 only: the driver deals the mask bits over 8 XCDs x 4 shader engines, and a
+    # count that leaves the engines uneven costs the launch more than the CUs it frees (Yelp: 72 CUs
+    # 570 M triples/s, 64 CUs 632 M)
+    return int(min(max(32 * round(want / 32), 64), total_cus // 2))
+
+
 class StreamTrainer:
     def __init__(self, model, users: torch.Tensor, items: torch.Tensor, seen_indptr: torch.Tensor,
                  seen_indices: torch.Tensor, lr: float, sampler: str = "adaptive",
@@ -38,7 +56,8 @@ class StreamTrainer:
                             0 < f < 1: a launch is cut at 1 - f; the next launch's snapshot is taken
                                there and sorted beside the remainder.
           refresh_cus n     n > 0: the sort runs on a stream masked to n of the chip's CUs and the
-                            STREAM kernel on the complementary mask (0: unmasked side stream).
+                            STREAM kernel on the complementary mask (0: unmasked side stream;
+                            -1: chosen from the shape, `auto_refresh_cus`).
           shard_refresh     several ranks (item_sync): every rank sorts d / world factors and an
                             all-gather shares the orders (Engine.adaptive_refresh_sharded) instead
                             of every rank sorting all of them; refresh_lag 0 only."""
@@ -72,8 +91,10 @@ class StreamTrainer:
         if self.shard_refresh and self.refresh_lag != 0.0:
             raise ValueError("shard_refresh needs refresh_lag = 0")
         self._main = self._side = None
-        if self.refresh_lag > 0.0 and refresh_cus > 0:
+        if self.refresh_lag > 0.0 and refresh_cus != 0:
             total = torch.cuda.get_device_properties(users.device).multi_processor_count
+            if refresh_cus < 0:
+                refresh_cus = auto_refresh_cus(I, self.engine.d, self.chunk, total)
             self._side = eng.MaskedStream(users.device, eng.cu_mask(0, refresh_cus, total))
             self._main = eng.MaskedStream(users.device,
                                           eng.cu_mask(refresh_cus, total - refresh_cus, total))

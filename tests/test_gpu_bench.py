@@ -32,7 +32,7 @@ def test_bench_single_gpu_line():
     assert j["roofline_atomic"]["line_atomics_per_triple"] >= 8.0
     assert j["cpu_baseline"]["cores"] >= 1 and j["cpu_baseline"]["value"] > 0
     sched = j["config"]["refresh_schedule"]
-    assert sched["lag"] == 1.0 and sched["side_stream_cus"] == 64  # the schedule the gates hold
+    assert sched["lag"] == 1.0 and sched["side_stream_cus"] >= 64  # the schedule the gates hold
     assert j["config"]["triples_counted_by_kernel"] == 6 * j["config"]["triples_per_step_per_gpu"]
 
 

@@ -24,10 +24,12 @@ def agg(path):
 
 
 shutil.copy(G / f"prof_{tag}" / "bench_kernel_stats.csv", P / f"{tag}_bench_kernel_stats.csv")
+if (G / f"prof_{tag}_sync" / "bench_kernel_stats.csv").exists():
+    shutil.copy(G / f"prof_{tag}_sync" / "bench_kernel_stats.csv", P / f"{tag}_bench_sync_kernel_stats.csv")
 if (G / f"prof_{tag}_adam" / "bench_kernel_stats.csv").exists():
     shutil.copy(G / f"prof_{tag}_adam" / "bench_kernel_stats.csv", P / f"{tag}_bench_adam_yelp_kernel_stats.csv")
 out = [f"# {tag} — rocprofv3 PMC passes (separate runs): FETCH_SIZE and WRITE_SIZE, unit KB (x1024 B)",
-       "# command: rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --steps 96 --warmup 8 --no-cpu-baseline",
+       "# command: rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --steps 24 --warmup 4 --no-cpu-baseline   (tools/profile_round.sh)",
        "", "## calibration on known byte counts (tools/ubench/pmc_calib.hip, 1 GiB buffers > Infinity Cache)",
        "kernel,counter,calls,per_call_KB,true_KB,ratio"]
 true = {"k_read_dword": 1048576, "k_read_dwordx4": 1048576, "k_gather_rows": 1048576,
