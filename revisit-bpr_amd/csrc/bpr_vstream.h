@@ -32,6 +32,14 @@
 // steps stale and a straggler's gradient is counted one step late — bounded by the number of
 // triples in flight (`max_inflight`), the same kind of asynchrony as the SGD STREAM kernel.
 //
+// r3: views are seqlock reads (vs_view), Adam's closed-form replay also serves short tails
+// (closed_min).  Two restructurings were built, passed the sequential-limit tests and were dropped
+// after measurement: closing AND opening at view time (fast, 277 M triples/s on
+// configs[4], but it lets triples far ahead in the stream claim rows for their step and merges the
+// batches in between into one optimizer step: -0.005 nDCG@100 with Adam), and closing at view time /
+// opening when contributing (parity restored, but no faster than this flow for Adam and 15 % slower
+// for the cheap optimizers).
+//
 // Cross-CU visibility (MI355X_MICROARCH.md "inter-workgroup visibility"): per-CU L1s and per-XCD
 // L2s are not coherent, so every access to shared row state is an agent-scope (sc1) load / store /
 // atomic, and the closer drains its stores (s_waitcnt vmcnt(0)) before the sc1 header store that
@@ -130,7 +138,7 @@ struct VOpt {
   // Adam, gaps >= closed_min steps past t_sat, in closed form (~45 instructions per row slice; the
   // step loop costs ~6 per element and step, so the crossover is 16 steps for torch's default
   // beta1 = 0.9 — a 176-step tail — and 3 steps for the paper's beta1 = 0.1, whose whole tail is 8
-  // steps: with it the loop ran on EVERY row access of configs[4]): the replayed movement is
+  // steps: r2 ran the loop on EVERY row access of BASELINE configs[4]): the replayed movement is
   //   lr (m / sqrt v) sum_s q^s / (1 + e r^-s),  q = b1 / r, r = sqrt b2, e = eps / sqrt v
   //   = lr (m / sqrt v) sum_j (-e)^j G_j(k),     G_j(k) = z_j (1 - z_j^k) / (1 - z_j), z_j = b1 / r^(j+1)
   // three terms; needs e r^-k <= 0.02 (truncation < 1e-5 of the movement), else the step loop
@@ -140,11 +148,11 @@ struct VOpt {
 };
 
 template <int KIND>
-__device__ __forceinline__ void vo_step_consts(const VOpt& o, int32_t t, float& step, float& ibc2) {
+__device__ __forceinline__ void vo_step_consts(const VOpt& o, int64_t t, float& step, float& ibc2) {
   step = o.lr;
   ibc2 = 1.f;  // 1 / sqrt(1 - b2^t)
   if constexpr (KIND == OPT_ADAM) {
-    if (t < o.t_sat) {
+    if (t < (int64_t)o.t_sat) {
       const float tf = (float)t;
       step = o.lr / (-expm1f(tf * o.ln_b1));
       ibc2 = 1.0f / sqrtf(-expm1f(tf * o.ln_b2));
@@ -186,8 +194,8 @@ __device__ __forceinline__ void vo_update(float& w, float g, float& m, float& v,
 // k zero-gradient steps s0+1 .. s0+k of a dense torch optimizer on the E elements a lane holds of
 // one row (STATE = false: only w is wanted — a view)
 template <int KIND, int E, bool STATE>
-__device__ __forceinline__ void vo_replay(float (&w)[E], float (&m)[E], float (&v)[E], int32_t s0,
-                                          int32_t k, const VOpt& o) {
+__device__ __forceinline__ void vo_replay(float (&w)[E], float (&m)[E], float (&v)[E], int64_t s0,
+                                          int64_t k, const VOpt& o) {
   if (k <= 0) return;
   if constexpr (KIND == OPT_MOMENTUM) {
     const float muk = __builtin_amdgcn_exp2f(fmaxf((float)k * o.log2_mu, -126.f));
@@ -216,8 +224,8 @@ __device__ __forceinline__ void vo_replay(float (&w)[E], float (&m)[E], float (&
     bool any = false;
 #pragma unroll
     for (int e = 0; e < E; ++e) any |= m[e] != 0.f;
-    const int kk = k < o.kmax ? k : o.kmax;
-    bool closed = any && o.zc[0] >= 0.f && s0 >= o.t_sat && k >= o.closed_min;
+    const int kk = (int)(k < (int64_t)o.kmax ? k : (int64_t)o.kmax);
+    bool closed = any && o.zc[0] >= 0.f && s0 >= (int64_t)o.t_sat && k >= (int64_t)o.closed_min;
     if (closed) {
 #pragma unroll
       for (int e = 0; e < E; ++e)
@@ -239,7 +247,7 @@ __device__ __forceinline__ void vo_replay(float (&w)[E], float (&m)[E], float (&
       }
     } else if (any && kk > 0) {
       float y1 = 1.f, y2 = 1.f;  // 1 - b1^s, 1 - b2^s of the step being replayed
-      const bool warm = s0 < o.t_sat;
+      const bool warm = s0 < (int64_t)o.t_sat;
       if (warm) {
         const float sf = (float)s0;
         y1 = -expm1f(sf * o.ln_b1);
@@ -285,7 +293,7 @@ __device__ __forceinline__ void vo_replay(float (&w)[E], float (&m)[E], float (&
 // zero-gradient steps it missed since `a`
 template <int KIND, int E>
 __device__ __forceinline__ void vs_apply(float (&w)[E], float (&m)[E], float (&v)[E],
-                                         const float (&g)[E], int32_t a, int32_t gs,
+                                         const float (&g)[E], int64_t a, int64_t gs,
                                          const VOpt& o) {
   vo_replay<KIND, E, true>(w, m, v, a, gs - 1 - a, o);
   float stp, ibc2;
@@ -295,7 +303,7 @@ __device__ __forceinline__ void vs_apply(float (&w)[E], float (&m)[E], float (&v
 }
 // the same for the scalar riding on an item row (item_bias), held by the group's lane 0
 template <int KIND, bool STATE>
-__device__ __forceinline__ void vo_replay1(float& w, float& m, float& v, int32_t s0, int32_t k,
+__device__ __forceinline__ void vo_replay1(float& w, float& m, float& v, int64_t s0, int64_t k,
                                            const VOpt& o) {
   float w1[1] = {w}, m1[1] = {m}, v1[1] = {v};
   vo_replay<KIND, 1, STATE>(w1, m1, v1, s0, k, o);
@@ -304,83 +312,133 @@ __device__ __forceinline__ void vo_replay1(float& w, float& m, float& v, int32_t
   v = v1[0];
 }
 template <int KIND>
-__device__ __forceinline__ void vs_apply1(float& w, float& m, float& v, float g, int32_t a,
-                                          int32_t gs, const VOpt& o) {
+__device__ __forceinline__ void vs_apply1(float& w, float& m, float& v, float g, int64_t a,
+                                          int64_t gs, const VOpt& o) {
   vo_replay1<KIND, true>(w, m, v, a, gs - 1 - a, o);
   float stp, ibc2;
   vo_step_consts<KIND>(o, gs, stp, ibc2);
   vo_update<KIND>(w, g, m, v, o, gs == 1, stp, ibc2);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Row access of the batched stream (r3: one optimizer evaluation per row and step).
-//
-//   vs_advance(row, t, writer)  -> the row as of virtual step t-1, in registers.
-//       writer (the triple will contribute a gradient to this row):
-//         * a pending step older than t is CLOSED right here by whoever wins the row's lock: one
-//           CAS (gstep <- t, slot flips, lock), the old accumulator is consumed with exchanges, ONE
-//           optimizer step with the summed gradient is applied to (w, m, v) and written back, the
-//           header is published (last = the closed step) — and the closer keeps the row it just
-//           computed: the values its gradient is evaluated on ARE the stored ones.  (r2 applied the
-//           pending step on the fly in a read-only view and evaluated the same optimizer step a
-//           second time when the triple contributed: 60 % of the kernel's VALU work twice.)
-//         * no step >= t open yet and nothing to close: step t is opened with one CAS, no lock.
-//         So a writer leaves with header.gstep >= t, and vs_add is a plain atomic add.
-//       reader (pad rows, idle lanes) or a writer that finds step >= t already open: read-only.
-//       Read-only accesses are SEQLOCK reads: header, rows, header again; a header that moved (a
-//       closer took the lock, stored the row, published) means the row words may be torn or a step
-//       ahead of the header they were read under — read again (bounded: after VS_READ_TRIES the
-//       possibly-stale view is accepted, the asynchrony the full-chip path has anyway).  A pending
-//       step the reader may not close is applied on the fly, in registers only.
-//   vs_add(row, t, g)  atomic add of the gradient into the accumulator that is current NOW (a
-//       straggler whose step was closed meanwhile joins the open one, as before).
-// ---------------------------------------------------------------------------------------------
+// The row as of virtual step t-1 (nothing is written).  wb: the riding scalar's view (0 if none).
+// SEQLOCK read (r3): header, row words, header again.  A closer takes the row's lock (one
+// CAS on the header), stores the row and publishes a new header; a view that read the header
+// before that and the row words after it would apply the pending step a second time on top of a row
+// that already has it (and may read a half-written row).  So the header is read again AFTER the
+// row loads have completed; if it moved — or the row is locked — the view is taken again, at most
+// VS_READ_TRIES times (then the possibly stale view is accepted: the asynchrony the full-chip path
+// has anyway; the sequential limit never retries).
 constexpr int VS_READ_TRIES = 6;
-
-__device__ __forceinline__ int32_t vh_last(uint64_t raw) { return (int32_t)(raw >> 33); }
-__device__ __forceinline__ int32_t vh_gstep(uint64_t raw) { return (int32_t)((raw >> 2) & 0x7fffffffull); }
-__device__ __forceinline__ int vh_slot(uint64_t raw) { return (int)((raw >> 1) & 1ull); }
-__device__ __forceinline__ bool vh_locked(uint64_t raw) { return (raw & 1ull) != 0ull; }
-
 template <int G, int E, int KIND>
-__device__ __forceinline__ void vs_advance(float (&w)[E], float& wb, const VTable& T, uint32_t row,
-                                           int d, int gl, int lane, int32_t t, const VOpt& o,
-                                           bool writer) {
+__device__ __forceinline__ uint64_t vs_view(float (&w)[E], float& wb, const VTable& T, uint32_t row,
+                                            int d, int gl, int64_t t, const VOpt& o) {
   constexpr bool STATEFUL = KIND != OPT_SGD;
   const size_t off = (size_t)row * (size_t)d;
-  const bool has_b = T.b != nullptr;
-  bool done = false;
+  float m[E], v[E], g[E];
+  float bm = 0.f, bv = 0.f, gb = 0.f;
+  VHdr h{0};
+  bool pend = false;
+  bool ok = false;
   int tries = 0;
-  wb = 0.f;
+  while (!__all(ok)) {
+    if (!ok) {
+      h.raw = ld_hdr(T.H + row);
+      if (h.locked() && tries < VS_READ_TRIES) {
+        ++tries;
+        __builtin_amdgcn_s_sleep(2);  // a closer is storing this row
+      } else {
+        load_row_sc1<G, E>(w, T.W + off, d, gl);
+#pragma unroll
+        for (int e = 0; e < E; ++e) m[e] = v[e] = g[e] = 0.f;
+        if constexpr (STATEFUL) {
+          if (T.M != nullptr) load_row_sc1<G, E>(m, T.M + off, d, gl);
+          if (T.V != nullptr) load_row_sc1<G, E>(v, T.V + off, d, gl);
+        }
+        bm = bv = gb = 0.f;
+        wb = 0.f;
+        if (T.b != nullptr) {
+          wb = ld_sc1(T.b + row);
+          if constexpr (STATEFUL) {
+            if (T.mb != nullptr) bm = ld_sc1(T.mb + row);
+            if (T.vb != nullptr) bv = ld_sc1(T.vb + row);
+          }
+        }
+        pend = h.gstep() > h.last() && h.gstep() < t;  // a closed step nobody has applied yet
+        if (pend) {
+          const size_t goff = ((size_t)h.slot() * (size_t)T.rows + row) * (size_t)d;
+          load_row_sc1<G, E>(g, T.Gacc + goff, d, gl);
+          if (T.b != nullptr) gb = ld_sc1(T.Gb + (size_t)h.slot() * (size_t)T.rows + row);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-read must not overtake the row reads
+        const uint64_t h2 = ld_hdr(T.H + row);
+        if (h2 == h.raw || tries >= VS_READ_TRIES) ok = true;
+        else ++tries;
+      }
+    }
+  }
+  int64_t a = h.last();
+  const int64_t gs = h.gstep();
+  if (pend) {  // apply it in this view
+    vs_apply<KIND, E>(w, m, v, g, a, gs, o);
+    if (T.b != nullptr) vs_apply1<KIND>(wb, bm, bv, gb, a, gs, o);
+    a = gs;
+  }
+  if constexpr (STATEFUL) {
+    const int64_t k = (t - 1) - a;
+    vo_replay<KIND, E, false>(w, m, v, a, k, o);
+    if (T.b != nullptr) vo_replay1<KIND, false>(wb, bm, bv, a, k, o);
+  }
+  return h.raw;  // the header this view was taken under (vs_contribute's first guess)
+}
+
+// Add this triple's gradient g (and gb for the riding scalar) to row's virtual step t.
+// `hint`: the header the row's view was taken under.  When it says "t closes the pending step" the
+// CAS is tried on it directly (the CAS itself validates it: one round trip saved on the common
+// path — a user row, a cold item row); a "join" is always decided on a fresh header, so that the
+// add lands in the accumulator that is current NOW.
+template <int G, int E, int KIND>
+__device__ __forceinline__ void vs_contribute(const VTable& T, uint32_t row, int d, int gl,
+                                              int lane, int64_t t, const float (&g)[E], float gb,
+                                              bool act, const VOpt& o, uint64_t hint) {
+  constexpr bool STATEFUL = KIND != OPT_SGD;
+  const size_t off = (size_t)row * (size_t)d;
+  bool done = !act;
+  bool guess = true;
   while (!__all(done)) {
     if (!done) {
-      const uint64_t h = ld_hdr(T.H + row);
-      if (vh_locked(h) && (writer || tries < VS_READ_TRIES)) {
-        ++tries;
-        __builtin_amdgcn_s_sleep(2);  // a closer is storing this row: look again
-      } else {
-        int32_t a = vh_last(h);
-        int32_t gs = vh_gstep(h);
-        const int slot = vh_slot(h);
-        uint64_t expect = h;  // the header a consistent read-only pass must see again
-        bool closed_here = false, proceed = true;
-        if (writer && gs < t) {
-          const bool close = gs > a;
-          const uint64_t next = vhdr_pack(a, t, slot ^ 1, close ? 1 : 0);
-          int won = 0;
-          if (gl == 0) {
-            uint64_t e0 = h;
-            won = __hip_atomic_compare_exchange_strong(T.H + row, &e0, next, __ATOMIC_RELAXED,
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                      ? 1 : 0;
-          }
-          won = group_bcast<G>(won, 0, lane);
-          if (!won) {
-            proceed = false;  // the header moved under me: look again
-          } else if (close) {
-            // ---- close step gs: ONE optimizer step with the summed gradient, under the lock
-            float* old = T.Gacc + ((size_t)slot * (size_t)T.rows + row) * (size_t)d;
-            float go[E], m[E], v[E];
+      VHdr h{hint};
+      if (!guess || t <= h.gstep() || h.locked()) h.raw = ld_hdr(T.H + row);
+      guess = false;
+      const int64_t gs = h.gstep();
+      if (t <= gs) {
+        // the row's pending step is mine, or already a later one (I am a straggler: join it)
+        float* acc = T.Gacc + ((size_t)h.slot() * (size_t)T.rows + row) * (size_t)d;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int f = e * G + gl;
+          if (f < d) atomic_add_f32(acc + f, g[e]);
+        }
+        if (T.b != nullptr && gl == 0)
+          atomic_add_f32(T.Gb + (size_t)h.slot() * (size_t)T.rows + row, gb);
+        done = true;
+      } else if (!h.locked()) {
+        const int ns = h.slot() ^ 1;
+        int won = 0;
+        if (gl == 0) {
+          uint64_t expect = h.raw;
+          won = __hip_atomic_compare_exchange_strong(T.H + row, &expect,
+                                                     vhdr_pack(h.last(), t, ns, 1),
+                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)
+                    ? 1 : 0;
+        }
+        won = group_bcast<G>(won, 0, lane);
+        if (won) {
+          const int64_t a = h.last();
+          int64_t new_last = a;
+          if (gs > a) {  // close step gs: ONE optimizer step with the summed gradient
+            float* old = T.Gacc + ((size_t)h.slot() * (size_t)T.rows + row) * (size_t)d;
+            float go[E], w[E], m[E], v[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
               const int f = e * G + gl;
@@ -398,102 +456,39 @@ __device__ __forceinline__ void vs_advance(float (&w)[E], float& wb, const VTabl
               if (T.M != nullptr) store_row_sc1<G, E>(T.M + off, m, d, gl);
               if (T.V != nullptr) store_row_sc1<G, E>(T.V + off, v, d, gl);
             }
-            float bm = 0.f, bv = 0.f;
-            if (has_b) {  // every lane computes the scalar (the view needs it), lane 0 stores it
-              wb = ld_sc1(T.b + row);
+            if (T.b != nullptr && gl == 0) {
+              float wb = ld_sc1(T.b + row), bm = 0.f, bv = 0.f;
               if constexpr (STATEFUL) {
                 if (T.mb != nullptr) bm = ld_sc1(T.mb + row);
                 if (T.vb != nullptr) bv = ld_sc1(T.vb + row);
               }
-              float gbo = 0.f;
-              if (gl == 0) gbo = xchg_zero(T.Gb + (size_t)slot * (size_t)T.rows + row);
-              gbo = group_bcast<G>(gbo, 0, lane);
+              const float gbo = xchg_zero(T.Gb + (size_t)h.slot() * (size_t)T.rows + row);
               vs_apply1<KIND>(wb, bm, bv, gbo, a, gs, o);
-              if (gl == 0) {
-                st_sc1(T.b + row, wb);
-                if constexpr (STATEFUL) {
-                  if (T.mb != nullptr) st_sc1(T.mb + row, bm);
-                  if (T.vb != nullptr) st_sc1(T.vb + row, bv);
-                }
+              st_sc1(T.b + row, wb);
+              if constexpr (STATEFUL) {
+                if (T.mb != nullptr) st_sc1(T.mb + row, bm);
+                if (T.vb != nullptr) st_sc1(T.vb + row, bv);
               }
             }
-            // publish: every store above has left this CU before the header says so
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (gl == 0) st_hdr(T.H + row, vhdr_pack(gs, t, slot ^ 1, 0));
-            // the row I hold is exact as of gs: the view is its replay to t-1
-            if constexpr (STATEFUL) {
-              vo_replay<KIND, E, false>(w, m, v, gs, (t - 1) - gs, o);
-              if (has_b) vo_replay1<KIND, false>(wb, bm, bv, gs, (t - 1) - gs, o);
-            }
-            closed_here = true;
-            done = true;
-          } else {
-            expect = next;  // step t is open now (nothing was pending); read the row as a reader
-            gs = t;
+            new_last = gs;
           }
-        }
-        if (proceed && !closed_here) {
-          // ---- read-only pass (seqlock): rows, then the header again
-          float m[E], v[E];
+          // open step t with my own gradient
+          float* acc = T.Gacc + ((size_t)ns * (size_t)T.rows + row) * (size_t)d;
 #pragma unroll
-          for (int e = 0; e < E; ++e) m[e] = v[e] = 0.f;
-          load_row_sc1<G, E>(w, T.W + off, d, gl);
-          if constexpr (STATEFUL) {
-            if (T.M != nullptr) load_row_sc1<G, E>(m, T.M + off, d, gl);
-            if (T.V != nullptr) load_row_sc1<G, E>(v, T.V + off, d, gl);
+          for (int e = 0; e < E; ++e) {
+            const int f = e * G + gl;
+            if (f < d) atomic_add_f32(acc + f, g[e]);
           }
-          float bm = 0.f, bv = 0.f;
-          if (has_b) {
-            wb = ld_sc1(T.b + row);
-            if constexpr (STATEFUL) {
-              if (T.mb != nullptr) bm = ld_sc1(T.mb + row);
-              if (T.vb != nullptr) bv = ld_sc1(T.vb + row);
-            }
-          }
-          const bool pend = gs > a && gs < t;  // a closed step nobody applied and I may not close
-          float g[E];
-          float gb = 0.f;
-#pragma unroll
-          for (int e = 0; e < E; ++e) g[e] = 0.f;
-          if (pend) {
-            const size_t goff = ((size_t)slot * (size_t)T.rows + row) * (size_t)d;
-            load_row_sc1<G, E>(g, T.Gacc + goff, d, gl);
-            if (has_b) gb = ld_sc1(T.Gb + (size_t)slot * (size_t)T.rows + row);
-          }
-          const uint64_t h2 = ld_hdr(T.H + row);
-          if (h2 != expect && tries < VS_READ_TRIES) {
-            ++tries;  // the row moved while I read it
-          } else {
-            if (pend) {
-              vs_apply<KIND, E>(w, m, v, g, a, gs, o);
-              if (has_b) vs_apply1<KIND>(wb, bm, bv, gb, a, gs, o);
-              a = gs;
-            }
-            if constexpr (STATEFUL) {
-              vo_replay<KIND, E, false>(w, m, v, a, (t - 1) - a, o);
-              if (has_b) vo_replay1<KIND, false>(wb, bm, bv, a, (t - 1) - a, o);
-            }
-            done = true;
-          }
+          if (T.b != nullptr && gl == 0) atomic_add_f32(T.Gb + (size_t)ns * (size_t)T.rows + row, gb);
+          // publish: every store above has left this CU before the header says so
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (gl == 0) st_hdr(T.H + row, vhdr_pack(new_last, t, ns, 0));
+          done = true;
         }
       }
+      // else: another group is closing this row — look again
     }
   }
-}
-
-// add this triple's gradient g (gb for the riding scalar) to the row's open step
-template <int G, int E>
-__device__ __forceinline__ void vs_add(const VTable& T, uint32_t row, int d, int gl,
-                                       const float (&g)[E], float gb, bool act) {
-  if (!act) return;
-  const int slot = vh_slot(ld_hdr(T.H + row));  // the accumulator that is current NOW
-  float* acc = T.Gacc + ((size_t)slot * (size_t)T.rows + row) * (size_t)d;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int f = e * G + gl;
-    if (f < d) atomic_add_f32(acc + f, g[e]);
-  }
-  if (T.b != nullptr && gl == 0) atomic_add_f32(T.Gb + (size_t)slot * (size_t)T.rows + row, gb);
 }
 
 // ---- LDS "seen" structures built per triple (the stream is NOT grouped by user here) -----------
@@ -547,11 +542,10 @@ struct VStreamArgs {
 };
 
 // rows of the triple as of step t-1 are staged in LDS ([3][G*E] floats per group: p_u, q_i, q_j),
-// so that the row access exists ONCE in the instruction stream (a loop over the three rows)
-// instead of three times with all three rows live in registers around it: the optimizer replay
-// inlined six times cost 256 VGPRs (one wave per SIMD).  The optimizer constants and the two table
-// descriptors live in LDS as well (r2 kept them in SGPRs: 25 + 20 of them, spilled to VGPR lanes
-// and selected per row with chains of s_cselect — 20 % of the kernel's instructions).
+// so that view() and contribute() each exist ONCE in the instruction stream (a loop over the
+// three rows) instead of three times with all three rows live in registers around them: the
+// optimizer replay inlined six times cost 256 VGPRs (one wave per SIMD); the kernel is bound by
+// the latency of its dependent memory round trips, i.e. by how many triples are in flight.
 template <int G, int E, int SAMPLER, int SEEN, int KIND>
 __global__ __launch_bounds__(256, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void k_vstream(const VStreamArgs a) {
   constexpr int DP = G * E;
@@ -566,16 +560,21 @@ __global__ __launch_bounds__(256, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void k_vstrea
   float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
   uint32_t* lds = bpr_vsmem + (threadIdx.x / G) * (a.bm_words + 3 * DP);
   float* rows = reinterpret_cast<float*>(lds + a.bm_words);  // [3][DP]
-  __shared__ VOpt s_o;
-  __shared__ VTable s_tab[2];  // [0] the user table, [1] the item table
-  if (threadIdx.x == 0) {
-    s_o = a.o;
-    s_tab[0] = a.P;
-    s_tab[1] = a.Q;
-  }
-  __syncthreads();
-  const VOpt& o = s_o;
-  const int32_t t_base = (int32_t)a.t_base;
+
+  auto table = [&](int r) {  // uniform selects: the user table for r == 0, else the item table
+    VTable T;
+    T.W = r == 0 ? a.P.W : a.Q.W;
+    T.M = r == 0 ? a.P.M : a.Q.M;
+    T.V = r == 0 ? a.P.V : a.Q.V;
+    T.Gacc = r == 0 ? a.P.Gacc : a.Q.Gacc;
+    T.H = r == 0 ? a.P.H : a.Q.H;
+    T.rows = r == 0 ? a.P.rows : a.Q.rows;
+    T.b = r == 0 ? nullptr : a.Q.b;
+    T.mb = r == 0 ? nullptr : a.Q.mb;
+    T.vb = r == 0 ? nullptr : a.Q.vb;
+    T.Gb = r == 0 ? nullptr : a.Q.Gb;
+    return T;
+  };
 
   for (int base = wave * gpw; base < a.n; base += n_waves * gpw) {
     const int k = base + gw;
@@ -583,10 +582,10 @@ __global__ __launch_bounds__(256, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void k_vstrea
     const int kk = act ? k : a.n - 1;
     const uint32_t u = (uint32_t)a.users[kk];
     const uint32_t i = (uint32_t)a.pos[kk];
-    const int32_t t = t_base + (int32_t)(kk / a.B);
-    const bool has_bias = a.Q.b != nullptr;
+    const int64_t t = a.t_base + (int64_t)(kk / a.B);
     int32_t j = 0;
     float bi = 0.f, bj = 0.f;
+    uint64_t hu = 0, hi_ = 0, hj = 0;  // headers the three views were taken under
 #pragma unroll 1
     for (int r = 0; r < 3; ++r) {
       if (r == 2) {  // the negative: drawn from the user's row as of t-1, like the reference
@@ -624,12 +623,11 @@ __global__ __launch_bounds__(256, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void k_vstrea
         }
       }
       const uint32_t row = r == 0 ? u : (r == 1 ? i : (uint32_t)j);
-      // padding_idx drops the gradient of the pad EMBEDDING row (torch's embedding backward); the
-      // pad item's bias is an ordinary parameter and keeps its gradient
-      const bool pad = (int32_t)row == (r == 0 ? a.pad_user : a.pad_item);
-      const bool writer = act && (!pad || (r != 0 && has_bias));
       float w[E], wb;
-      vs_advance<G, E, KIND>(w, wb, s_tab[r != 0], row, d, gl, lane, t, o, writer);
+      const uint64_t hr = vs_view<G, E, KIND>(w, wb, table(r), row, d, gl, t, a.o);
+      hu = r == 0 ? hr : hu;
+      hi_ = r == 1 ? hr : hi_;
+      hj = r == 2 ? hr : hj;
 #pragma unroll
       for (int e = 0; e < E; ++e) rows[r * DP + e * G + gl] = w[e];
       bi = r == 1 ? wb : bi;
@@ -652,8 +650,11 @@ __global__ __launch_bounds__(256, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void k_vstrea
         s_cnt += 1.f;
       }
     }
-    // per-triple gradients, w = sigma(-x): row r gets c_p p + c_i q_i + c_j q_j
+    // per-triple gradients, w = sigma(-x): row r gets c_p p + c_i q_i + c_j q_j.
+    // padding_idx drops the gradient of the pad EMBEDDING row (torch's embedding backward); the
+    // pad item's bias is an ordinary parameter and keeps its gradient.
     const float w = 1.0f / (1.0f + expf(x));
+    const bool has_bias = a.Q.b != nullptr;
 #pragma unroll 1
     for (int r = 0; r < 3; ++r) {
       const uint32_t row = r == 0 ? u : (r == 1 ? i : (uint32_t)j);
@@ -666,7 +667,9 @@ __global__ __launch_bounds__(256, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void k_vstrea
       for (int e = 0; e < E; ++e)
         g[e] = cp * rows[e * G + gl] + ci * rows[DP + e * G + gl] + cj * rows[2 * DP + e * G + gl];
       const float gb = r == 0 ? 0.f : (r == 1 ? -w : w);
-      vs_add<G, E>(s_tab[r != 0], row, d, gl, g, gb, act && (!pad || (r != 0 && has_bias)));
+      vs_contribute<G, E, KIND>(table(r), row, d, gl, lane, t, g, gb,
+                                act && (!pad || (r != 0 && has_bias)), a.o,
+                                r == 0 ? hu : (r == 1 ? hi_ : hj));
     }
   }
   if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);
@@ -728,20 +731,20 @@ __global__ __launch_bounds__(256) void k_vflush(const VFlushArgs a) {
           g1[f] = 0.f;
         }
       }
-      vs_apply<KIND, E>(w, m, v, g, (int32_t)a0, (int32_t)gs, a.o);  // (the pad row's g is all zero)
+      vs_apply<KIND, E>(w, m, v, g, a0, gs, a.o);  // (the pad row's g is all zero)
       if (T.b != nullptr) {
         const float gb = T.Gb[row] + T.Gb[T.rows + row];
         if (gl == 0) {
           T.Gb[row] = 0.f;
           T.Gb[T.rows + row] = 0.f;
         }
-        vs_apply1<KIND>(wb, bm, bv, gb, (int32_t)a0, (int32_t)gs, a.o);
+        vs_apply1<KIND>(wb, bm, bv, gb, a0, gs, a.o);
       }
       cur = gs;
     }
     if constexpr (STATEFUL) {
-      vo_replay<KIND, E, true>(w, m, v, (int32_t)cur, (int32_t)(a.now - cur), a.o);
-      if (T.b != nullptr) vo_replay1<KIND, true>(wb, bm, bv, (int32_t)cur, (int32_t)(a.now - cur), a.o);
+      vo_replay<KIND, E, true>(w, m, v, cur, a.now - cur, a.o);
+      if (T.b != nullptr) vo_replay1<KIND, true>(wb, bm, bv, cur, a.now - cur, a.o);
     }
     store_row<G, E>(T.W + off, w, d, gl);
     if constexpr (STATEFUL) {
