@@ -165,6 +165,26 @@ int bpr_adaptive_refresh_pending(bpr_ctx* ctx, int32_t* pending_host);
 int bpr_adaptive_refresh_part(bpr_ctx* ctx, int32_t f_lo, int32_t f_hi);
 int bpr_adaptive_refresh_publish(bpr_ctx* ctx);
 int bpr_adaptive_snapshot_ptrs(bpr_ctx* ctx, int32_t back, void** order_host, void** sigma_host);
+/* ---- multi-GPU inside the library (the reference's DDP launcher, experiments/launcher.py:
+ * 35-73, is never enabled by a config, so there is no reference behaviour to mirror) ------------------
+ * One RCCL communicator per ctx (librccl.so is opened at run time: no link-time dependency).
+ * bpr_comm_unique_id: rank 0 fills BPR_COMM_ID_BYTES bytes of HOST memory (ncclGetUniqueId) and ships
+ * them to the other ranks out of band; bpr_comm_init: every rank, collectively (ncclCommInitRank);
+ * it also cuts the reconciliation BASE from the item table as it is now (identical on every rank).
+ * bpr_item_sync: the steady-state step of the item-table reconciliation — fold the all-reduced
+ * deltas of the reconciliation in flight into the live replica (one period late), cut this rank's
+ * new delta, all-reduce it on the communicator's own stream under whatever the ctx stream does next
+ * (Q <- Q_base + sum_r (Q_r - Q_base); the base is updated from the all-reduced sum only, so it
+ * stays bit-identical on every rank).  bpr_item_sync_finish folds the last one in.  With a
+ * communicator of world > 1, bpr_adaptive_refresh sorts d / world factors per rank and all-gathers
+ * the orders (bpr_adaptive_refresh_part / _publish) when world divides d.
+ * revisit_bpr/distributed.py runs the same protocol through torch.distributed (RCCL or gloo). */
+#define BPR_COMM_ID_BYTES 128
+int bpr_comm_unique_id(void* id_host);
+int bpr_comm_init(bpr_ctx* ctx, const void* id_host, int32_t rank, int32_t world);
+int bpr_comm_destroy(bpr_ctx* ctx);
+int bpr_item_sync(bpr_ctx* ctx);
+int bpr_item_sync_finish(bpr_ctx* ctx);
 /* The side stream of the split refresh (a hipStream_t of the ctx's device; NULL = a plain
  * non-blocking stream created by the library on first use).  The caller keeps ownership. */
 int bpr_set_side_stream(bpr_ctx* ctx, void* hip_stream);

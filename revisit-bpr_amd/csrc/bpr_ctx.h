@@ -103,6 +103,7 @@ struct bpr_ctx {
   int heavy_T = 0;                 // users with more seen items than this are heavy
   int64_t heavy_n = 0;
   const int64_t* heavy_for = nullptr;  // the indptr the table was built from (NULL = not built)
+  void* comm = nullptr;  // bpr_comm.hip: the RCCL communicator and the reconciliation buffers (NULL: one GPU)
   // scalar slots
   float* dev_scalars = nullptr;
   // timing of the dominant kernel

@@ -404,6 +404,7 @@ int bpr_ctx_destroy(bpr_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   free_strict_scratch(c);
+  comm_free(c);
   refresh_free(c);
   side_free(c);
   vs_free(c);
@@ -581,6 +582,17 @@ int bpr_adaptive_refresh(bpr_ctx* c) {
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->vs_active)  // batched STREAM: the snapshot must see the item rows as of "now"
     if (int rc = vs_flush(c, false, true)) return rc;
+  const int world = comm_world(c);
+  if (world > 1 && c->d % world == 0 && !c->refresh_pending) {
+    // several ranks behind one communicator: every rank sorts its share of the factors of its own
+    // replica, an all-gather hands everybody every factor's order, the same snapshot is published
+    const int per = c->d / world, r = comm_rank(c);
+    if (int rc = refresh_impl(c, false, r * per, (r + 1) * per)) return rc;
+    const int back = c->have_snapshot ? (c->snap_front ^ 1) : c->snap_front;
+    if (int rc = comm_gather_snapshot(c, c->order_alloc[back] + BPR_ORDER_PAD, c->sigma_buf[back], per))
+      return rc;
+    return refresh_publish_impl(c);
+  }
   return refresh_impl(c, false, 0, c->d);
 }
 

@@ -275,6 +275,33 @@ class Engine:
         dist.all_gather_into_tensor(sigma, mine_s, group=group)
         native.check(self._lib.bpr_adaptive_refresh_publish(self._ctx))
 
+    # ---- multi-GPU inside the library (RCCL behind the C ABI; distributed.ItemSync is the torch twin)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId through the library: rank 0 calls it and ships the 128 bytes to the others."""
+        buf = ctypes.create_string_buffer(128)
+        native.check(native.load().bpr_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        """Collective: the ctx gets an RCCL communicator; the reconciliation base is cut from the item
+        table as it is now (identical on every rank)."""
+        self._sync_stream()
+        native.check(self._lib.bpr_comm_init(self._ctx, ctypes.c_char_p(unique_id), rank, world))
+
+    def item_sync(self) -> None:
+        """Steady-state reconciliation step (fold the all-reduce in flight, cut the next delta,
+        all-reduce it on the communicator's stream): `bpr_item_sync`."""
+        self._sync_stream()
+        native.check(self._lib.bpr_item_sync(self._ctx))
+
+    def item_sync_finish(self) -> None:
+        self._sync_stream()
+        native.check(self._lib.bpr_item_sync_finish(self._ctx))
+
+    def comm_destroy(self) -> None:
+        native.check(self._lib.bpr_comm_destroy(self._ctx))
+
     def refresh_pending(self) -> bool:
         out = ctypes.c_int32(0)
         native.check(self._lib.bpr_adaptive_refresh_pending(self._ctx, ctypes.byref(out)))

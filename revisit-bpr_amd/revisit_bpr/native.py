@@ -66,6 +66,11 @@ SIGNATURES = {
     "bpr_adaptive_refresh_part": (c_int, [c_void_p, c_int32, c_int32]),
     "bpr_adaptive_refresh_publish": (c_int, [c_void_p]),
     "bpr_adaptive_snapshot_ptrs": (c_int, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_void_p)]),
+    "bpr_comm_unique_id": (c_int, [c_void_p]),
+    "bpr_comm_init": (c_int, [c_void_p, c_void_p, c_int32, c_int32]),
+    "bpr_comm_destroy": (c_int, [c_void_p]),
+    "bpr_item_sync": (c_int, [c_void_p]),
+    "bpr_item_sync_finish": (c_int, [c_void_p]),
     "bpr_set_side_stream": (c_int, [c_void_p, c_void_p]),
     "bpr_stream_create": (c_int, [c_int, c_void_p, c_int32, POINTER(c_void_p)]),
     "bpr_stream_destroy": (c_int, [c_void_p]),

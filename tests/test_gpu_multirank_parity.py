@@ -130,3 +130,46 @@ def test_item_sync_fused_step_equals_finish_then_start():
     torch.cuda.synchronize()
     assert torch.equal(Qa, Qb) and torch.equal(sa.base[0], sb.base[0])
     assert not torch.equal(Qa, Q0)
+
+
+def test_c_abi_comm_single_rank():
+    """bpr_comm_init / bpr_item_sync (RCCL inside the library) with a communicator of one
+    rank — all a 1-GPU box can run: librccl is found, the communicator is created, the delta /
+    all-reduce / fold cycle leaves a lone replica exactly where training put it, the base follows
+    it, and bpr_adaptive_refresh still sorts everything itself.  Against the torch twin
+    (distributed.ItemSync) on the same updates: bit-identical tables."""
+    import torch
+
+    import oracle
+    from revisit_bpr.distributed import ItemSync
+    from revisit_bpr.engine import Engine
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    I, d = 3001, 64
+    Q0 = torch.randn(I, d, device="cuda", generator=g) * 0.1
+    Q0[0] = 0
+    Qa, Qb = Q0.clone(), Q0.clone()
+    bias = torch.zeros(I, device="cuda")
+    e = Engine(torch.zeros(8, d, device="cuda"), Qa, bias)
+    e.comm_init(Engine.comm_unique_id(), 0, 1)
+    twin = ItemSync([Qb])
+    for k in range(3):
+        upd = torch.randn(I, d, device="cuda", generator=g) * 0.01
+        Qa += upd
+        Qb += upd
+        bias += 0.01
+        e.item_sync()
+        twin.step()
+    e.item_sync_finish()
+    twin.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(Qa, Qb) and not torch.equal(Qa, Q0)
+    assert torch.allclose(bias, torch.full_like(bias, 0.03))
+    e.adaptive_refresh()
+    QT, _ = oracle.adaptive_stats(Qa.cpu().numpy())
+    import numpy as np
+    assert np.array_equal(e.adaptive_snapshot()[0].cpu().numpy(), oracle.adaptive_order(QT))
+    e.comm_destroy()
+    e.item_sync_finish if False else None
+    with pytest.raises(Exception):
+        e.item_sync()  # no communicator any more
