@@ -1,5 +1,5 @@
 #!/bin/bash
-# k_stream levers on one MI355X: heavy-user bitmaps, hot-block size / assignment, look-ahead, CU count.
+# k_stream levers on one MI355X: heavy-user bitmaps, hot-block size / assignment, CU count.
 cd "$(dirname "$0")/.."
 run() { python bench.py --no-cpu-baseline --steps 94 --warmup 10 "$@" 2>&1 | python -c "
 import sys, json, os
