@@ -298,8 +298,11 @@ int bpr_shuffle_epoch(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_
  * wavefront group for the whole launch and its row is written back with a plain store; with 0
  * (default) every user-row update is an atomic add.  run_len = consecutive triples one
  * group walks with the user row held in registers: 1..30, or 0 (default) = chosen per launch —
- * 8 once that makes >= 12 k groups, 4 for smaller launches (they would leave the chip idle). */
+ * 8 when runs of 8 fill the launch stream's CUs more than once; for smaller launches the shortest
+ * runs of 4..8 triples that fit those CUs in one residency, one run per group (a small launch
+ * ends when its slowest group does).  bpr_stream_run_len: what the last STREAM launch used. */
 int bpr_set_stream_opts(bpr_ctx* ctx, int32_t grouped_by_user, int32_t run_len);
+int bpr_stream_run_len(bpr_ctx* ctx);
 
 /* Hot item rows.  On popularity-skewed data the STREAM kernel is limited by fp32 atomics queueing
  * on the memory channels that happen to hold the most popular item rows (rows are scattered over

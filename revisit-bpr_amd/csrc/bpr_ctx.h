@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/bprcore.h"
@@ -21,6 +23,10 @@ struct bpr_ctx {
   int d = 0, G = 0, E = 0;
   bool grouped = false;  // STREAM: chunks are grouped by user (bpr_plan_epoch output)
   int run_len = 0;       // STREAM: consecutive triples walked by one group (0: by launch size)
+  int last_run_len = 0;  // what the last STREAM launch used
+  int stream_cus = 0;    // CUs of `stream` (its CU mask's popcount), cached per stream handle
+  void* stream_cus_of = nullptr;
+  std::map<std::tuple<int, int, int, int, int64_t>, int> stream_occ;  // k_stream blocks per CU, per instantiation
   int pad_user = -1, pad_item = -1;
   const int64_t* indptr = nullptr;
   const int32_t* indices = nullptr;

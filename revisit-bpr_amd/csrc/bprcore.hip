@@ -215,6 +215,28 @@ static int launch_triples(bpr_ctx* c, TripleArgs a, bool timed) {
   });
 }
 
+// CUs the ctx's launch stream may use: the popcount of its CU mask (bpr_stream_create), the whole
+// chip for an unmasked stream.  Queried once per stream handle.
+static int stream_cus(bpr_ctx* c) {
+  if (c->stream_cus_of == (void*)c->stream && c->stream_cus > 0) return c->stream_cus;
+  int n_cu = 0;
+  hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+  int cus = n_cu;
+  if (c->stream != nullptr) {
+    uint32_t mask[16] = {0};
+    if (hipExtStreamGetCUMask(c->stream, 16, mask) == hipSuccess) {
+      int bits = 0;
+      for (int w = 0; w < 16; ++w) bits += __builtin_popcount(mask[w]);
+      if (bits > 0 && bits < n_cu) cus = bits;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  c->stream_cus = cus > 0 ? cus : 256;
+  c->stream_cus_of = (void*)c->stream;
+  return c->stream_cus;
+}
+
 // STREAM: one group per run of a.run_len triples; max_inflight caps the number of groups (= triples
 // in flight).  A cap below one 256-thread block shrinks the block (whole waves), so
 // max_inflight = 1 at G = 64 really is ONE wave walking the stream sequentially.
@@ -226,7 +248,6 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
   return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
     constexpr int G = T::G, E = T::E;
-    const int64_t n_runs = (a.n + a.run_len - 1) / a.run_len;
     unsigned block = 256;
     a.gpw_active = 64 / G;
     if (cap_groups > 0 && cap_groups * G < 256) {
@@ -263,11 +284,58 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       }
     }
     const size_t shmem = (size_t)(block / G) * (size_t)lds_words * sizeof(uint32_t);
+    const int64_t per_block = (int64_t)(block / 64) * a.gpw_active;
+    // groups the launch stream's CUs hold at once (occupancy of THIS instantiation x its CUs)
+    auto pick = [&](auto fn) {
+      using std::integral_constant;
+      auto with_seen = [&](auto smp) {
+        if (seen == SEEN_BITMAP) fn(smp, integral_constant<int, SEEN_BITMAP>{});
+        else if (seen == SEEN_LIST) fn(smp, integral_constant<int, SEEN_LIST>{});
+        else fn(smp, integral_constant<int, SEEN_CSR>{});
+      };
+      if (sampler == NEG_GIVEN)
+        fn(integral_constant<int, NEG_GIVEN>{}, integral_constant<int, SEEN_CSR>{});
+      else if (sampler == NEG_UNIFORM) with_seen(integral_constant<int, NEG_UNIFORM>{});
+      else with_seen(integral_constant<int, NEG_ADAPTIVE>{});
+    };
+    const auto occ_key = std::make_tuple(c->d, sampler, seen, (int)block, (int64_t)shmem);
+    auto occ_it = c->stream_occ.find(occ_key);
+    int occ = occ_it != c->stream_occ.end() ? occ_it->second : 0;
+    if (occ < 1) pick([&](auto smp, auto sn) {
+      constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
+      if (c->d == G * E)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_stream<G, E, SMP, SN, true>, (int)block,
+                                                     shmem);
+      else
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_stream<G, E, SMP, SN, false>,
+                                                     (int)block, shmem);
+    });
+    if (occ < 1) {
+      (void)hipGetLastError();
+      occ = 1;
+    }
+    c->stream_occ[occ_key] = occ;
+    const int64_t resident = (int64_t)occ * stream_cus(c) * per_block;
+    // run_len 0 = by launch size.  A launch whose runs of 8 overfill the chip takes runs of 8 and a
+    // grid of ~1.5 runs per group (the dispatcher balances the rest: r1 sweep).  A smaller launch
+    // (Netflix-sized periods, a rank's share of a period at 8 ranks) is over when its slowest group
+    // is: the shortest runs of >= 4 triples that still fit the chip in ONE residency, one run per
+    // group (profiles/r03_sweep_small.txt: 40,704 triples d=64 0.0433 -> 0.0393 ms, 24,896 triples
+    // d=128 0.0550 -> 0.0413 ms; runs shorter than 4 re-load the user row too often).
+    if (a.run_len <= 0) {
+      a.run_len = 8;
+      if (cap_groups <= 0 && (a.n + 7) / 8 < resident) {
+        a.run_len = 4;
+        while (a.run_len < 8 && (a.n + a.run_len - 1) / a.run_len > resident) ++a.run_len;
+      }
+    }
+    c->last_run_len = a.run_len;
+    const int64_t n_runs = (a.n + a.run_len - 1) / a.run_len;
     int64_t want = n_runs;
     if (cap_groups > 0 && want > cap_groups) want = cap_groups;
-    const int64_t per_block = (int64_t)(block / 64) * a.gpw_active;
     int64_t nblk = (want + per_block - 1) / per_block;
-    if (cap_groups <= 0 || n_runs <= cap_groups) nblk = (2 * nblk + 2) / 3;  // 1.5 runs per group
+    if ((cap_groups <= 0 || n_runs <= cap_groups) && n_runs > resident)
+      nblk = (2 * nblk + 2) / 3;  // 1.5 runs per group
     const int64_t max_blk = std::min<int64_t>(stream_grid_cap() * (256 / block), STREAM_MAX_GRID);
     if (nblk > max_blk) nblk = max_blk;
     const unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
@@ -284,16 +352,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
           hipLaunchKernelGGL((k_stream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
                              c->stream, a);
       };
-      using std::integral_constant;
-      auto with_seen = [&](auto smp) {
-        if (seen == SEEN_BITMAP) go(smp, integral_constant<int, SEEN_BITMAP>{});
-        else if (seen == SEEN_LIST) go(smp, integral_constant<int, SEEN_LIST>{});
-        else go(smp, integral_constant<int, SEEN_CSR>{});
-      };
-      if (sampler == NEG_GIVEN)
-        go(integral_constant<int, NEG_GIVEN>{}, integral_constant<int, SEEN_CSR>{});
-      else if (sampler == NEG_UNIFORM) with_seen(integral_constant<int, NEG_UNIFORM>{});
-      else with_seen(integral_constant<int, NEG_ADAPTIVE>{});
+      pick(go);
     }
     const bool hot = a.hot_slot != nullptr;
     if (cut) {
@@ -831,9 +890,7 @@ static int train_stream_impl(bpr_ctx* c, const int32_t* users, const int32_t* po
   a.seed = seed; a.offset = offset;
   a.n = (int32_t)n; a.I = (int32_t)c->I; a.d = c->d;
   a.pad_user = c->pad_user; a.pad_item = c->pad_item;
-  // run_len 0 = by launch size: runs of 8 once they make >= 12 k groups (the chip holds ~16 k),
-  // runs of 4 below that (Netflix-sized periods of 40 k triples: 349 -> 409 M triples/s)
-  a.run_len = c->run_len > 0 ? c->run_len : (n >= 8 * 12288 ? 8 : 4);
+  a.run_len = c->run_len;  // 0: launch_stream picks it from the launch size and the chip's occupancy
   a.grouped = c->grouped;
   a.au = c->au; a.ai = c->ai; a.an = c->an; a.lr = c->opt.lr;
   a.iw = ItemWeights{c->w_accept, c->w_alias};
@@ -994,6 +1051,10 @@ int bpr_set_hot_rows(bpr_ctx* c, int32_t hot_rows, int32_t replicas) {
   c->hot_rows_opt = hot_rows;
   c->hot_reps_opt = hot_rows > 0 ? replicas : 0;
   return BPR_OK;
+}
+
+int bpr_stream_run_len(bpr_ctx* c) {
+  return c == nullptr ? 0 : c->last_run_len;
 }
 
 int bpr_set_stream_opts(bpr_ctx* c, int32_t grouped_by_user, int32_t run_len) {

@@ -469,6 +469,10 @@ class Engine:
     def set_stream_opts(self, grouped_by_user: bool, run_len: int = 0) -> None:
         native.check(self._lib.bpr_set_stream_opts(self._ctx, int(grouped_by_user), run_len))
 
+    def stream_run_len(self) -> int:
+        """Run length the last STREAM launch used (run_len = 0 lets the library pick it)."""
+        return int(self._lib.bpr_stream_run_len(self._ctx))
+
     def set_hot_rows(self, hot_rows: int = 256, replicas: int = 1) -> None:
         """Replica delta rows for the most popular item rows in STREAM mode (0 = off); takes
         effect at the next plan_epoch."""
