@@ -35,26 +35,26 @@ struct Rccl {
 };
 
 static Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  // resolved once (thread-safe: a function-local static's initialiser)
+  static const Rccl r = [] {
+    Rccl x;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (r.handle != nullptr) break;
+      x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (x.handle != nullptr) break;
     }
-    if (r.handle != nullptr) {
-      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
-      r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
-      r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
-      r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
-      r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
-      r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
-      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.AllGather)
-        r.handle = nullptr;
+    if (x.handle != nullptr) {
+      x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.handle, "ncclGetUniqueId");
+      x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.handle, "ncclCommInitRank");
+      x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
+      x.AllReduce = (decltype(x.AllReduce))dlsym(x.handle, "ncclAllReduce");
+      x.AllGather = (decltype(x.AllGather))dlsym(x.handle, "ncclAllGather");
+      x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.handle, "ncclGetErrorString");
+      if (!x.GetUniqueId || !x.CommInitRank || !x.CommDestroy || !x.AllReduce || !x.AllGather)
+        x.handle = nullptr;
     }
-  }
-  return r.handle != nullptr ? &r : nullptr;
+    return x;
+  }();
+  return r.handle != nullptr ? const_cast<Rccl*>(&r) : nullptr;
 }
 
 #define BPR_NCCL_CHECK(expr)                                                              \

@@ -501,6 +501,39 @@ def test_stream_sequential_limit_equals_b1_sgd(sampler, seen, monkeypatch):
         assert close(sc.cpu().numpy()[:3], sco[:3], 1e-4)
 
 
+def test_stream_run_length_follows_the_launch_size():
+    """run_len = 0 lets the library pick: runs of 8 for launches that fill the chip more than once,
+    the shortest runs of 4..8 triples that fit it in one residency below that (a small launch ends
+    when its slowest group does), 8 under a max_inflight cap; an explicit run_len is kept.  The
+    picks do not depend on it (lr = 0: uniform picks equal the oracle's for every run length)."""
+    d, U, I = 64, 3000, 800
+    total = torch.cuda.get_device_properties(0).multi_processor_count
+    n_big, n_small = 40 * 8 * total * 2 * 8, 6 * total * 2 * 4  # >> / << groups the chip holds x 8
+    P, Q, indptr, indices, users, pos, _ = rand_problem(U, I, d, 100, seed=77, B=n_big)
+    e = make_engine(P, Q, None, (0.01, 0.01, 0.01))
+    e.bind_seen_csr(dev(indptr), dev(indices))
+    e.set_optimizer(kind=0, lr=0.0)
+    order = np.argsort(users, kind="stable")
+    users, pos = users[order], pos[order]
+    want = None
+    for n, run_len, expect in ((n_big, 0, (8, 8)), (n_small, 0, (4, 4)), (n_small, 3, (3, 3)),
+                               (40000, 0, (4, 8))):
+        e.set_stream_opts(True, run_len)
+        negs = torch.zeros(n, dtype=torch.int32, device="cuda")
+        e.train_stream(dev(users[:n]), dev(pos[:n]), sampler=1, neg=negs, seed=3, offset=0)
+        assert expect[0] <= e.stream_run_len() <= expect[1], (n, run_len, e.stream_run_len())
+        if n == n_small:
+            got = negs.cpu().numpy()
+            if want is None:
+                want = oracle.sample_uniform(indptr, indices, I, users[:n], seed=3, offset=0)
+            assert np.array_equal(got, want)
+    e.set_stream_opts(True, 0)
+    negs = torch.zeros(n_small, dtype=torch.int32, device="cuda")
+    e.train_stream(dev(users[:n_small]), dev(pos[:n_small]), sampler=1, neg=negs, seed=3, offset=0,
+                   max_inflight=4)
+    assert e.stream_run_len() == 8
+
+
 @pytest.mark.parametrize("seen", ["", "list", "csr"])
 @pytest.mark.parametrize("d", [8, 32, 50, 64, 128, 256, 1024])
 def test_stream_picks_match_the_oracle_at_full_concurrency(d, seen, monkeypatch):
