@@ -27,11 +27,11 @@ def test_two_rank_training_matches_reference_curves(golden_dir, kind, mode):
         {"stream-lag": "29634", "stream-shard": "29636"}[mode]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "tools" / "parity_multi.py"),
-           kind, "1,2,3,4,5", mode]
+           kind, ",".join(str(s) for s in range(1, 31)), mode]  # 30 seeds: 5 made a 2-sigma gate flaky
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     runs = [json.loads(line) for line in res.stdout.splitlines() if line.startswith("{")]
-    assert len(runs) == 5 and all(r["world"] == 2 for r in runs)
+    assert len(runs) == 30 and all(r["world"] == 2 for r in runs)
     ref = json.loads((golden_dir / "e2e_reference.json").read_text())
     report, ok = [], True
     for key in ("ndcg@100", "recall@20"):
