@@ -45,6 +45,13 @@ if CFG1:
     USERS, ITEMS, ACTIONS, EPOCHS = 10_000, 5_000, 500_000, 8
 REG = {"user": 0.0016, "item": 0.0001, "neg": 0.00375}
 INIT_SEED, ORDER_SEED = 13, 13
+# E2E_ORDERS=vary: every run shuffles with its OWN epoch-order stream (seed 100000 + sampler seed)
+# instead of the shared ORDER_SEED — the yardstick for the paths that shuffle on the device (STREAM,
+# batched STREAM): one fixed order is not neutral (Adam / uniform: 0.006 nDCG below the mean over
+# orders half-way up the curve).  `E2E_ORDERS=vary make_golden_e2e.py <optimizer> <kind>_<seed> ...`
+# writes e2e_reference_<optimizer>_orders_<run>.json, `... merge <optimizer>` folds them into
+# e2e_reference_<optimizer>_orders.json.
+VARY_ORDERS = os.environ.get("E2E_ORDERS") == "vary"
 SAMPLER_SEEDS = [1, 2, 3, 4, 5]
 ADAPTIVE_P = 0.05
 
@@ -106,7 +113,7 @@ def run(data, seen_all, sampler_kind, sampler_seed, optimizer="sgd"):
         sampler.update_stats()
     users_t, items_t = torch.from_numpy(data.users.astype(np.int64)), torch.from_numpy(
         data.items.astype(np.int64))
-    order_rng = np.random.default_rng(ORDER_SEED)
+    order_rng = np.random.default_rng(100000 + sampler_seed if VARY_ORDERS else ORDER_SEED)
     curve = [evaluate(model, data, seen_all)]
     model.train()
     for _ in range(EPOCHS):
@@ -127,10 +134,19 @@ def run(data, seen_all, sampler_kind, sampler_seed, optimizer="sgd"):
 def merge(name):
     """`make_golden_e2e.py merge sgd|adam|rmsprop|nesterov`: fold the per-run files written by
     `make_golden_e2e.py <optimizer> <kind>_<seed> ...` into the optimizer's fixture and remove them."""
-    main_file = OUT / ("e2e_reference.json" if name == "sgd" else f"e2e_reference_{name}.json")
-    res = json.loads(main_file.read_text())
-    for f in sorted(OUT.glob(f"e2e_reference_{name}_*_*.json")):
-        run = f.stem[len(f"e2e_reference_{name}_"):]
+    if VARY_ORDERS:
+        main_file = OUT / f"e2e_reference_{name}_orders.json"
+        res = json.loads(main_file.read_text()) if main_file.exists() else \
+            {"optimizer": name, **OPT_KW[name], "orders": "per run: default_rng(100000 + sampler seed)", "runs": {}}
+        prefix = f"e2e_reference_{name}_orders_"
+    else:
+        main_file = OUT / ("e2e_reference.json" if name == "sgd" else f"e2e_reference_{name}.json")
+        res = json.loads(main_file.read_text())
+        prefix = f"e2e_reference_{name}_"
+    for f in sorted(OUT.glob(prefix + "*_*.json")):
+        run = f.stem[len(prefix):]
+        if not VARY_ORDERS and run.startswith("orders"):
+            continue
         j = json.loads(f.read_text())
         res["runs"][run] = {"ndcg@100": j["ndcg@100"], "recall@20": j["recall@20"]}
         f.unlink()
@@ -156,7 +172,8 @@ def main_opt(name, only):
         curve = run(data, seen_all, kind, s, optimizer=name)
         out = {"optimizer": name, **OPT_KW[name],
                "ndcg@100": [c[0] for c in curve], "recall@20": [c[1] for c in curve]}
-        (OUT / f"e2e_reference_{name}_{kind}_{s}.json").write_text(json.dumps(out, indent=1))
+        tag = f"{name}_orders" if VARY_ORDERS else name
+        (OUT / f"e2e_reference_{tag}_{kind}_{s}.json").write_text(json.dumps(out, indent=1))
         print(name, kind, s, f"{time.time() - t0:.0f}s", [round(c[0], 4) for c in curve],
               flush=True)
 

@@ -32,7 +32,8 @@ def test_two_rank_training_matches_reference_curves(golden_dir, kind, mode):
     assert res.returncode == 0, res.stderr[-2000:]
     runs = [json.loads(line) for line in res.stdout.splitlines() if line.startswith("{")]
     assert len(runs) == 30 and all(r["world"] == 2 for r in runs)
-    ref = json.loads((golden_dir / "e2e_reference.json").read_text())
+    # the ranks shuffle on the device: the yardstick is the reference over epoch orders
+    ref = json.loads((golden_dir / "e2e_reference_sgd_orders.json").read_text())
     report, ok = [], True
     for key in ("ndcg@100", "recall@20"):
         for epoch in (-2, -1):

@@ -5,9 +5,10 @@ own device shuffle (STREAM, batched STREAM, "strict-own-order") average over ord
 fair yardstick is strict-own-order — exact mini-batch semantics, same order distribution.
 
   python tools/e2e_many_seeds.py OPT KIND N_SEEDS FIRST_SEED PATH[,PATH...]
-    OPT   sgd | adam            KIND  uniform | adaptive
+    OPT   sgd | adam | rmsprop | nesterov      KIND  uniform | adaptive
     PATH  strict-ref-order | strict-own-order | batched | stream-sync | stream-lag1 |
           stream-lag1-masked | stream-split2-lag1
+ref* = the reference over epoch orders (e2e_reference_<opt>_orders.json), ref = its one fixed order.
 Results of r03: profiles/r03_strict_adam_uniform_study.txt, profiles/r03_e2e_many_seeds.txt"""
 import json
 import math
@@ -20,7 +21,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "revisit-bpr_amd"))
 sys.path.insert(0, str(ROOT))
-from tests.test_gpu_e2e_parity import SCHEDULES, evaluator, make_model, ref_stats  # noqa: E402
+from tests.test_gpu_e2e_parity import SCHEDULES, TORCH_OPT, evaluator, make_model, ref_stats  # noqa: E402
 from revisit_bpr.fast import BatchedStreamTrainer, StreamTrainer, StrictTrainer  # noqa: E402
 
 opt_name, kind = sys.argv[1], sys.argv[2]
@@ -34,6 +35,11 @@ if opt_name == "sgd":
 else:
     gold = json.loads((g / f"e2e_reference_{opt_name}.json").read_text())
     ref = {"config": cfg, "runs": gold["runs"]}
+if (g / f"e2e_reference_{opt_name}_orders.json").exists() and "fixed-order-ref" not in sys.argv:
+    # paths with their own shuffle are compared with the reference over epoch orders
+    ref_orders = {"config": cfg, "runs": json.loads((g / f"e2e_reference_{opt_name}_orders.json").read_text())["runs"]}
+else:
+    ref_orders = None
 d = np.load(g / "e2e_data.npz")
 U, I = int(d["num_users"]), int(d["num_items"])
 dev = torch.device("cuda")
@@ -46,13 +52,14 @@ def run(path, seed):
     if opt_name == "sgd":
         opt = torch.optim.SGD(model.parameters(), lr=gold["lr"])
     else:
-        opt = torch.optim.Adam(model.parameters(), lr=gold["lr"], betas=tuple(gold["betas"]))
+        opt = TORCH_OPT[opt_name](model.parameters(), gold)
     common = dict(sampler=kind, adaptive_p=cfg["adaptive_p"], batch_size=cfg["B"], seed=seed)
     if path.startswith("strict"):
         tr = StrictTrainer(model, opt, users, items, indptr, indices,
                            order_seed=cfg["order_seed"] if path == "strict-ref-order" else None, **common)
-    elif path == "batched":
-        tr = BatchedStreamTrainer(model, opt, users, items, indptr, indices, **common)
+    elif path.startswith("batched"):  # batched | batched-inflight<N>
+        cap = int(path[len("batched-inflight"):]) if path.startswith("batched-inflight") else None
+        tr = BatchedStreamTrainer(model, opt, users, items, indptr, indices, max_inflight=cap, **common)
     else:
         assert opt_name == "sgd", "STREAM is the plain-SGD path"
         tr = StreamTrainer(model, users, items, indptr, indices, lr=cfg["lr"],
@@ -72,11 +79,12 @@ for path in paths:
     res[path] = curves
     for key in ("ndcg@100", "recall@20"):
         for epoch in (2, 4, E):
-            r = ref_stats(ref, kind, key, epoch)
+            use = ref_orders if (ref_orders is not None and path != "strict-ref-order") else ref
+            r = ref_stats(use, kind, key, epoch)
             o = np.array([c[epoch][key] for c in curves])
             se = math.sqrt(r.var(ddof=1) / len(r) + o.var(ddof=1) / len(o))
             line = (f"{path:19s} {opt_name} {kind} {key} epoch {epoch:2d}: ours {o.mean():.4f} (n={len(o)}, sd {o.std(ddof=1):.4f}) "
-                    f"ref {r.mean():.4f} (n={len(r)})  diff {o.mean() - r.mean():+.4f} z {(o.mean() - r.mean()) / se:+.2f}")
+                    f"ref{'*' if use is ref_orders else ' '} {r.mean():.4f} (n={len(r)})  diff {o.mean() - r.mean():+.4f} z {(o.mean() - r.mean()) / se:+.2f}")
             if "strict-own-order" in res and path != "strict-own-order":
                 b = np.array([c[epoch][key] for c in res["strict-own-order"]])
                 se2 = math.sqrt(b.var(ddof=1) / len(b) + o.var(ddof=1) / len(o))
