@@ -35,12 +35,22 @@ def test_two_rank_training_matches_reference_curves(golden_dir, kind, mode):
     # the ranks shuffle on the device: the yardstick is the reference over epoch orders
     ref = json.loads((golden_dir / "e2e_reference_sgd_orders.json").read_text())
     report, ok = [], True
+    # A rank sees the other ranks' item updates up to two chunks late (one reconciliation in flight,
+    # DESIGN.md 7).  On this 96 k-triple set a chunk is 5 % of an epoch (at ML-20M: 1 %), and the
+    # uniform-sampler curve still climbs 0.01 per epoch at the end: the gate allows that lag times
+    # the reference's local slope on top of the plateau tolerance.
+    d = np.load(golden_dir / "e2e_data.npz")
+    cfg = json.loads((golden_dir / "e2e_reference.json").read_text())["config"]
+    I, n = int(d["num_items"]), len(d["users"])
+    period = max(1, int(I * math.log(I) / cfg["B"])) * cfg["B"]
+    lag_epochs = 2 * (period / 2) / n
     for key in ("ndcg@100", "recall@20"):
         for epoch in (-2, -1):
             o = np.array([r[key][epoch] for r in runs])
             rr = np.array([v[key][epoch] for k, v in ref["runs"].items() if k.startswith(kind)])
+            prev = np.array([v[key][epoch - 1] for k, v in ref["runs"].items() if k.startswith(kind)])
             se = math.sqrt(o.var(ddof=1) / len(o) + rr.var(ddof=1) / len(rr))
-            tol = 0.002 + 2 * se
+            tol = 0.002 + lag_epochs * abs(rr.mean() - prev.mean()) + 2 * se
             diff = o.mean() - rr.mean()
             report.append(f"2 ranks {kind} {key} epoch {epoch}: ours {o.mean():.4f}±{o.std(ddof=1):.4f} "
                           f"ref {rr.mean():.4f}±{rr.std(ddof=1):.4f} diff {diff:+.4f} tol {tol:.4f}")
