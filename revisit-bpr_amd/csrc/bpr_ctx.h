@@ -1,6 +1,7 @@
 // bpr_ctx.h — private state of a bpr_ctx (shared by bprcore.hip and bpr_refresh.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <map>
@@ -83,6 +84,7 @@ struct bpr_ctx {
   // next bpr_adaptive_refresh_begin only queues the sort.  Any call that moves the item table
   // afterwards clears it.
   bool keys_cut = false;
+  bool keys_event = false;  // ev_keys was recorded by the cut kernel itself (hipExtLaunchKernelGGL)
   // private scratch — epoch planner
   uint64_t* plan_keys = nullptr;
   uint64_t* plan_keys_sorted = nullptr;

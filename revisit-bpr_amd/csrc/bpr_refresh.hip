@@ -781,12 +781,14 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
   int32_t* const order = c->order_alloc[back] + BPR_ORDER_PAD + foff;
   float* const sigma = c->sigma_buf[back] + f_lo;
   // ---- cut (unless the last STREAM launch's epilogue did it: bpr_train_stream_cut)
+  const bool event_on_cut = c->keys_cut && c->keys_event;  // ev_keys rode on the cut kernel
   if (!c->keys_cut) {
     dim3 tgrid((unsigned)((I + 31) / 32), (unsigned)((d + 31) / 32));
     hipLaunchKernelGGL(k_transpose, tgrid, dim3(256), 0, c->stream, c->Q, c->keysT, I, d,
                        c->sig_acc);
   }
   c->keys_cut = false;
+  c->keys_event = false;
   // the sort reads the buffers just cut; the next cut goes to the other pair
   const float* const keysT = c->keysT + foff;
   double* const sig_acc = c->sig_acc + 2 * f_lo;
@@ -803,7 +805,7 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
       BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
       BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
     }
-    BPR_HIP_CHECK(hipEventRecord(c->ev_keys, c->stream));
+    if (!event_on_cut) BPR_HIP_CHECK(hipEventRecord(c->ev_keys, c->stream));
     BPR_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_keys, 0));
     st = c->side;
   }

@@ -365,8 +365,21 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       ea.T = c->keysT; ea.sig_acc = c->sig_acc;
       ea.H = hot ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d; ea.I = (int32_t)c->I;
       dim3 eg((unsigned)((c->I + 31) / 32), (unsigned)((c->d + 31) / 32) + 1u);
-      hipLaunchKernelGGL(k_stream_epilogue_cut, eg, dim3(256), 0, c->stream, ea);
+      // the split refresh's side stream waits for this cut: the event rides on the kernel's own
+      // completion signal (hipExtLaunchKernelGGL stop event) instead of a marker packet behind it
+      static const bool ride = getenv("BPR_CUT_EVENT") == nullptr || atoi(getenv("BPR_CUT_EVENT")) != 0;
+      if (ride && c->ev_keys == nullptr) {
+        BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
+        BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
+      }
+      if (ride) {
+        hipExtLaunchKernelGGL(k_stream_epilogue_cut, eg, dim3(256), 0, c->stream, nullptr, c->ev_keys,
+                              0, ea);
+      } else {
+        hipLaunchKernelGGL(k_stream_epilogue_cut, eg, dim3(256), 0, c->stream, ea);
+      }
       c->keys_cut = true;
+      c->keys_event = ride;
     } else if (out_scalars != nullptr || hot) {
       EpilogueArgs ea;
       memset(&ea, 0, sizeof(ea));
