@@ -202,13 +202,19 @@ def main_cfg1(args):
                           "eval_users": int(len(data.eval_users)), "generator": "synthetic.generate_latent("
                           "10000, 5000, 500000, factors=8, strength=1.5, median_per_user=25, min_per_user=5, "
                           "seed=7, eval_users=2000)", "data_sha256": data_checksum(data)}, "runs": {}}
-        for f in sorted(OUT.glob("e2e_cfg1_*_*.json")):
-            if f.name == "e2e_cfg1_reference.json":
+        stem = "e2e_cfg1o_" if VARY_ORDERS else "e2e_cfg1_"
+        main_file = OUT / ("e2e_cfg1_reference_orders.json" if VARY_ORDERS else "e2e_cfg1_reference.json")
+        if VARY_ORDERS:
+            res["config"]["order_seed"] = "per run: 100000 + sampler seed"
+            if main_file.exists():
+                res["runs"] = json.loads(main_file.read_text())["runs"]
+        for f in sorted(OUT.glob(stem + "*_*.json")):
+            if f.name.startswith("e2e_cfg1_reference"):
                 continue
             j = json.loads(f.read_text())
-            res["runs"][f.stem[len("e2e_cfg1_"):]] = j
+            res["runs"][f.stem[len(stem):]] = j
             f.unlink()
-        (OUT / "e2e_cfg1_reference.json").write_text(json.dumps(res, indent=1))
+        main_file.write_text(json.dumps(res, indent=1))
         print(sorted(res["runs"]))
         return
     data = cfg1_data()
@@ -216,7 +222,7 @@ def main_cfg1(args):
     for kind, s in [(k, int(v)) for k, v in (r.split("_") for r in args)]:
         t0 = time.time()
         curve = run(data, seen_all, kind, s)
-        (OUT / f"e2e_cfg1_{kind}_{s}.json").write_text(json.dumps(
+        (OUT / f"e2e_cfg1{'o' if VARY_ORDERS else ''}_{kind}_{s}.json").write_text(json.dumps(
             {"ndcg@100": [c[0] for c in curve], "recall@20": [c[1] for c in curve]}, indent=1))
         print("cfg1", kind, s, f"{time.time() - t0:.0f}s", [round(c[0], 4) for c in curve], flush=True)
 
