@@ -85,6 +85,10 @@ struct bpr_ctx {
   // afterwards clears it.
   bool keys_cut = false;
   bool keys_event = false;  // ev_keys was recorded by the cut kernel itself (hipExtLaunchKernelGGL)
+  // k_stream's in-kernel tail (the cut as the end of the launch): two sets of
+  // {started, finished, tile, -} tickets used alternately
+  uint32_t* tail_ctr = nullptr;
+  int tail_parity = 0;
   // private scratch — epoch planner
   uint64_t* plan_keys = nullptr;
   uint64_t* plan_keys_sorted = nullptr;

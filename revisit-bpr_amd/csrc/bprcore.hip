@@ -283,7 +283,12 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
         }
       }
     }
-    const size_t shmem = (size_t)(block / G) * (size_t)lds_words * sizeof(uint32_t);
+    // cut = true: the next snapshot's keys are cut by a TAIL of the launch itself (stream_tail,
+    // bpr_kernels.h) — BPR_TAIL=0 keeps r3's separate k_stream_epilogue_cut (measurements)
+    const bool tail_on = getenv("BPR_TAIL") == nullptr || atoi(getenv("BPR_TAIL")) != 0;
+    const bool tail = cut && tail_on;
+    size_t shmem = (size_t)(block / G) * (size_t)lds_words * sizeof(uint32_t);
+    if (tail) shmem = std::max<size_t>(shmem, 32 * 33 * sizeof(float));  // the transposition tile
     const int64_t per_block = (int64_t)(block / 64) * a.gpw_active;
     // groups the launch stream's CUs hold at once (occupancy of THIS instantiation x its CUs)
     auto pick = [&](auto fn) {
@@ -340,22 +345,51 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     if (nblk > max_blk) nblk = max_blk;
     const unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
     a.bm_words = lds_words;
+    const bool hot = a.hot_slot != nullptr;
+    StreamTail tl;
+    memset(&tl, 0, sizeof(tl));
+    if (cut && c->ev_keys == nullptr) {
+      BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
+      BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
+    }
+    if (tail) {
+      if (c->tail_ctr == nullptr) {
+        BPR_HIP_CHECK(hipMalloc(&c->tail_ctr, 8 * sizeof(uint32_t)));
+        BPR_HIP_CHECK(hipMemsetAsync(c->tail_ctr, 0, 8 * sizeof(uint32_t), c->stream));
+        c->tail_parity = 0;
+      }
+      tl.ctr = c->tail_ctr;
+      tl.parity = c->tail_parity;
+      c->tail_parity ^= 1;
+      tl.out = out_scalars;
+      tl.delta = c->hot_delta;
+      tl.hot_slot = hot ? c->hot_slot : nullptr;
+      tl.T = c->keysT;
+      tl.sig_acc = c->sig_acc;
+      tl.H = hot ? c->hot_H : 0;
+      tl.R = c->hot_R;
+    }
     {
       Timer tm(c, true);
       (void)tm;
+      // (tail: the event the split refresh's side stream waits for rides on the launch's own
+      // completion signal — hipExtLaunchKernelGGL's stop event — no marker packet)
+      hipEvent_t stop = tail ? c->ev_keys : nullptr;
       auto go = [&](auto smp, auto sn) {
         constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
         if (c->d == G * E)
-          hipLaunchKernelGGL((k_stream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
-                             c->stream, a);
+          hipExtLaunchKernelGGL((k_stream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
+                                c->stream, nullptr, stop, 0, a, tl);
         else
-          hipLaunchKernelGGL((k_stream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
-                             c->stream, a);
+          hipExtLaunchKernelGGL((k_stream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
+                                c->stream, nullptr, stop, 0, a, tl);
       };
       pick(go);
     }
-    const bool hot = a.hot_slot != nullptr;
-    if (cut) {
+    if (tail) {
+      c->keys_cut = true;
+      c->keys_event = true;
+    } else if (cut) {
       // the epilogue also cuts the next snapshot's keys (k_stream_epilogue_cut) — into the key
       // buffer the split refresh that may still be sorting does NOT read (bpr_ctx.h keysT_buf)
       EpilogueCutArgs ea;
@@ -368,10 +402,6 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       // the split refresh's side stream waits for this cut: the event rides on the kernel's own
       // completion signal (hipExtLaunchKernelGGL stop event) instead of a marker packet behind it
       static const bool ride = getenv("BPR_CUT_EVENT") == nullptr || atoi(getenv("BPR_CUT_EVENT")) != 0;
-      if (ride && c->ev_keys == nullptr) {
-        BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
-        BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
-      }
       if (ride) {
         hipExtLaunchKernelGGL(k_stream_epilogue_cut, eg, dim3(256), 0, c->stream, nullptr, c->ev_keys,
                               0, ea);
@@ -481,6 +511,7 @@ int bpr_ctx_destroy(bpr_ctx* c) {
   side_free(c);
   vs_free(c);
   hipFree(c->dev_scalars);
+  hipFree(c->tail_ctr);
   for (auto e : c->ev_start) hipEventDestroy(e);
   for (auto e : c->ev_stop) hipEventDestroy(e);
   delete c;

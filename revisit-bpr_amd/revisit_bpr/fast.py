@@ -165,6 +165,12 @@ class StreamTrainer:
             hi = min(lo + self.chunk, self.n)
             if lo < hi:
                 self._chunk(lo, hi)
+            elif self.shard_refresh and self.sampler == eng.NEG_ADAPTIVE:
+                # a rank that ran out of triples (shards are balanced by interactions, not equal)
+                # still owes the others its share of the sort and the all-gather of this round:
+                # every collective of a round is entered by every rank, in the same order
+                e.adaptive_refresh_sharded(self.item_sync.rank, self.item_sync.world,
+                                           self.item_sync.group)
             if self.item_sync is not None and (k + 1) % self.sync_every == 0:
                 self.item_sync.step()
         if self.item_sync is not None:

@@ -29,7 +29,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from accelerate.utils import set_seed  # noqa: E402
 
-from revisit_bpr.metrics import NDCG, Precision, Recall, RocAucManySlow, RocAucOne  # noqa: E402
+from revisit_bpr.metrics import (MAP, NDCG, FBeta, Precision, Recall, RocAucMany,  # noqa: E402
+                                 RocAucManySlow, RocAucOne)
 from revisit_bpr.models import BPR  # noqa: E402
 from revisit_bpr.models.bpr import MF  # noqa: E402
 from revisit_bpr.modules import AdaptiveSampler  # noqa: E402
@@ -229,12 +230,51 @@ def gen_metrics() -> None:
         m(lt, tt)
         m(lt[:3], tt[:3])
         out[f"{name}_ndcg@10_stream"] = m.get_metric().numpy()
+        # r4: the remaining metric classes (map.py, fbeta.py, auc.py RocAucMany, NDCG's linear gain)
+        # and the mask argument of the AUC family; the mask comes from its own stream so that the
+        # arrays above stay what they were
+        mrng = np.random.default_rng(11 + nb)
+        mask = (mrng.random((nb, ni)) < 0.85).astype(np.float32)
+        mask[:, 0] = 1.0
+        out[f"{name}_mask"] = mask
+        mt = torch.from_numpy(mask)
+        for k in (5, 10, 20, 50, 100):
+            out[f"{name}_map@{k}"] = MAP(topk=k).compute(lt, tt).numpy()
+            out[f"{name}_map_raw@{k}"] = MAP(topk=k, normalized=False).compute(lt, tt).numpy()
+            out[f"{name}_f1@{k}"] = FBeta(topk=k).compute(lt, tt).numpy()
+            out[f"{name}_f0.5@{k}"] = FBeta(topk=k, beta=0.5).compute(lt, tt).numpy()
+            out[f"{name}_ndcg_linear@{k}"] = NDCG(topk=k, gain_function="linear").compute(lt, tt).numpy()
+        out[f"{name}_auc_many_dense"] = RocAucMany().compute(lt, tt).numpy()
+        out[f"{name}_auc_many_dense_masked"] = RocAucMany().compute(lt, tt, mt).numpy()
+        out[f"{name}_auc_many_masked"] = RocAucManySlow().compute(lt, tt, mt).numpy()
+        out[f"{name}_auc_one_masked"] = RocAucOne().compute(lt, tt, mt).numpy()
+        for cls, key in ((MAP, "map"), (FBeta, "f1"), (Recall, "recall"), (Precision, "precision")):
+            m = cls(topk=10)
+            m(lt, tt)
+            m(lt[:3], tt[:3])
+            out[f"{name}_{key}@10_stream"] = m.get_metric().numpy()
+        # the eval loop's view (example.py:195-230): item 0 masked like a seen item, never a target
+        l0, t0 = lt.clone(), tt.clone()
+        l0[:, 0] = -1e13
+        t0[:, 0] = 0.0
+        for k in (5, 10, 20, 50, 100):
+            out[f"{name}_pad0_ndcg@{k}"] = NDCG(topk=k).compute(l0, t0).numpy()
+            out[f"{name}_pad0_recall@{k}"] = Recall(topk=k).compute(l0, t0).numpy()
+            out[f"{name}_pad0_precision@{k}"] = Precision(topk=k).compute(l0, t0).numpy()
+        out[f"{name}_pad0_auc_many"] = RocAucManySlow().compute(l0, t0).numpy()
+        m = RocAucManySlow()
+        m(lt[1:], tt[1:], mt[1:])  # (row 0 has no positives: 0/0)
+        m(lt[1:4], tt[1:4])
+        out[f"{name}_auc_many_stream"] = m.get_metric().numpy()
     np.savez_compressed(OUT / "metrics.npz", **out)
     print("wrote metrics")
 
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["metrics"]:  # only metrics.npz
+        gen_metrics()
+        sys.exit(0)
     for seed in (13, 42069):
         gen_math(seed, "uin", False)
     gen_math(13, "uin", True)

@@ -1071,6 +1071,53 @@ def test_split_refresh_pipeline_sequential_equals_oracle(lag, fused):
         assert close(e.Q.cpu().numpy(), Qo, 2e-5)
 
 
+@pytest.mark.parametrize("tail", ["1", "0"])
+@pytest.mark.parametrize("d,sampler,n", [(128, 2, 120_000), (128, 1, 30_000), (256, 2, 40_000),
+                                          (100, 0, 25_000), (32, 2, 900)])
+def test_stream_cut_at_full_concurrency_sees_the_final_table(d, sampler, n, tail, monkeypatch):
+    """bpr_train_stream_cut with the chip full: the keys of the next snapshot are cut by the launch's
+    own tail (r4; BPR_TAIL=0: by r3's separate epilogue kernel) AFTER every workgroup's atomics —
+    the snapshot committed afterwards is bit for bit the oracle's order of the item table as the
+    launch left it (hot rows folded), launch after launch (the tail's tickets alternate), and the
+    loss statistics count every triple."""
+    monkeypatch.setenv("BPR_TAIL", tail)
+    rng = np.random.default_rng(d + n)
+    U, I = 6000, 3000
+    P = rng.normal(0, 0.1, (U, d)).astype(np.float32)
+    Q = rng.normal(0, 0.1, (I, d)).astype(np.float32)
+    P[0] = 0
+    Q[0] = 0
+    lens = rng.integers(1, 40, U)
+    lens[0] = 0
+    rows = [np.sort(rng.choice(np.arange(1, I), size=int(k), replace=False)).astype(np.int32) for k in lens]
+    indptr = np.zeros(U + 1, np.int64)
+    indptr[1:] = np.cumsum(lens)
+    indices = np.concatenate(rows)
+    users = rng.integers(1, U, n).astype(np.int32)
+    pos = (1 + (rng.zipf(1.3, n) % (I - 1))).astype(np.int32)  # skewed: the hot block is in use
+    e = make_engine(P, Q, None, (0.01, 0.02, 0.03))
+    e.bind_seen_csr(dev(indptr), dev(indices))
+    e.set_optimizer(kind=0, lr=0.05)
+    e.set_stream_opts(True, 0)
+    pu, pi = e.plan_epoch(dev(users), dev(pos), n, seed=3)  # grouped by user, hot block built
+    neg = dev(rng.integers(1, I, n).astype(np.int32)) if sampler == 0 else None
+    sc = torch.zeros(4, device="cuda")
+    e.adaptive_refresh()
+    for launch in range(3):
+        e.train_stream(pu, pi, sampler=sampler, neg=neg, adaptive_p=0.05, seed=5, offset=launch * n,
+                       scalars=sc, cut=True)
+        Qnow = e.Q.cpu().numpy()  # (stream order: after the launch and its fold)
+        e.adaptive_refresh_begin()  # only queues the sort: the keys were cut by the launch
+        e.Q.mul_(1.0)
+        e.adaptive_refresh_commit()
+        QT, sig = oracle.adaptive_stats(Qnow)
+        got_o, got_s = e.adaptive_snapshot()
+        assert np.array_equal(got_o.cpu().numpy(), oracle.adaptive_order(QT)), launch
+        assert close(got_s.cpu().numpy(), sig, 1e-5)
+        assert int(sc[3]) == (launch + 1) * n
+    assert torch.isfinite(e.Q).all() and torch.isfinite(sc).all()
+
+
 # ---- heavy users: precomputed seen bitmaps in HBM -------------------------------------------------
 @pytest.mark.parametrize("seen,heavy_t", [("", None), ("list", None), ("", "-1"), ("", "40"), ("list", "600")])
 @pytest.mark.parametrize("d", [64, 256])
