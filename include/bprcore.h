@@ -185,6 +185,20 @@ int bpr_comm_init(bpr_ctx* ctx, const void* id_host, int32_t rank, int32_t world
 int bpr_comm_destroy(bpr_ctx* ctx);
 int bpr_item_sync(bpr_ctx* ctx);
 int bpr_item_sync_finish(bpr_ctx* ctx);
+/* The bases follow the tables when they are re-bound (another shape or buffer).  A table overwritten
+ * IN PLACE (checkpoint restore, restore-best) is invisible to the library: call this afterwards,
+ * on every rank, with identical tables — nothing may be in flight that should still be applied. */
+int bpr_item_sync_rebase(bpr_ctx* ctx);
+/* Two tiers inside the library (see bpr_hot_exchange below): bpr_comm_hot_tier sets the hot set
+ * (the same list on every rank), allocates the exchange buffers and turns the tier on;
+ * bpr_hot_sync after every STREAM launch (or sub-launch) folds the hot exchange in flight, cuts the
+ * launch's hot deltas and all-reduces them on the communicator's stream; bpr_item_sync stays the
+ * per-period step of the cold rows (call it right after bpr_hot_sync); bpr_item_sync_finish folds
+ * both.  Every collective of the ctx's communicator runs on the communicator's stream in program
+ * order (bpr_adaptive_refresh's all-gather included: with a communicator it IS collective — every
+ * rank must call it the same number of times, in the same place of the sequence). */
+int bpr_comm_hot_tier(bpr_ctx* ctx, const int32_t* items_host, int32_t H, const uint32_t* counts_host);
+int bpr_hot_sync(bpr_ctx* ctx);
 /* The side stream of the split refresh (a hipStream_t of the ctx's device; NULL = a plain
  * non-blocking stream created by the library on first use).  The caller keeps ownership. */
 int bpr_set_side_stream(bpr_ctx* ctx, void* hip_stream);
@@ -316,6 +330,35 @@ int bpr_stream_run_len(bpr_ctx* ctx);
  * as updating Q directly, up to the association of fp32 sums.  hot_rows = 0 turns it off.  Takes
  * effect at the next bpr_plan_epoch. */
 int bpr_set_hot_rows(bpr_ctx* ctx, int32_t hot_rows, int32_t replicas);
+
+/* ---- two-tier item reconciliation, HOT tier (several GPUs; no reference counterpart — the
+ * reference's latent DDP, experiments/launcher.py:35-73, would all-reduce every gradient of every
+ * step).  At full-size launches per rank, N replicas each pour a whole launch into the same few
+ * popular rows before anybody sees the others' updates; those rows — and only those — are therefore
+ * exchanged after EVERY launch (or sub-launch) as a block of H x d floats (128 KB at H = 256,
+ * d = 128), while the cold rows keep the per-period all-reduce of bpr_item_fold_delta.
+ *
+ * bpr_set_hot_items  the hot set as the caller gives it — the ranks must agree on it (the H most
+ *                    popular items of the WHOLE training set); items_host [H] distinct item rows in
+ *                    the canonical order of the exchange buffers, counts_host [I] (or NULL) only
+ *                    steers the slot placement.  H = 0 returns to bpr_set_hot_rows' own choice.
+ * bpr_hot_tier_begin hot_base [H, d] <- the hot rows of the item table (replicas identical at this
+ *                    point); from here on STREAM launches leave their hot-row deltas in the block.
+ * bpr_hot_exchange   one pass over the block on the ctx stream:
+ *                      fold_prev: hot_base += tot   (tot = all-reduced sum of the previous exchange)
+ *                      cut:       tot <- this rank's deltas of the launches since, deltas <- 0
+ *                      Q[hot rows] <- hot_base + tot;  cold_base (optional, [I, d]): same rows <- same
+ *                    The caller all-reduces `tot` (SUM) between two calls.  hot_base only ever takes
+ *                    all-reduced sums: it stays bit-identical on every rank.  cold_base keeps the
+ *                    cold tier's delta of a hot row at exactly zero.
+ * bpr_hot_tier_end   launches fold their hot block themselves again (call bpr_hot_exchange with
+ *                    fold_prev as due and cut = 1 first, all-reduce, then once more with cut = 0). */
+int bpr_set_hot_items(bpr_ctx* ctx, const int32_t* items_host, int32_t H, const uint32_t* counts_host);
+int bpr_hot_rows(bpr_ctx* ctx, int32_t* rows_host);
+int bpr_hot_tier_begin(bpr_ctx* ctx, float* hot_base);
+int bpr_hot_exchange(bpr_ctx* ctx, float* hot_base, float* tot, int32_t fold_prev, int32_t cut,
+                     float* cold_base);
+int bpr_hot_tier_end(bpr_ctx* ctx);
 
 /* Epoch order for STREAM mode — replaces DataLoader(shuffle=True, generator=manual_seed(seed))
  * (example.py:307-321; experiments/bpr/exp.py:109-118): a seeded pseudo-random partition of the n

@@ -77,6 +77,12 @@ struct Comm {
   float *bbase = nullptr, *bown = nullptr, *btot = nullptr;  // [I] each (item bias), or NULL
   int64_t n = 0, nb = 0;
   bool pending = false;
+  const float *q_at = nullptr, *bias_at = nullptr;  // the tables the bases were cut from
+  // hot tier (bpr_comm_hot_tier / bpr_hot_sync): the hot block's own exchange, every launch
+  float *hb = nullptr, *htot = nullptr;  // [H*d] each
+  int64_t nh = 0;
+  bool hot_pending = false;
+  hipEvent_t ev_hot_cut = nullptr, ev_hot_done = nullptr, ev_gather = nullptr;
 };
 
 void comm_free(bpr_ctx* c) {
@@ -87,8 +93,12 @@ void comm_free(bpr_ctx* c) {
   if (m->comm && l) l->CommDestroy(m->comm);
   hipFree(m->base); hipFree(m->own); hipFree(m->tot);
   hipFree(m->bbase); hipFree(m->bown); hipFree(m->btot);
+  hipFree(m->hb); hipFree(m->htot);
   if (m->ev_cut) hipEventDestroy(m->ev_cut);
   if (m->ev_done) hipEventDestroy(m->ev_done);
+  if (m->ev_hot_cut) hipEventDestroy(m->ev_hot_cut);
+  if (m->ev_hot_done) hipEventDestroy(m->ev_hot_done);
+  if (m->ev_gather) hipEventDestroy(m->ev_gather);
   if (m->stream) hipStreamDestroy(m->stream);
   delete m;
   c->comm = nullptr;
@@ -117,6 +127,13 @@ static int comm_rebase(bpr_ctx* c, Comm* m) {
     BPR_HIP_CHECK(hipMemcpyAsync(m->bbase, c->bias, sizeof(float) * nb, hipMemcpyDeviceToDevice,
                                  c->stream));
   m->pending = false;
+  m->q_at = c->Q;
+  m->bias_at = c->bias;
+  if (m->hb != nullptr && c->hot_tier) {  // the hot base follows the table too
+    if (m->hot_pending) BPR_HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->hot_pending = false;
+    if (int rc = bpr_hot_tier_begin(c, m->hb)) return rc;
+  }
   return BPR_OK;
 }
 
@@ -140,9 +157,13 @@ int comm_item_sync(bpr_ctx* c, bool finish_only) {
     set_error("bpr_item_sync: no communicator (bpr_comm_init first)");
     return BPR_ERR_INVALID;
   }
-  if (m->n != c->I * c->d || m->nb != (c->bias != nullptr ? c->I : 0)) {
+  if (m->n != c->I * c->d || m->nb != (c->bias != nullptr ? c->I : 0) || m->q_at != c->Q ||
+      m->bias_at != c->bias) {
+    // tables (re)bound since — another shape or another buffer: start from them.  (A table
+    // overwritten IN PLACE, e.g. a checkpoint restored into the same storage, is invisible here:
+    // bpr_item_sync_rebase.)
     if (m->pending) BPR_HIP_CHECK(hipStreamSynchronize(m->stream));
-    if (int rc = comm_rebase(c, m)) return rc;  // tables (re)bound since: start from them
+    if (int rc = comm_rebase(c, m)) return rc;
   }
   c->keys_cut = false;  // the item table moves
   const float scale = 1.0f;
@@ -172,15 +193,43 @@ int comm_item_sync(bpr_ctx* c, bool finish_only) {
   return comm_launch_allreduce(c, m);
 }
 
-// all-gather of this rank's slice of the back snapshot (bpr_adaptive_refresh with a communicator)
+// hot tier: fold the exchange in flight, cut the launch's hot deltas (cut) and all-reduce them
+static int comm_hot_sync(bpr_ctx* c, bool cut) {
+  Comm* m = static_cast<Comm*>(c->comm);
+  if (m == nullptr || m->hb == nullptr || !c->hot_tier) {
+    set_error("bpr_hot_sync: no hot tier (bpr_comm_init, then bpr_comm_hot_tier)");
+    return BPR_ERR_INVALID;
+  }
+  if (!cut && !m->hot_pending) return BPR_OK;
+  if (m->hot_pending) BPR_HIP_CHECK(hipStreamWaitEvent(c->stream, m->ev_hot_done, 0));
+  if (int rc = bpr_hot_exchange(c, m->hb, m->htot, m->hot_pending ? 1 : 0, cut ? 1 : 0, m->base)) return rc;
+  m->hot_pending = false;
+  if (!cut) return BPR_OK;
+  Rccl* l = rccl();
+  BPR_HIP_CHECK(hipEventRecord(m->ev_hot_cut, c->stream));
+  BPR_HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_hot_cut, 0));
+  BPR_NCCL_CHECK(l->AllReduce(m->htot, m->htot, (size_t)m->nh, ncclFloat32, ncclSum, m->comm, m->stream));
+  BPR_HIP_CHECK(hipEventRecord(m->ev_hot_done, m->stream));
+  m->hot_pending = true;
+  return BPR_OK;
+}
+
+// all-gather of this rank's slice of the back snapshot (bpr_adaptive_refresh with a communicator).
+// Every collective of a communicator goes to ITS stream, in program order — an all-gather on the
+// ctx stream beside an all-reduce still in flight on the communicator's would be two concurrent
+// operations on one communicator — with events ordering it against the ctx stream on both sides.
 int comm_gather_snapshot(bpr_ctx* c, int32_t* order_back, float* sigma_back, int per) {
   Comm* m = static_cast<Comm*>(c->comm);
   Rccl* l = rccl();
   const size_t cnt = (size_t)per * (size_t)c->I;
+  BPR_HIP_CHECK(hipEventRecord(m->ev_gather, c->stream));
+  BPR_HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_gather, 0));
   BPR_NCCL_CHECK(l->AllGather(order_back + (size_t)m->rank * cnt, order_back, cnt, ncclInt32, m->comm,
-                              c->stream));
+                              m->stream));
   BPR_NCCL_CHECK(l->AllGather(sigma_back + (size_t)m->rank * per, sigma_back, (size_t)per, ncclFloat32,
-                              m->comm, c->stream));
+                              m->comm, m->stream));
+  BPR_HIP_CHECK(hipEventRecord(m->ev_gather, m->stream));
+  BPR_HIP_CHECK(hipStreamWaitEvent(c->stream, m->ev_gather, 0));
   return BPR_OK;
 }
 
@@ -229,7 +278,45 @@ int bpr_comm_init(bpr_ctx* c, const void* id_host, int32_t rank, int32_t world) 
   BPR_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   BPR_HIP_CHECK(hipEventCreateWithFlags(&m->ev_cut, hipEventDisableTiming));
   BPR_HIP_CHECK(hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
+  BPR_HIP_CHECK(hipEventCreateWithFlags(&m->ev_hot_cut, hipEventDisableTiming));
+  BPR_HIP_CHECK(hipEventCreateWithFlags(&m->ev_hot_done, hipEventDisableTiming));
+  BPR_HIP_CHECK(hipEventCreateWithFlags(&m->ev_gather, hipEventDisableTiming));
   return comm_rebase(c, m);
+}
+
+int bpr_item_sync_rebase(bpr_ctx* c) {
+  if (int rc = check_bound(c, "bpr_item_sync_rebase")) return rc;
+  Comm* m = static_cast<Comm*>(c->comm);
+  if (m == nullptr) return fail(BPR_ERR_INVALID, "bpr_item_sync_rebase: no communicator");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (m->pending || m->hot_pending) BPR_HIP_CHECK(hipStreamSynchronize(m->stream));
+  return comm_rebase(c, m);
+}
+
+int bpr_comm_hot_tier(bpr_ctx* c, const int32_t* items_host, int32_t H, const uint32_t* counts_host) {
+  if (int rc = check_bound(c, "bpr_comm_hot_tier")) return rc;
+  Comm* m = static_cast<Comm*>(c->comm);
+  if (m == nullptr) return fail(BPR_ERR_INVALID, "bpr_comm_hot_tier: no communicator (bpr_comm_init first)");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (m->hot_pending) BPR_HIP_CHECK(hipStreamSynchronize(m->stream));
+  m->hot_pending = false;
+  if (c->hot_tier) bpr_hot_tier_end(c);
+  hipFree(m->hb); hipFree(m->htot);
+  m->hb = m->htot = nullptr;
+  m->nh = 0;
+  if (int rc = bpr_set_hot_items(c, items_host, H, counts_host)) return rc;
+  if (H <= 0) return BPR_OK;
+  m->nh = (int64_t)c->hot_H * c->d;
+  BPR_HIP_CHECK(hipMalloc(&m->hb, sizeof(float) * m->nh));
+  BPR_HIP_CHECK(hipMalloc(&m->htot, sizeof(float) * m->nh));
+  BPR_HIP_CHECK(hipMemsetAsync(m->htot, 0, sizeof(float) * m->nh, c->stream));
+  return bpr_hot_tier_begin(c, m->hb);
+}
+
+int bpr_hot_sync(bpr_ctx* c) {
+  if (int rc = check_bound(c, "bpr_hot_sync")) return rc;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  return comm_hot_sync(c, true);
 }
 
 int bpr_comm_destroy(bpr_ctx* c) {
@@ -250,6 +337,9 @@ int bpr_item_sync(bpr_ctx* c) {
 int bpr_item_sync_finish(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_item_sync_finish")) return rc;
   BPR_HIP_CHECK(hipSetDevice(c->device));
+  Comm* m = static_cast<Comm*>(c->comm);
+  if (m != nullptr && m->hb != nullptr && c->hot_tier)
+    if (int rc = comm_hot_sync(c, false)) return rc;
   return comm_item_sync(c, true);
 }
 

@@ -85,10 +85,6 @@ struct bpr_ctx {
   // afterwards clears it.
   bool keys_cut = false;
   bool keys_event = false;  // ev_keys was recorded by the cut kernel itself (hipExtLaunchKernelGGL)
-  // k_stream's in-kernel tail (the cut as the end of the launch): two sets of
-  // {started, finished, tile, -} tickets used alternately
-  uint32_t* tail_ctr = nullptr;
-  int tail_parity = 0;
   // private scratch — epoch planner
   uint64_t* plan_keys = nullptr;
   uint64_t* plan_keys_sorted = nullptr;
@@ -108,6 +104,12 @@ struct bpr_ctx {
   void* hot_delta_alloc = nullptr;
   double hot_balance = 1.0;      // modelled max / mean channel load of a launch (hot_build_impl)
   const int32_t* hot_key_ptr = nullptr;  // training positives the popularity was measured on
+  // two-tier item reconciliation (several GPUs): the hot set is given by the caller (the same on
+  // every rank, bpr_set_hot_items), hot_canon[slot] = the row's position in that list, and while
+  // hot_tier is on the launches leave their deltas in the block for bpr_hot_exchange
+  bool hot_explicit = false;
+  bool hot_tier = false;
+  int32_t* hot_canon = nullptr;  // [hot_H]
   int64_t hot_key_n = 0;
   // heavy users' seen bitmaps (built once per seen CSR, by the first sampling STREAM launch)
   uint32_t* heavy_off = nullptr;   // [U] word offset of the user's row in heavy_bits, ~0u = light
@@ -139,6 +141,7 @@ void side_free(bpr_ctx* c);         // bpr_refresh.hip
 int heavy_build_impl(bpr_ctx* c);   // bpr_refresh.hip
 void heavy_free(bpr_ctx* c);        // bpr_refresh.hip
 int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n);  // bpr_refresh.hip
+int hot_set_items_impl(bpr_ctx* c, const int32_t* items, int H, const uint32_t* counts);  // bpr_refresh.hip
 void hot_free(bpr_ctx* c);                                       // bpr_refresh.hip
 int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n,
                     int64_t chunk, uint64_t seed, int32_t* users_out, int32_t* pos_out);

@@ -502,11 +502,9 @@ __device__ __forceinline__ float neg_logsigmoid(float x) {
 // Loss statistics: wave shuffle → LDS → ONE plain store of the block's partial sums.  (Adding them
 // to the caller's 4 floats with atomics from every wave serialises ~10^4 same-line atomics per
 // launch — measured 0.3 ms — so the final sum is a separate one-block kernel, k_sum_partials.)
-// (through = true: the slot is written through to memory — agent-scope store — so that another
-// workgroup of the SAME launch can read it: k_stream's in-kernel tail)
 __device__ __forceinline__ void reduce_scalars(float* partials, float s_loss, float s_reg,
                                                float s_abs, float s_cnt, int lane,
-                                               bool accumulate = false, bool through = false) {
+                                               bool accumulate = false) {
   __shared__ float red[4][4];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -527,10 +525,7 @@ __device__ __forceinline__ void reduce_scalars(float* partials, float s_loss, fl
     float v = 0.f;
     for (int k = 0; k < nw; ++k) v += red[k][threadIdx.x];
     float* slot = partials + (int64_t)blockIdx.x * 4 + threadIdx.x;
-    if (through)
-      __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      *slot = accumulate ? *slot + v : v;
+    *slot = accumulate ? *slot + v : v;
   }
 }
 

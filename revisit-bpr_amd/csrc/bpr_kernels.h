@@ -224,131 +224,6 @@ __global__ __launch_bounds__(256) void k_stream_epilogue_cut(const EpilogueCutAr
   }
 }
 
-// The same cut as a TAIL of the STREAM launch itself (r4; bpr_train_stream_cut): no second kernel, no
-// kernel boundary and no event packet between two launches.  The cut needs the item table as the
-// launch leaves it, so it can only start when every workgroup is through its runs; the workgroups
-// still resident at that moment do it together:
-//   * every workgroup takes a START ticket when it begins and a FINISH ticket when its runs are done
-//     and its atomics are acknowledged (s_waitcnt vmcnt(0): device-scope atomics are performed below
-//     the L2s, the acknowledgement is their completion);
-//   * a workgroup that finishes while workgroups are still waiting to be dispatched (started <
-//     gridDim.x) leaves — its slot is needed; one that finishes after the last dispatch JOINS the
-//     tail: it waits until finished == gridDim.x (everybody not finished is resident and waits for
-//     nothing, so this cannot deadlock; at least the last workgroup to start joins) and then takes
-//     tiles of the cut from a shared counter until none are left.
-// The L2s of the 8 XCDs are not coherent with each other within a launch: the tail reads the item
-// table, the hot block and the loss partials with agent-scope (sc1) loads, which are served below
-// the L2s where the atomics were performed; what it writes (keys, folded hot rows, zeroed deltas,
-// loss sums) is only read by later kernels.
-// Counters: two sets of 4 words, used alternately; a launch zeroes the set of the next one.
-struct StreamTail {
-  uint32_t* ctr;  // NULL = no tail
-  int32_t parity;
-  float* out;     // caller's 4 loss scalars (NULL = none)
-  float* delta;
-  const int32_t* hot_slot;  // NULL = no hot block
-  float* T;
-  double* sig_acc;
-  int32_t H, R;
-};
-
-__device__ __forceinline__ float ld_agent(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The tail's arguments are the kernel's second by-value parameter, but the run loop sits at the
-// kernel's register limit and every argument the compiler preloads costs it SGPRs (spilled into
-// VGPR lanes, then into scratch): they are read from the kernarg segment at the point of use,
-// through a pointer the optimiser cannot see through.
-typedef const StreamTail __attribute__((address_space(4))) * TailPtr;
-template <typename Args>
-__device__ __forceinline__ TailPtr tail_args() {
-  const char __attribute__((address_space(4)))* k =
-      (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-  TailPtr p = (TailPtr)(k + ((sizeof(Args) + 7) & ~(size_t)7));
-  asm volatile("" : "+s"(p));
-  return p;
-}
-
-__device__ __forceinline__ void stream_tail(const StreamTail t, float* __restrict__ Q,
-                                         const float* __restrict__ partials, const int d,
-                                         const int I, float* tile /* >= 32*33 floats of LDS */) {
-  __shared__ uint32_t s_word;
-  uint32_t* const c = t.ctr + 4 * t.parity;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my atomics (and write-through stores) are done
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t started = __hip_atomic_load(&c[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&c[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_word = started == gridDim.x ? 1u : 0u;
-  }
-  __syncthreads();
-  if (s_word == 0u) return;
-  if (threadIdx.x == 0)
-    while (__hip_atomic_load(&c[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
-      __builtin_amdgcn_s_sleep(8);
-  __syncthreads();
-  const int tiles_i = (I + 31) >> 5, tiles_f = (d + 31) >> 5;
-  const uint32_t n_tiles = (uint32_t)(tiles_i * tiles_f);
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x (blockDim / 32)
-  const int rows_per_pass = (int)(blockDim.x >> 5);
-  const int hd = t.H * d;
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0)
-      s_word = __hip_atomic_fetch_add(&c[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const uint32_t w = s_word;
-    if (w > n_tiles) break;
-    if (w == n_tiles) {  // the statistics "tile"
-      for (int k = threadIdx.x; k < 2 * d; k += blockDim.x) t.sig_acc[k] = 0.0;  // (as k_transpose does)
-      if (t.out != nullptr && threadIdx.x < 64) {
-        // one wave: lane l sums partials l, l + 64, … of each of the 4 scalars (double), then a
-        // butterfly over the wave
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int b = threadIdx.x; b < (int)gridDim.x; b += 64)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) acc[k] += (double)ld_agent(partials + (int64_t)b * 4 + k);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
-        if (threadIdx.x == 0)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) t.out[k] += (float)acc[k];
-      }
-      continue;
-    }
-    const int i0 = (int)(w / (uint32_t)tiles_f) * 32;
-    const int f0 = (int)(w % (uint32_t)tiles_f) * 32;
-    for (int r = ty; r < 32; r += rows_per_pass) {
-      const int i = i0 + r, f = f0 + tx;
-      float v = 0.f;
-      if (i < I && f < d) {
-        float* q = Q + (uint32_t)i * (uint32_t)d + f;
-        v = ld_agent(q);
-        const int32_t s = t.hot_slot != nullptr ? t.hot_slot[i] : -1;
-        if (s >= 0) {
-          float sum = 0.f;
-          for (int rep = 0; rep < t.R; ++rep) {
-            float* p = t.delta + rep * hd + s * d + f;
-            sum += ld_agent(p);
-            *p = 0.f;
-          }
-          v += sum;
-          *q = v;
-        }
-      }
-      tile[r * 33 + tx] = v;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += rows_per_pass) {
-      const int f = f0 + r, i = i0 + tx;
-      if (f < d && i < I) t.T[(int64_t)f * I + i] = tile[tx * 33 + r];
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // STREAM: the throughput kernel.
 //
@@ -436,20 +311,8 @@ __global__ __launch_bounds__(256, (E <= 4 ? (SAMPLER == NEG_ADAPTIVE && SEEN == 
                                                  ? BPR_STREAM_WAVES_PER_EU - 1
                                                  : BPR_STREAM_WAVES_PER_EU)
                                           : (E <= 8 ? 3 : 2)))
-void k_stream(const StreamArgs a, const StreamTail /* read through tail_args() */) {
+void k_stream(const StreamArgs a) {
   constexpr int GPW = 64 / G;
-  {
-    const TailPtr tp = tail_args<StreamArgs>();
-    uint32_t* const ctr = tp->ctr;
-    if (ctr != nullptr && threadIdx.x == 0) {
-      const int par = tp->parity;
-      __hip_atomic_fetch_add(&ctr[4 * par], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (blockIdx.x == 0) {  // the next tail launch's counters (kernel boundaries order the launches)
-        uint32_t* nx = ctr + 4 * (par ^ 1);
-        nx[0] = nx[1] = nx[2] = 0u;
-      }
-    }
-  }
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
   const int gw = lane / G;
@@ -708,16 +571,7 @@ void k_stream(const StreamArgs a, const StreamTail /* read through tail_args() *
       }
     }
   }
-  const TailPtr tp = tail_args<StreamArgs>();
-  const bool has_tail = tp->ctr != nullptr;
-  if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane, false, has_tail);
-  if (has_tail) {
-    __syncthreads();  // the LDS scratch of the run loop becomes the tail's transposition tile
-    StreamTail t;
-    t.ctr = tp->ctr; t.parity = tp->parity; t.out = tp->out; t.delta = tp->delta;
-    t.hot_slot = tp->hot_slot; t.T = tp->T; t.sig_acc = tp->sig_acc; t.H = tp->H; t.R = tp->R;
-    stream_tail(t, a.Q, a.partials, d, a.I, reinterpret_cast<float*>(bpr_smem));
-  }
+  if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1097,6 +951,68 @@ __global__ __launch_bounds__(256) void k_item_fold_delta(float* __restrict__ q,
     q[k] = nq;
     own[k] = dl;
     tot[k] = dl;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// two-tier reconciliation, HOT tier (multi-GPU): the hot block of a launch is exchanged on its own,
+// every launch (or sub-launch), while the cold rows wait for the per-period all-reduce.
+//   hb  [H, d]  the hot rows as of the last reconciled exchange — bit-identical on every rank
+//               (only all-reduced sums are ever added to it), canonical row order
+//   tot [H, d]  in: the all-reduced sum of every rank's deltas of the PREVIOUS exchange (fold_prev);
+//               out: this rank's deltas of the launch just finished (cut), to be all-reduced next
+// One pass: hb += tot_prev;  dl = delta[slot] (summed over replicas), delta = 0;  tot = dl;
+//           Q[item] = hb + dl   — the reconciled value plus what only this rank knows so far.
+// cold_base (optional): the cold tier's base of the same rows is set to the new Q, so that the cold
+// tier's delta of a hot row is exactly zero (hot rows travel in the hot tier only).
+// ---------------------------------------------------------------------------------------------
+struct HotStepArgs {
+  float* Q;
+  float* delta;
+  const int32_t* hot_items;
+  const int32_t* canon;
+  float* hb;
+  float* tot;
+  float* cold_base;
+  int32_t H, R, d, fold_prev, cut;
+};
+
+__global__ __launch_bounds__(256) void k_hot_step(const HotStepArgs a) {
+  const int64_t n = (int64_t)a.H * a.d;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(k / a.d), f = (int)(k % a.d);
+    const int32_t it = a.hot_items[s];
+    const int64_t c = (int64_t)a.canon[s] * a.d + f;
+    float b = a.hb[c];
+    if (a.fold_prev) b += a.tot[c];
+    float dl = 0.f;
+    if (a.cut) {
+      for (int r = 0; r < a.R; ++r) {
+        dl += a.delta[(int64_t)r * n + k];
+        a.delta[(int64_t)r * n + k] = 0.f;
+      }
+      a.tot[c] = dl;
+    }
+    a.hb[c] = b;
+    if (it >= 0) {
+      const int64_t q = (int64_t)it * a.d + f;
+      a.Q[q] = b + dl;
+      if (a.cold_base != nullptr) a.cold_base[q] = b + dl;
+    }
+  }
+}
+
+// hb = the hot rows of Q in canonical order (start of the hot tier: replicas are identical)
+__global__ __launch_bounds__(256) void k_hot_gather(const float* __restrict__ Q,
+                                                    const int32_t* __restrict__ hot_items,
+                                                    const int32_t* __restrict__ canon,
+                                                    float* __restrict__ hb, int H, int d) {
+  const int64_t n = (int64_t)H * d;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(k / d), f = (int)(k % d);
+    hb[(int64_t)canon[s] * d + f] = Q[(int64_t)hot_items[s] * d + f];
   }
 }
 

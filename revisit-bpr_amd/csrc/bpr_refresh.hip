@@ -464,6 +464,10 @@ void hot_free(bpr_ctx* c) {
   hipFree(c->hot_slot);
   hipFree(c->hot_items);
   hipFree(c->hot_delta_alloc);
+  hipFree(c->hot_canon);
+  c->hot_canon = nullptr;
+  c->hot_explicit = false;
+  c->hot_tier = false;
   c->hot_delta_alloc = nullptr;
   c->hot_slot = c->hot_items = nullptr;
   c->hot_delta = nullptr;
@@ -486,32 +490,23 @@ static inline int channel_of(uint64_t byte_addr) {
 // decides which channels carry its load: the rows are placed greedily, heaviest first, each into
 // the free slot whose channels end up least loaded — counting the load the rows left in Q put on
 // every channel — so the block evens out the whole launch, not only itself.
-int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n) {
-  hot_free(c);
+// cnt: positives per item (the channel model's load; may be all zero for a given hot set);
+// given != NULL: the hot set, in the caller's canonical order (bpr_set_hot_items).
+static int hot_build_from(bpr_ctx* c, std::vector<uint32_t>& cnt, const int32_t* given, int H, int64_t n) {
   const int64_t I = c->I;
-  int H = c->hot_rows_opt, R = c->hot_reps_opt;
-  if (H > I - 1) H = (int)(I - 1);
-  c->hot_key_ptr = pos;
-  c->hot_key_n = n;
-  if (H <= 0 || R <= 0 || n <= 0) return BPR_OK;
-  uint32_t* counts = nullptr;
-  BPR_HIP_CHECK(hipMalloc(&counts, sizeof(uint32_t) * I));
-  BPR_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * I, c->stream));
-  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_item_hist, dim3(grid), dim3(256), 0, c->stream, pos, n, I, counts);
-  std::vector<uint32_t> cnt((size_t)I);
-  BPR_HIP_CHECK(hipMemcpyAsync(cnt.data(), counts, sizeof(uint32_t) * I, hipMemcpyDeviceToHost,
-                               c->stream));
-  BPR_HIP_CHECK(hipStreamSynchronize(c->stream));  // one-time setup per training set
-  hipFree(counts);
-  // the H most popular rows (ties by ascending id; the pad row and rows nobody likes stay out)
+  const int R = c->hot_reps_opt > 0 ? c->hot_reps_opt : 1;
   std::vector<int32_t> by((size_t)I);
-  for (int64_t i = 0; i < I; ++i) by[i] = (int32_t)i;
-  if (c->pad_item >= 0 && c->pad_item < I) cnt[c->pad_item] = 0;
-  std::partial_sort(by.begin(), by.begin() + H, by.end(), [&](int32_t x, int32_t y) {
-    return cnt[x] != cnt[y] ? cnt[x] > cnt[y] : x < y;
-  });
-  while (H > 0 && cnt[by[H - 1]] == 0) --H;
+  if (given != nullptr) {
+    for (int k = 0; k < H; ++k) by[k] = given[k];
+  } else {
+    // the H most popular rows (ties by ascending id; the pad row and rows nobody likes stay out)
+    for (int64_t i = 0; i < I; ++i) by[i] = (int32_t)i;
+    if (c->pad_item >= 0 && c->pad_item < I) cnt[c->pad_item] = 0;
+    std::partial_sort(by.begin(), by.begin() + H, by.end(), [&](int32_t x, int32_t y) {
+      return cnt[x] != cnt[y] ? cnt[x] > cnt[y] : x < y;
+    });
+    while (H > 0 && cnt[by[H - 1]] == 0) --H;
+  }
   if (H == 0) return BPR_OK;
   // the block starts on a channel-round boundary so that slot -> channels is known
   const size_t round_bytes = (size_t)HOT_CHANNELS * HOT_GRANULE;
@@ -534,16 +529,24 @@ int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n) {
     const double w = (double)cnt[i] + neg_share;
     for (int l = 0; l < lines; ++l) load[channel_of(qbase + (uint64_t)(i * row_bytes + l * 128))] += w;
   }
-  std::vector<int32_t> slot_of((size_t)I, -1), item_of((size_t)H, -1);
+  // placement order: heaviest first (a given set need not be sorted by popularity)
+  std::vector<int> place((size_t)H);
+  for (int k = 0; k < H; ++k) place[k] = k;
+  std::stable_sort(place.begin(), place.end(), [&](int x, int y) { return cnt[by[x]] > cnt[by[y]]; });
+  std::vector<int32_t> slot_of((size_t)I, -1), item_of((size_t)H, -1), canon_of((size_t)H, -1);
   std::vector<char> used((size_t)H, 0);
   const uint64_t hbase = (uint64_t)(uintptr_t)c->hot_delta;
   static const bool naive = getenv("BPR_HOT_NAIVE") != nullptr;  // measurement aid: slot = rank
-  for (int k = 0; k < H; ++k) {
+  // (the greedy search is H^2 slot evaluations: beyond 4,096 rows the block is filled in order —
+  // that many rows even out over the channels by themselves)
+  const bool in_order = naive || H > 4096;
+  for (int kk = 0; kk < H; ++kk) {
+    const int k = place[kk];
     const int32_t it = by[k];
     const double w = (double)cnt[it] + neg_share;
     int best = -1;
     double best_cost = 0.0;
-    for (int s = 0; s < H && !naive; ++s) {
+    for (int s = 0; s < H && !in_order; ++s) {
       if (used[s]) continue;
       double cost = 0.0;  // the most loaded channel among the slot's lines, after the row moved in
       for (int l = 0; l < lines; ++l)
@@ -553,10 +556,11 @@ int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n) {
         best_cost = cost;
       }
     }
-    if (naive) best = k;
+    if (in_order) best = kk;
     used[best] = 1;
     slot_of[it] = best;
     item_of[best] = it;
+    canon_of[best] = k;
     for (int l = 0; l < lines; ++l)
       load[channel_of(hbase + (uint64_t)(best * row_bytes + l * 128))] += w;
   }
@@ -573,14 +577,64 @@ int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n) {
   }
   BPR_HIP_CHECK(hipMalloc(&c->hot_slot, sizeof(int32_t) * I));
   BPR_HIP_CHECK(hipMalloc(&c->hot_items, sizeof(int32_t) * H));
+  BPR_HIP_CHECK(hipMalloc(&c->hot_canon, sizeof(int32_t) * H));
   BPR_HIP_CHECK(hipMemcpyAsync(c->hot_slot, slot_of.data(), sizeof(int32_t) * I,
                                hipMemcpyHostToDevice, c->stream));
   BPR_HIP_CHECK(hipMemcpyAsync(c->hot_items, item_of.data(), sizeof(int32_t) * H,
+                               hipMemcpyHostToDevice, c->stream));
+  BPR_HIP_CHECK(hipMemcpyAsync(c->hot_canon, canon_of.data(), sizeof(int32_t) * H,
                                hipMemcpyHostToDevice, c->stream));
   BPR_HIP_CHECK(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
   c->hot_H = H;
   c->hot_R = R;
   return BPR_OK;
+}
+
+int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n) {
+  if (c->hot_explicit) {  // the caller's hot set stays (bpr_set_hot_items); only note the training set
+    c->hot_key_ptr = pos;
+    c->hot_key_n = n;
+    return BPR_OK;
+  }
+  hot_free(c);
+  const int64_t I = c->I;
+  int H = c->hot_rows_opt;
+  if (H > I - 1) H = (int)(I - 1);
+  c->hot_key_ptr = pos;
+  c->hot_key_n = n;
+  if (H <= 0 || c->hot_reps_opt <= 0 || n <= 0) return BPR_OK;
+  uint32_t* counts = nullptr;
+  BPR_HIP_CHECK(hipMalloc(&counts, sizeof(uint32_t) * I));
+  BPR_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * I, c->stream));
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_item_hist, dim3(grid), dim3(256), 0, c->stream, pos, n, I, counts);
+  std::vector<uint32_t> cnt((size_t)I);
+  BPR_HIP_CHECK(hipMemcpyAsync(cnt.data(), counts, sizeof(uint32_t) * I, hipMemcpyDeviceToHost,
+                               c->stream));
+  BPR_HIP_CHECK(hipStreamSynchronize(c->stream));  // one-time setup per training set
+  hipFree(counts);
+  return hot_build_from(c, cnt, nullptr, H, n);
+}
+
+// bpr_set_hot_items: the hot set as the caller gives it (the ranks of a multi-GPU job agree on it);
+// counts (per item, may be NULL) only steer the slot placement.
+int hot_set_items_impl(bpr_ctx* c, const int32_t* items, int H, const uint32_t* counts) {
+  const void* key_ptr = c->hot_key_ptr;
+  const int64_t key_n = c->hot_key_n;
+  hot_free(c);
+  c->hot_key_ptr = (const int32_t*)key_ptr;
+  c->hot_key_n = key_n;
+  c->hot_explicit = H > 0;
+  if (H <= 0) return BPR_OK;
+  std::vector<uint32_t> cnt((size_t)c->I, 0u);
+  int64_t n = 0;
+  if (counts != nullptr)
+    for (int64_t i = 0; i < c->I; ++i) {
+      cnt[i] = counts[i];
+      n += counts[i];
+    }
+  if (c->hot_reps_opt <= 0) c->hot_reps_opt = 1;
+  return hot_build_from(c, cnt, items, H, n > 0 ? n : 1);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -283,12 +283,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
         }
       }
     }
-    // cut = true: the next snapshot's keys are cut by a TAIL of the launch itself (stream_tail,
-    // bpr_kernels.h) — BPR_TAIL=0 keeps r3's separate k_stream_epilogue_cut (measurements)
-    const bool tail_on = getenv("BPR_TAIL") == nullptr || atoi(getenv("BPR_TAIL")) != 0;
-    const bool tail = cut && tail_on;
-    size_t shmem = (size_t)(block / G) * (size_t)lds_words * sizeof(uint32_t);
-    if (tail) shmem = std::max<size_t>(shmem, 32 * 33 * sizeof(float));  // the transposition tile
+    const size_t shmem = (size_t)(block / G) * (size_t)lds_words * sizeof(uint32_t);
     const int64_t per_block = (int64_t)(block / 64) * a.gpw_active;
     // groups the launch stream's CUs hold at once (occupancy of THIS instantiation x its CUs)
     auto pick = [&](auto fn) {
@@ -346,50 +341,30 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     const unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
     a.bm_words = lds_words;
     const bool hot = a.hot_slot != nullptr;
-    StreamTail tl;
-    memset(&tl, 0, sizeof(tl));
+    if (cut && hot && c->hot_tier) {
+      set_error("bpr_train_stream_cut: the hot tier is on — the fold belongs to bpr_hot_exchange, the "
+                "cut to bpr_adaptive_refresh_begin after it");
+      return BPR_ERR_INVALID;
+    }
     if (cut && c->ev_keys == nullptr) {
       BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
       BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
     }
-    if (tail) {
-      if (c->tail_ctr == nullptr) {
-        BPR_HIP_CHECK(hipMalloc(&c->tail_ctr, 8 * sizeof(uint32_t)));
-        BPR_HIP_CHECK(hipMemsetAsync(c->tail_ctr, 0, 8 * sizeof(uint32_t), c->stream));
-        c->tail_parity = 0;
-      }
-      tl.ctr = c->tail_ctr;
-      tl.parity = c->tail_parity;
-      c->tail_parity ^= 1;
-      tl.out = out_scalars;
-      tl.delta = c->hot_delta;
-      tl.hot_slot = hot ? c->hot_slot : nullptr;
-      tl.T = c->keysT;
-      tl.sig_acc = c->sig_acc;
-      tl.H = hot ? c->hot_H : 0;
-      tl.R = c->hot_R;
-    }
     {
       Timer tm(c, true);
       (void)tm;
-      // (tail: the event the split refresh's side stream waits for rides on the launch's own
-      // completion signal — hipExtLaunchKernelGGL's stop event — no marker packet)
-      hipEvent_t stop = tail ? c->ev_keys : nullptr;
       auto go = [&](auto smp, auto sn) {
         constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
         if (c->d == G * E)
-          hipExtLaunchKernelGGL((k_stream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
-                                c->stream, nullptr, stop, 0, a, tl);
+          hipLaunchKernelGGL((k_stream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
+                             c->stream, a);
         else
-          hipExtLaunchKernelGGL((k_stream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
-                                c->stream, nullptr, stop, 0, a, tl);
+          hipLaunchKernelGGL((k_stream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
+                             c->stream, a);
       };
       pick(go);
     }
-    if (tail) {
-      c->keys_cut = true;
-      c->keys_event = true;
-    } else if (cut) {
+    if (cut) {
       // the epilogue also cuts the next snapshot's keys (k_stream_epilogue_cut) — into the key
       // buffer the split refresh that may still be sorting does NOT read (bpr_ctx.h keysT_buf)
       EpilogueCutArgs ea;
@@ -410,14 +385,15 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       }
       c->keys_cut = true;
       c->keys_event = ride;
-    } else if (out_scalars != nullptr || hot) {
+    } else if (out_scalars != nullptr || (hot && !c->hot_tier)) {
+      const bool fold = hot && !c->hot_tier;  // hot tier: the deltas stay for bpr_hot_exchange
       EpilogueArgs ea;
       memset(&ea, 0, sizeof(ea));
       ea.partials = a.partials; ea.n_blocks = (int)grid; ea.out = out_scalars;
       ea.Q = c->Q; ea.delta = c->hot_delta; ea.hot_items = c->hot_items;
-      ea.H = hot ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d;
+      ea.H = fold ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d;
       ea.fold_blocks =
-          hot ? (int)std::min<int64_t>(((int64_t)c->hot_H * c->d + 255) / 256, 64) : 0;
+          fold ? (int)std::min<int64_t>(((int64_t)c->hot_H * c->d + 255) / 256, 64) : 0;
       hipLaunchKernelGGL(k_stream_epilogue, dim3(1 + ea.fold_blocks), dim3(256), 0, c->stream, ea);
     }
     BPR_HIP_CHECK(hipGetLastError());
@@ -511,7 +487,6 @@ int bpr_ctx_destroy(bpr_ctx* c) {
   side_free(c);
   vs_free(c);
   hipFree(c->dev_scalars);
-  hipFree(c->tail_ctr);
   for (auto e : c->ev_start) hipEventDestroy(e);
   for (auto e : c->ev_stop) hipEventDestroy(e);
   delete c;
@@ -1094,6 +1069,70 @@ int bpr_set_hot_rows(bpr_ctx* c, int32_t hot_rows, int32_t replicas) {
   hot_free(c);  // rebuilt by the next bpr_plan_epoch
   c->hot_rows_opt = hot_rows;
   c->hot_reps_opt = hot_rows > 0 ? replicas : 0;
+  return BPR_OK;
+}
+
+int bpr_set_hot_items(bpr_ctx* c, const int32_t* items_host, int32_t H, const uint32_t* counts_host) {
+  if (int rc = check_bound(c, "bpr_set_hot_items")) return rc;
+  if (H < 0 || H > 32768 || H >= c->I || (H > 0 && items_host == nullptr))
+    return fail(BPR_ERR_INVALID, "bpr_set_hot_items: need 0 <= H <= min(32768, I - 1) item ids");
+  if (c->hot_tier) return fail(BPR_ERR_INVALID, "bpr_set_hot_items: the hot tier is on (bpr_hot_tier_end first)");
+  std::vector<char> seen((size_t)c->I, 0);
+  for (int k = 0; k < H; ++k) {
+    const int32_t it = items_host[k];
+    if (it < 0 || it >= c->I || it == c->pad_item || seen[it])
+      return fail(BPR_ERR_INVALID, "bpr_set_hot_items: ids must be distinct item rows, not the pad row");
+    seen[it] = 1;
+  }
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return hot_set_items_impl(c, items_host, H, counts_host);
+}
+
+int bpr_hot_rows(bpr_ctx* c, int32_t* rows_host) {
+  if (c == nullptr || rows_host == nullptr) return fail(BPR_ERR_INVALID, "bpr_hot_rows: NULL argument");
+  *rows_host = c->hot_H;
+  return BPR_OK;
+}
+
+int bpr_hot_tier_begin(bpr_ctx* c, float* hot_base) {
+  if (int rc = check_bound(c, "bpr_hot_tier_begin")) return rc;
+  if (c->hot_H <= 0 || !c->hot_explicit)
+    return fail(BPR_ERR_INVALID, "bpr_hot_tier_begin: no hot set (bpr_set_hot_items first: the ranks "
+                                 "must agree on it)");
+  if (hot_base == nullptr) return fail(BPR_ERR_INVALID, "bpr_hot_tier_begin: hot_base is NULL");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  const int64_t n = (int64_t)c->hot_H * c->d;
+  hipLaunchKernelGGL(k_hot_gather, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256),
+                     0, c->stream, c->Q, c->hot_items, c->hot_canon, hot_base, c->hot_H, c->d);
+  BPR_HIP_CHECK(hipGetLastError());
+  c->hot_tier = true;
+  return BPR_OK;
+}
+
+int bpr_hot_tier_end(bpr_ctx* c) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_hot_tier_end: ctx is NULL");
+  c->hot_tier = false;  // (the caller has folded everything: bpr_hot_exchange with cut = 1 last)
+  return BPR_OK;
+}
+
+int bpr_hot_exchange(bpr_ctx* c, float* hot_base, float* tot, int32_t fold_prev, int32_t cut,
+                     float* cold_base) {
+  if (int rc = check_bound(c, "bpr_hot_exchange")) return rc;
+  if (!c->hot_tier) return fail(BPR_ERR_INVALID, "bpr_hot_exchange: the hot tier is off (bpr_hot_tier_begin)");
+  if (hot_base == nullptr || tot == nullptr)
+    return fail(BPR_ERR_INVALID, "bpr_hot_exchange: NULL buffer");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  c->keys_cut = false;  // the item table moves
+  HotStepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = c->Q; a.delta = c->hot_delta; a.hot_items = c->hot_items; a.canon = c->hot_canon;
+  a.hb = hot_base; a.tot = tot; a.cold_base = cold_base;
+  a.H = c->hot_H; a.R = c->hot_R; a.d = c->d; a.fold_prev = fold_prev != 0; a.cut = cut != 0;
+  const int64_t n = (int64_t)c->hot_H * c->d;
+  hipLaunchKernelGGL(k_hot_step, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0,
+                     c->stream, a);
+  BPR_HIP_CHECK(hipGetLastError());
   return BPR_OK;
 }
 

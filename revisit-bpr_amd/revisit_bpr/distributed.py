@@ -14,6 +14,20 @@ multi-device path to mirror (DDP launcher exists, no config enable
 
 ``ItemSync.sync()`` is blocking; ``start()`` / ``finish()`` split it so the all-reduce runs on a
 side stream under the next chunk's kernels.
+
+Two tiers (r4).  With a full refresh period per RANK and launch, N replicas each pour a whole
+launch into the same few popular rows before anybody sees the others' updates — at aggressive
+learning rates that diverges (profiles/r03_cadence_study.txt).  ``ItemSync(hot_rows=H, engine=...)``
+therefore reconciles the H most popular rows of the WHOLE training set on their own: their updates
+already live in the engine's hot delta block (a launch's ``hot_delta``), and ``hot_step()`` — after
+every launch or sub-launch — all-reduces that block (H·d floats: 128 KB at H = 256, d = 128) and
+folds the sum one launch later, while the cold rows keep the per-period delta all-reduce above
+(``step()``).  ``bpr_hot_exchange`` (include/bprcore.h) is the fused pass.
+
+The collective is pluggable: ``torch.distributed`` (RCCL / gloo), or ``LocalWorld`` — N ranks in ONE
+process on one GPU, stepped round-robin, whose "all-reduce" is resolved when the last rank has
+contributed: the same data flow as N processes (the protocol only ever reads a sum one step after
+it was launched), without N processes.  tools/cadence_study.py runs its sweeps on it.
 """
 from __future__ import annotations
 
@@ -51,34 +65,15 @@ class _null:
         return False
 
 
-class ItemSync:
-    """Keeps the replicated tensors (item table, optional item bias) consistent across ranks.
+class _DistComm:
+    """torch.distributed: the all-reduce is enqueued on a side stream, `complete` makes the current
+    stream wait for it."""
 
-    On a ROCm device the two elementwise passes around the all-reduce are the fused kernels
-    ``bpr_item_delta`` / ``bpr_item_fold`` of libbprcore (one pass over the table each, buffers
-    allocated once); on CPU tensors (gloo tests) the same algebra runs as torch ops."""
-
-    def __init__(self, tensors: list[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
-                 scale: float = 1.0) -> None:
-        self.tensors = [t.detach() for t in tensors if t is not None]
+    def __init__(self, group=None, cuda: bool = False) -> None:
         self.group = group
-        self.scale = scale  # 1.0: apply every rank's update; 1/world: DDP-style mean
-        self.base = [t.clone() for t in self.tensors]
-        self._own = [torch.empty_like(t) for t in self.tensors]
-        self._tot = [torch.empty_like(t) for t in self.tensors]
-        self._pending = False
-        self.timing = False  # record the all-reduce on the side stream with events (bench.py)
-        self._events: list = []
-        self._cuda = bool(self.tensors) and self.tensors[0].is_cuda
-        self._side = torch.cuda.Stream() if self._cuda else None
-        self._lib = None
-        if self._cuda:
-            from revisit_bpr import native
-
-            self._lib, self._check = native.load(), native.check
-            for t in self.tensors:
-                if t.dtype != torch.float32 or not t.is_contiguous():
-                    raise ValueError("ItemSync needs contiguous float32 tensors")
+        self._side = torch.cuda.Stream() if cuda else None
+        self.timing = False
+        self.events: list = []
 
     @property
     def world(self) -> int:
@@ -88,6 +83,176 @@ class ItemSync:
     def rank(self) -> int:
         return dist.get_rank(self.group) if dist.is_initialized() else 0
 
+    def launch(self, tensors, tag=None) -> None:
+        if self.world <= 1:
+            return
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                for t in tensors:
+                    self._one(t, tag)
+        else:
+            for t in tensors:
+                self._one(t, tag)
+
+    def _one(self, t, tag) -> None:
+        if self.timing and self._side is not None:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            b.record()
+            self.events.append((a, b, t.numel() * t.element_size(), tag))
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def complete(self, tensors, tag=None) -> None:
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
+    def all_reduce_now(self, t, op=dist.ReduceOp.SUM) -> None:
+        if self.world > 1:
+            dist.all_reduce(t, op=op, group=self.group)
+
+
+class LocalWorld:
+    """N ranks in one process.  `member(r)` is rank r's collective backend: `launch` registers the
+    rank's buffers under a running sequence number, `complete` — called one protocol step later, when
+    every rank has launched — replaces them by the element-wise sum over the ranks.  Ranks must be
+    stepped round-robin (all ranks finish step k before any starts step k + 2)."""
+
+    def __init__(self, world: int) -> None:
+        self.world = int(world)
+        self._pending: dict = {}   # (tag, seq) -> {rank: [tensors]}
+        self._sums: dict = {}      # (tag, seq) -> [summed tensors], readers left
+
+    def member(self, rank: int) -> "_LocalComm":
+        return _LocalComm(self, rank)
+
+    def _launch(self, rank, key, tensors) -> None:
+        self._pending.setdefault(key, {})[rank] = list(tensors)
+
+    def _complete(self, rank, key, tensors) -> None:
+        if key not in self._sums:
+            parts = self._pending.pop(key, {})
+            if len(parts) != self.world:
+                raise RuntimeError(f"LocalWorld: exchange {key} read by rank {rank} before ranks "
+                                   f"{sorted(set(range(self.world)) - set(parts))} contributed "
+                                   "(ranks must be stepped round-robin)")
+            # the sum in rank order, the same on every reader (RCCL's ring order is its own)
+            tot = [torch.stack([parts[r][k] for r in range(self.world)]).sum(0)
+                   for k in range(len(tensors))]
+            self._sums[key] = [tot, self.world]
+        tot, left = self._sums[key]
+        for t, v in zip(tensors, tot):
+            t.copy_(v)
+        if left <= 1:
+            del self._sums[key]
+        else:
+            self._sums[key][1] = left - 1
+
+
+class _LocalComm:
+    timing = False
+
+    def __init__(self, world: LocalWorld, rank: int) -> None:
+        self._w, self.rank, self.world = world, rank, world.world
+        self._seq: dict = {}
+        self._open: dict = {}
+
+    def launch(self, tensors, tag=None) -> None:
+        seq = self._seq.get(tag, 0)
+        self._seq[tag] = seq + 1
+        self._open[tag] = seq
+        self._w._launch(self.rank, (tag, seq), tensors)
+
+    def complete(self, tensors, tag=None) -> None:
+        self._w._complete(self.rank, (tag, self._open.pop(tag)), tensors)
+
+    def all_reduce_now(self, t, op=None) -> None:
+        raise RuntimeError("LocalWorld has no blocking collectives: pass `rounds` / `item_counts` "
+                           "computed over all ranks to the trainers instead")
+
+
+class ItemSync:
+    """Keeps the replicated tensors (item table, optional item bias) consistent across ranks.
+
+    On a ROCm device the two elementwise passes around the all-reduce are the fused kernels
+    ``bpr_item_delta`` / ``bpr_item_fold`` of libbprcore (one pass over the table each, buffers
+    allocated once); on CPU tensors (gloo tests) the same algebra runs as torch ops.
+
+    hot_rows > 0 (needs `engine`, whose item table must be tensors[0]): the hot tier — see the
+    module docstring.  `item_counts` [I]: training positives per item over ALL ranks (the hot set
+    must be the same everywhere); None = this rank's `local_items` are counted and all-reduced."""
+
+    def __init__(self, tensors: list[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
+                 scale: float = 1.0, comm=None, engine=None, hot_rows: int = 0,
+                 item_counts: Optional[torch.Tensor] = None,
+                 local_items: Optional[torch.Tensor] = None) -> None:
+        self.tensors = [t.detach() for t in tensors if t is not None]
+        self.group = group
+        self.scale = scale  # 1.0: apply every rank's update; 1/world: DDP-style mean
+        self.base = [t.clone() for t in self.tensors]
+        self._own = [torch.empty_like(t) for t in self.tensors]
+        self._tot = [torch.empty_like(t) for t in self.tensors]
+        self._pending = False
+        self._cuda = bool(self.tensors) and self.tensors[0].is_cuda
+        self.comm = comm if comm is not None else _DistComm(group, self._cuda)
+        self._lib = None
+        if self._cuda:
+            from revisit_bpr import native
+
+            self._lib, self._check = native.load(), native.check
+            for t in self.tensors:
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise ValueError("ItemSync needs contiguous float32 tensors")
+        # ---- hot tier
+        self.engine = engine
+        self.hot_tier = False
+        self._hot_pending = False
+        if hot_rows > 0 and self.world > 1:
+            self._setup_hot(int(hot_rows), item_counts, local_items)
+
+    def _setup_hot(self, H: int, item_counts, local_items) -> None:
+        e = self.engine
+        if e is None or not self._cuda or e.Q.data_ptr() != self.tensors[0].data_ptr():
+            raise ValueError("the hot tier needs the engine whose item table is tensors[0]")
+        I = e.I
+        if item_counts is None:
+            if local_items is None:
+                raise ValueError("hot tier: pass item_counts (all ranks) or this rank's local_items")
+            item_counts = torch.bincount(local_items.long().reshape(-1), minlength=I).to(torch.int64)
+            self.comm.all_reduce_now(item_counts)
+        cnt = item_counts.detach().to("cpu", torch.int64).clone()
+        cnt[0] = 0
+        H = min(H, int((cnt > 0).sum()))
+        if H <= 0:
+            return
+        # the H most popular rows, ties by ascending id — the same list on every rank
+        order = torch.argsort(cnt * (I + 1) + (I - torch.arange(I)), descending=True)[:H]
+        e.set_hot_items(order.to(torch.int32), cnt.clamp(max=2**32 - 1))
+        d = e.d
+        self._hb = torch.empty(H, d, dtype=torch.float32, device=e.device)
+        self._htot = torch.zeros(H, d, dtype=torch.float32, device=e.device)
+        e.hot_tier_begin(self._hb)
+        self.hot_tier = True
+        self.hot_items = order
+
+    @property
+    def timing(self) -> bool:
+        return self.comm.timing
+
+    @timing.setter
+    def timing(self, on: bool) -> None:
+        self.comm.timing = bool(on)
+
+    @property
+    def world(self) -> int:
+        return self.comm.world
+
+    @property
+    def rank(self) -> int:
+        return self.comm.rank
+
     def max_over_ranks(self, value: int) -> int:
         """MAX of a host integer over the group (e.g. chunks per epoch: ranks whose shard holds
         fewer chunks must still take part in every reconciliation, or the collectives of different
@@ -96,7 +261,7 @@ class ItemSync:
             return int(value)
         dev = self.tensors[0].device if self.tensors else torch.device("cpu")
         t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self.comm.all_reduce_now(t, op=dist.ReduceOp.MAX)
         return int(t.item())
 
     # ---- the two elementwise passes ---------------------------------------------------------
@@ -122,26 +287,54 @@ class ItemSync:
             else:
                 t.add_(st - own)
 
-    def _all_reduce(self, tot) -> None:
-        if self.world > 1:
-            if self.timing and self._cuda:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
-                b.record()
-                self._events.append((a, b, tot.numel() * tot.element_size()))
-            else:
-                dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
-
     def timing_read(self) -> dict:
-        """Average duration of the recorded all-reduces (ms, on the stream they ran on) and their
-        message size; clears the record."""
+        """Average duration of the recorded all-reduces (ms, on the stream they ran on) per tier and
+        their message sizes; clears the record."""
         torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b, _ in self._events]
-        size = self._events[0][2] if self._events else 0
-        self._events = []
-        return {"all_reduces": len(ms), "all_reduce_ms_avg": (sum(ms) / len(ms)) if ms else None,
-                "message_bytes": size}
+        ev = getattr(self.comm, "events", [])
+        out = {}
+        for tag in ("cold", "hot"):
+            ms = [a.elapsed_time(b) for a, b, _, tg in ev if tg == tag]
+            size = next((n for _, _, n, tg in ev if tg == tag), 0)
+            out[tag] = {"all_reduces": len(ms), "all_reduce_ms_avg": (sum(ms) / len(ms)) if ms else None,
+                        "message_bytes": size}
+        if hasattr(self.comm, "events"):
+            self.comm.events = []
+        res = dict(out["cold"])
+        res["hot"] = out["hot"]
+        return res
+
+    # ---- hot tier -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def hot_step(self) -> None:
+        """After every STREAM launch (or sub-launch) of the engine: fold the all-reduced hot block of
+        the previous exchange, cut this launch's hot deltas and send them off.  Every rank calls it
+        the same number of times (a rank whose launch was empty contributes zeros)."""
+        if not self.hot_tier:
+            return
+        if self._hot_pending:
+            self.comm.complete([self._htot], "hot")
+        self.engine.hot_exchange(self._hb, self._htot, fold_prev=self._hot_pending, cut=True,
+                                 cold_base=self.base[0])
+        self.comm.launch([self._htot], "hot")
+        self._hot_pending = True
+
+    @torch.no_grad()
+    def hot_finish(self) -> None:
+        """Fold the hot exchange in flight (end of an epoch: the tables are read next)."""
+        if not self.hot_tier or not self._hot_pending:
+            return
+        self.comm.complete([self._htot], "hot")
+        self.engine.hot_exchange(self._hb, self._htot, fold_prev=True, cut=False,
+                                 cold_base=self.base[0])
+        self._hot_pending = False
+
+    def close(self) -> None:
+        """Leave the hot tier (launches fold their hot block themselves again)."""
+        if self.hot_tier:
+            self.hot_finish()
+            self.engine.hot_tier_end()
+            self.hot_tier = False
 
     # ---- API ----------------------------------------------------------------------------------
     @torch.no_grad()
@@ -154,19 +347,13 @@ class ItemSync:
     @torch.no_grad()
     def start(self) -> None:
         """Cut this rank's deltas on the compute stream (a consistent snapshot) and launch their
-        all-reduce on the side stream."""
+        all-reduce on the side stream.  (Hot tier: call right after `hot_step` — the hot rows' cold
+        base then equals their value and their cold delta is exactly zero.)"""
         if self._pending:
             self.finish()
         for t, b, own, tot in zip(self.tensors, self.base, self._own, self._tot):
             self._delta(t, b, own, tot)
-        if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._side):
-                for tot in self._tot:
-                    self._all_reduce(tot)
-        else:
-            for tot in self._tot:
-                self._all_reduce(tot)
+        self.comm.launch(self._tot, "cold")
         self._pending = True
 
     @torch.no_grad()
@@ -178,15 +365,12 @@ class ItemSync:
         if self._lib is None:
             self.finish()
             return self.start()
-        torch.cuda.current_stream().wait_stream(self._side)
+        self.comm.complete(self._tot, "cold")
         for t, b, own, tot in zip(self.tensors, self.base, self._own, self._tot):
             self._check(self._lib.bpr_item_fold_delta(t.data_ptr(), b.data_ptr(), own.data_ptr(),
                                                       tot.data_ptr(), self.scale, t.numel(),
                                                       torch.cuda.current_stream().cuda_stream))
-        self._side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._side):
-            for tot in self._tot:
-                self._all_reduce(tot)
+        self.comm.launch(self._tot, "cold")
 
     @torch.no_grad()
     def finish(self, rebase: bool = False) -> None:
@@ -196,7 +380,6 @@ class ItemSync:
         if not self._pending:
             return
         self._pending = False
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+        self.comm.complete(self._tot, "cold")
         for t, b, own, tot in zip(self.tensors, self.base, self._own, self._tot):
             self._fold(t, b, own, tot, rebase)

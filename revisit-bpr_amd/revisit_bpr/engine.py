@@ -478,6 +478,36 @@ class Engine:
         effect at the next plan_epoch."""
         native.check(self._lib.bpr_set_hot_rows(self._ctx, hot_rows, replicas))
 
+    # ---- two-tier reconciliation, hot tier (revisit_bpr.distributed.ItemSync drives it)
+    def set_hot_items(self, items: torch.Tensor, counts: Optional[torch.Tensor] = None) -> None:
+        """The hot set as given (the ranks of a job agree on it): `items` int32 ids in the canonical
+        order of the exchange buffers; `counts` [I] positives per item (steers the placement)."""
+        import numpy as np
+
+        it = np.ascontiguousarray(items.detach().cpu().numpy(), dtype=np.int32)
+        cn = None if counts is None else np.ascontiguousarray(counts.detach().cpu().numpy(), dtype=np.uint32)
+        native.check(self._lib.bpr_set_hot_items(
+            self._ctx, it.ctypes.data_as(ctypes.c_void_p), int(it.size),
+            None if cn is None else cn.ctypes.data_as(ctypes.c_void_p)))
+
+    def hot_rows(self) -> int:
+        v = ctypes.c_int32()
+        native.check(self._lib.bpr_hot_rows(self._ctx, ctypes.byref(v)))
+        return v.value
+
+    def hot_tier_begin(self, hot_base: torch.Tensor) -> None:
+        self._sync_stream()
+        native.check(self._lib.bpr_hot_tier_begin(self._ctx, hot_base.data_ptr()))
+
+    def hot_exchange(self, hot_base: torch.Tensor, tot: torch.Tensor, fold_prev: bool, cut: bool,
+                     cold_base: Optional[torch.Tensor] = None) -> None:
+        self._sync_stream()
+        native.check(self._lib.bpr_hot_exchange(self._ctx, hot_base.data_ptr(), tot.data_ptr(),
+                                                int(fold_prev), int(cut), _ptr(cold_base)))
+
+    def hot_tier_end(self) -> None:
+        native.check(self._lib.bpr_hot_tier_end(self._ctx))
+
     def plan_epoch(self, users: torch.Tensor, pos: torch.Tensor, chunk: int, seed: int,
                    out: Optional[tuple[torch.Tensor, torch.Tensor]] = None):
         """Shuffle the training triples into chunks of `chunk`, each grouped by user (on device)."""

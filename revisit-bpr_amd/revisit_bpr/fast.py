@@ -41,7 +41,8 @@ class StreamTrainer:
                  max_inflight: Optional[int] = None, run_len: int = 0, rank: int = 0,
                  item_sync=None, sync_every: int = 1, world: Optional[int] = None,
                  refresh_lag: float = 0.0, refresh_split: int = 1, refresh_cus: int = 0,
-                 shard_refresh: bool = False) -> None:
+                 shard_refresh: bool = False, cadence: str = "job", hot_split: int = 1,
+                 rounds: Optional[int] = None) -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
         adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302.
@@ -60,7 +61,17 @@ class StreamTrainer:
                             -1: chosen from the shape, `auto_refresh_cus`).
           shard_refresh     several ranks (item_sync): every rank sorts d / world factors and an
                             all-gather shares the orders (Engine.adaptive_refresh_sharded) instead
-                            of every rank sorting all of them; refresh_lag 0 only."""
+                            of every rank sorting all of them; refresh_lag 0 only.
+
+        Several ranks (item_sync), r4:
+          cadence           "job": a chunk is 1 / world of the refresh period, so the snapshot and the
+                            item reconciliation keep the single-GPU cadence counted in triples of
+                            the whole job (launches shrink with the number of ranks).
+                            "rank": every rank launches a FULL period; refresh and cold reconciliation
+                            once per rank-period, the hot rows (item_sync's hot tier) after every
+                            launch — what keeps full-size launches stable.
+          hot_split k       a chunk runs as k launches with a hot-tier exchange after each.
+          rounds            chunks per epoch over all ranks (None: a MAX all-reduce decides)."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
             raise ValueError("users / items must be int32 device tensors")
         if not 0.0 <= refresh_lag <= 1.0 or refresh_split < 1:
@@ -81,7 +92,12 @@ class StreamTrainer:
         # and the item reconciliation keep their single-GPU cadence
         if world is None:
             world = item_sync.world if item_sync is not None else 1
-        self.chunk = max(1, min(every * batch_size // (max(world, 1) * refresh_split), self.n))
+        if cadence not in ("job", "rank"):
+            raise ValueError("cadence must be 'job' or 'rank'")
+        self.cadence = cadence
+        per_period = max(world, 1) if cadence == "job" else 1
+        self.chunk = max(1, min(every * batch_size // (per_period * refresh_split), self.n))
+        self.hot_split = max(1, int(hot_split))
         U = self.engine.U
         # staleness budget: at most ~U/4 triples in flight against one parameter cut
         self.max_inflight = max(64, U // 4) if max_inflight is None else max_inflight
@@ -109,26 +125,42 @@ class StreamTrainer:
         # shards are balanced by interactions, not equal: every rank runs the same number of
         # rounds per epoch (a rank out of triples still joins the item reconciliations)
         self.rounds = -(-self.n // self.chunk)
-        if item_sync is not None:
+        if rounds is not None:
+            self.rounds = int(rounds)
+        elif item_sync is not None:
             self.rounds = item_sync.max_over_ranks(self.rounds)
 
-    def _launch(self, lo: int, hi: int, cut: bool = False) -> None:
-        self.engine.train_stream(self._pu[lo:hi], self._pi[lo:hi], sampler=self.sampler,
-                                 adaptive_p=self.adaptive_p, seed=self.seed,
-                                 offset=(self.rank << 40) + self.drawn,
-                                 max_inflight=self.max_inflight, scalars=self._scalars, cut=cut)
-        self.drawn += hi - lo
+    # The epoch is written as a generator that yields after every launch (+ hot-tier exchange) and
+    # after every chunk: `train_epoch` just runs it; a LocalWorld simulation (several ranks in one
+    # process, revisit_bpr.distributed) resumes the ranks' generators round-robin.
+    def _launch(self, lo: int, hi: int, cut: bool = False):
+        hot = self.item_sync is not None and self.item_sync.hot_tier
+        k = self.hot_split if hot else 1
+        for p in range(k):  # every rank runs k pieces, empty ones included: the exchanges line up
+            a, b = lo + (hi - lo) * p // k, lo + (hi - lo) * (p + 1) // k
+            if b > a:
+                self.engine.train_stream(self._pu[a:b], self._pi[a:b], sampler=self.sampler,
+                                         adaptive_p=self.adaptive_p, seed=self.seed,
+                                         offset=(self.rank << 40) + self.drawn,
+                                         max_inflight=self.max_inflight, scalars=self._scalars,
+                                         cut=cut and p == k - 1)
+                self.drawn += b - a
+            if hot:
+                self.item_sync.hot_step()
+            yield
 
-    def _chunk(self, lo: int, hi: int) -> None:
+    def _chunk(self, lo: int, hi: int):
         e, lag = self.engine, self.refresh_lag
         if self.sampler != eng.NEG_ADAPTIVE:
-            return self._launch(lo, hi)
+            yield from self._launch(lo, hi)
+            return
         if lag == 0.0:
             if self.shard_refresh:
                 e.adaptive_refresh_sharded(self.item_sync.rank, self.item_sync.world, self.item_sync.group)
             else:
                 e.adaptive_refresh()
-            return self._launch(lo, hi)
+            yield from self._launch(lo, hi)
+            return
         # with one launch per snapshot (lag 1) and nothing touching the item table between two
         # launches (no item reconciliation) the keys of the NEXT snapshot are cut by the epilogue
         # of this launch: `begin` then only queues the sort
@@ -139,47 +171,68 @@ class StreamTrainer:
             e.adaptive_refresh()         # first launch: nothing in flight yet
         cut = lo if lag >= 1.0 else min(hi, lo + max(1, int(round((1.0 - lag) * (hi - lo)))))
         if cut > lo:
-            self._launch(lo, cut)
+            yield from self._launch(lo, cut)
         e.adaptive_refresh_begin()
         if cut < hi:
-            self._launch(cut, hi, cut=fused)
+            yield from self._launch(cut, hi, cut=fused)
+
+    def stream_scope(self):
+        """Context in which this trainer's calls must run: its CU-masked launch stream, if any."""
+        import contextlib
+
+        return torch.cuda.stream(self._main.torch) if self._main is not None else contextlib.nullcontext()
 
     def train_epoch(self) -> dict:
-        if self._main is not None:  # the whole epoch on the CU-masked stream
-            cur = torch.cuda.current_stream(self.users.device)
-            self._main.torch.wait_stream(cur)
-            with torch.cuda.stream(self._main.torch):
-                out = self._train_epoch()
-            cur.wait_stream(self._main.torch)
-            return out
-        return self._train_epoch()
+        self.epoch_begin()
+        with self.stream_scope():  # the whole epoch on the CU-masked stream
+            for _ in self.epoch_iter():
+                pass
+        return self.epoch_end()
 
-    def _train_epoch(self) -> dict:
+    def epoch_begin(self) -> None:
+        if self._main is not None:
+            self._main.torch.wait_stream(torch.cuda.current_stream(self.users.device))
+
+    def epoch_end(self) -> dict:
+        if self._main is not None:
+            torch.cuda.current_stream(self.users.device).wait_stream(self._main.torch)
+        sc = self._scalars.tolist()
+        cnt = max(sc[3], 1.0)
+        return {"bpr_loss": sc[0] / cnt, "l2_reg": sc[1] / cnt, "logits_diff": sc[2] / cnt,
+                "loss": (sc[0] + sc[1]) / cnt, "triples": int(sc[3])}
+
+    def epoch_iter(self):
+        """One epoch as a generator (see `_launch`); resume it inside `stream_scope()`."""
         e = self.engine
         self.model._reset_reg()
         e.plan_epoch(self.users, self.items, self.chunk, self.seed + self.epoch,
                      out=(self._pu, self._pi))
         self._scalars.zero_()
+        hot = self.item_sync is not None and self.item_sync.hot_tier
         for k in range(self.rounds):
             lo = k * self.chunk
             hi = min(lo + self.chunk, self.n)
             if lo < hi:
-                self._chunk(lo, hi)
-            elif self.shard_refresh and self.sampler == eng.NEG_ADAPTIVE:
+                yield from self._chunk(lo, hi)
+            else:
                 # a rank that ran out of triples (shards are balanced by interactions, not equal)
-                # still owes the others its share of the sort and the all-gather of this round:
-                # every collective of a round is entered by every rank, in the same order
-                e.adaptive_refresh_sharded(self.item_sync.rank, self.item_sync.world,
-                                           self.item_sync.group)
+                # still owes the others every collective of the round, in the same order: its share
+                # of a sharded sort + all-gather, and (hot tier) one exchange per launch
+                if self.shard_refresh and self.sampler == eng.NEG_ADAPTIVE:
+                    e.adaptive_refresh_sharded(self.item_sync.rank, self.item_sync.world,
+                                               self.item_sync.group)
+                launches = 2 if 0.0 < self.refresh_lag < 1.0 else 1
+                for _ in range(launches * (self.hot_split if hot else 1)):
+                    if hot:
+                        self.item_sync.hot_step()
+                    yield
             if self.item_sync is not None and (k + 1) % self.sync_every == 0:
                 self.item_sync.step()
+            yield
         if self.item_sync is not None:
+            self.item_sync.hot_finish()
             self.item_sync.finish()
         self.epoch += 1
-        sc = self._scalars.tolist()
-        cnt = max(sc[3], 1.0)
-        return {"bpr_loss": sc[0] / cnt, "l2_reg": sc[1] / cnt, "logits_diff": sc[2] / cnt,
-                "loss": (sc[0] + sc[1]) / cnt, "triples": int(sc[3])}
 
 
 class StrictTrainer:

@@ -71,6 +71,9 @@ SIGNATURES = {
     "bpr_comm_destroy": (c_int, [c_void_p]),
     "bpr_item_sync": (c_int, [c_void_p]),
     "bpr_item_sync_finish": (c_int, [c_void_p]),
+    "bpr_item_sync_rebase": (c_int, [c_void_p]),
+    "bpr_comm_hot_tier": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "bpr_hot_sync": (c_int, [c_void_p]),
     "bpr_set_side_stream": (c_int, [c_void_p, c_void_p]),
     "bpr_stream_create": (c_int, [c_int, c_void_p, c_int32, POINTER(c_void_p)]),
     "bpr_stream_destroy": (c_int, [c_void_p]),
@@ -105,6 +108,11 @@ SIGNATURES = {
     "bpr_item_fold_delta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64,
                                     c_void_p]),
     "bpr_set_hot_rows": (c_int, [c_void_p, c_int32, c_int32]),
+    "bpr_set_hot_items": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "bpr_hot_rows": (c_int, [c_void_p, c_void_p]),
+    "bpr_hot_tier_begin": (c_int, [c_void_p, c_void_p]),
+    "bpr_hot_exchange": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "bpr_hot_tier_end": (c_int, [c_void_p]),
     "bpr_plan_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_void_p,
                                c_void_p]),
     "bpr_flush_lazy": (c_int, [c_void_p]),
