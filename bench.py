@@ -52,6 +52,29 @@ SCHEDULE = {"refresh_lag": 1.0, "refresh_split": 1, "refresh_cus": -1}  # -1: fa
 SCHEDULE_MULTI = {"refresh_lag": 0.0, "refresh_split": 1, "refresh_cus": 0}
 
 
+# Parity of the schedule the default line times (STREAM, snapshot one launch older: lag 1, sort on 64
+# masked CUs), as measured — not asserted — by the committed many-seed runs; the gates are in
+# tests/test_gpu_e2e_parity.py / test_gpu_fullscale_parity.py.  diff = ours - reference, seed means.
+PARITY_OF_TIMED_SCHEDULE = {
+    "tolerance_north_star": 0.002,
+    "small_set_vs_reference_over_epoch_orders": {
+        "source": "profiles/e2e_parity_r04.txt (4,000 x 1,500 golden protocol, d=32, lr 0.05, 12 epochs)",
+        "note": "filled from the r4 run of tools/e2e_many_seeds.py; r3: plateau +0.0013 nDCG@100 / "
+                "+0.0009 Recall@20, epoch 4 +0.0036 / +0.0038 (the older snapshot learns the steep part "
+                "faster on this small set)"},
+    "small_set_vs_reference_fixed_order": {
+        "source": "profiles/r03_e2e_many_seeds.txt (n = 200 ours, 30 reference runs)",
+        "ndcg@100": {"epoch2": [0.0041, 17.3], "epoch4": [0.0032, 6.3], "epoch12": [0.0018, 3.8]},
+        "recall@20": {"epoch2": [0.0038, 15.4], "epoch4": [0.0032, 4.3], "epoch12": [0.0024, 3.9]},
+        "format": "[diff, z]"},
+    "ml20m_shape_vs_exact_minibatches": {
+        "source": "profiles/r03_fullscale_many_seeds.txt (136,677 x 20,108, d=128, lr 0.05, 6 epochs, 30 seeds "
+                  "per side, against STRICT = the reference's mini-batch semantics)",
+        "ndcg@100": {"epoch3": 0.0010, "epoch6": 0.0002}, "recall@20": {"epoch3": 0.0005, "epoch6": 0.0006},
+        "se": 0.0004},
+}
+
+
 def cut_user_pieces(users, L, grouped):
     """Number of atomic user-row adds of one STREAM launch over `users` (device int32, grouped by
     user): k_stream cuts a user wherever a run boundary (a multiple of L) falls inside its triples;
@@ -88,13 +111,18 @@ def parse_args():
     ap.add_argument("--batch-size", type=int, default=256,
                     help="reference batch size; only sets the refresh period I·ln(I)/B batches")
     ap.add_argument("--sync-every", type=int, default=1, help="item all-reduce period in steps (N>1)")
-    ap.add_argument("--cadence", choices=["job", "rank"], default="job",
-                    help="N>1: 'job' = every rank advances refresh period / N triples per step, so the "
-                         "snapshot refresh and the item reconciliation happen every I ln I triples of the "
-                         "WHOLE job (the cadence the multi-rank parity runs validate: "
-                         "tests/test_gpu_multirank_parity.py, DESIGN.md §7); 'rank' = a full period per "
-                         "rank and step (measured unsafe: at the full ML-20M shape 4 ranks DIVERGE at lr 0.05, "
-                         "profiles/r03_cadence_study.txt)")
+    ap.add_argument("--cadence", choices=["job", "rank"], default="rank",
+                    help="N>1: 'rank' (default, r4) = every rank launches a FULL refresh period per step; the "
+                         "snapshot refresh and the cold rows' reconciliation happen once per rank-period, the "
+                         "--tier-rows most popular rows are exchanged after every launch (two-tier "
+                         "reconciliation, DESIGN.md §7; profiles/r04_cadence_study.txt holds the parity runs); "
+                         "'job' = every rank advances refresh period / N triples per step, so refresh and "
+                         "reconciliation keep the single-GPU cadence counted in triples of the whole job "
+                         "(launches shrink with N: r3's default)")
+    ap.add_argument("--tier-rows", type=int, default=1024,
+                    help="N>1, --cadence rank: rows of the hot tier (0 = one tier: r3's protocol)")
+    ap.add_argument("--hot-split", type=int, default=1,
+                    help="N>1, hot tier: launches per step, with a hot-tier exchange after each")
     ap.add_argument("--no-shard-refresh", action="store_true",
                     help="N>1, --refresh-lag 0: every rank sorts ALL factors of the snapshot instead of d/N of "
                          "them + an all-gather (Engine.adaptive_refresh_sharded, the default)")
@@ -122,6 +150,9 @@ def parse_args():
     ap.add_argument("--item-skew", type=float, default=None,
                     help="override the item popularity exponent (debug: 0 = uniform popularity)")
     ap.add_argument("--ungrouped", action="store_true", help="all-atomic user rows (debug)")
+    ap.add_argument("--sustained-epochs", type=int, default=3,
+                    help="after the timed region: this many WHOLE epochs (plan + every step) timed by wall "
+                         "clock, reported as `sustained` (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=13)
@@ -311,7 +342,7 @@ def main():
     sampler = {"adaptive": eng.NEG_ADAPTIVE, "uniform": eng.NEG_UNIFORM, "given": eng.NEG_GIVEN}[args.sampler]
 
     # snapshot schedule of the adaptive sampler
-    sched = SCHEDULE if world == 1 else SCHEDULE_MULTI
+    sched = SCHEDULE if world == 1 or args.cadence == "rank" else SCHEDULE_MULTI
     lag = sched["refresh_lag"] if args.refresh_lag is None else args.refresh_lag
     split = sched["refresh_split"] if args.refresh_split is None else args.refresh_split
     cus = sched["refresh_cus"] if args.refresh_cus is None else args.refresh_cus
@@ -343,7 +374,11 @@ def main():
     if main_stream is None and args.main_cus > 0:
         total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         main_stream = eng.MaskedStream(dev, eng.cu_mask(total_cus - args.main_cus, args.main_cus, total_cus))
-    sync = ItemSync([Q]) if world > 1 else None
+    sync = None
+    if world > 1:
+        tier = args.tier_rows if (args.cadence == "rank" and not batched) else 0
+        sync = ItemSync([Q], engine=e, hot_rows=tier, local_items=src_items)
+    pieces = args.hot_split if (sync is not None and sync.hot_tier) else 1
     scalars = torch.zeros(4, device=dev)
     seed = args.seed
     given_neg = (torch.randint(1, I, (chunk,), device=dev, dtype=torch.int32)
@@ -358,11 +393,16 @@ def main():
                                    seed=seed, offset=(rank << 40) + k * chunk + (lo - base),
                                    max_inflight=args.max_inflight, scalars=scalars)
         else:
-            e.train_stream(users[lo:hi], items[lo:hi], sampler=sampler,
-                           neg=None if given_neg is None else given_neg[:hi - lo],
-                           adaptive_p=args.adaptive_p, seed=seed,
-                           offset=(rank << 40) + k * chunk + (lo - base),
-                           max_inflight=args.max_inflight, scalars=scalars, cut=cut)
+            for p in range(pieces):  # hot tier: an exchange of the hot block after every launch
+                a, b = lo + (hi - lo) * p // pieces, lo + (hi - lo) * (p + 1) // pieces
+                e.train_stream(users[a:b], items[a:b], sampler=sampler,
+                               neg=None if given_neg is None else given_neg[:b - a],
+                               adaptive_p=args.adaptive_p, seed=seed,
+                               offset=(rank << 40) + k * chunk + (a - base),
+                               max_inflight=args.max_inflight, scalars=scalars,
+                               cut=cut and p == pieces - 1)
+                if sync is not None and sync.hot_tier:
+                    sync.hot_step()
 
     def step(k: int):
         c = k % n_chunks
@@ -420,17 +460,33 @@ def main():
         e.timing_enable(max(1, args.time_every))
         if sync is not None:
             sync.timing = True
-            sync._events = []
         scalars.zero_()
         t0 = time.perf_counter()
         first = k0 + args.warmup + 1
         for k in range(first, first + args.steps):
             step(k)
         if sync is not None:
+            sync.hot_finish()
             sync.finish()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         barrier()
+        # SUSTAINED: whole epochs in place — every epoch's bpr_plan_epoch where it belongs, nothing
+        # modelled — wall clock over `sus_epochs` x n_chunks steps (the driver's 20-step
+        # region is 5 ms and holds no plan)
+        sus_epochs = 0 if args.sustained_epochs <= 0 else args.sustained_epochs
+        sus_dt = 0.0
+        if sus_epochs > 0:
+            k_s = ((first + args.steps) // n_chunks + 1) * n_chunks  # the next epoch boundary
+            ts = time.perf_counter()
+            for k in range(k_s, k_s + sus_epochs * n_chunks):
+                step(k)
+            if sync is not None:
+                sync.hot_finish()
+                sync.finish()
+            torch.cuda.synchronize()
+            sus_dt = time.perf_counter() - ts
+            barrier()
         # the epoch plan, timed on its own (3 calls; it does not touch the model)
         tp = time.perf_counter()
         for r in range(3):
@@ -446,23 +502,24 @@ def main():
     kernel_ms, launches = e.timing_read()
     e.timing_enable(False)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, sus_dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, sus_dt = float(t[0].item()), float(t[1].item())
     sc = scalars.cpu().numpy()
     if batched:
         e.flush_lazy()
     q_after = Q.double().sum().item(), Q.abs().double().sum().item()
     # a kernel that did nothing cannot produce a number: every triple of the timed region was
     # counted by the kernel itself, the loss it accumulated is a real -log sigma, the tables moved
-    assert int(round(float(sc[3]))) == args.steps * chunk, (sc[3], args.steps * chunk)
+    counted = (args.steps + sus_epochs * n_chunks) * chunk
+    assert int(round(float(sc[3]))) == counted, (sc[3], counted)
     assert 0.0 < float(sc[0] / sc[3]) < 5.0 and q_after != q_before and torch.isfinite(Q).all()
     # line-atomics per triple of the chunk planned last (what the L2 atomic units see): 2 item rows
     # of d*4/128 lines each + one row per piece of every user a run boundary cuts (k_stream's rule)
     lines_per_row = max(1, (d * 4) // 128)
     user_atomic_rows = 0.0
     if not batched:
-        L = args.run_len if args.run_len > 0 else (8 if chunk >= 8 * 12288 else 4)
+        L = e.stream_run_len()  # what the library's last launch used (it picks it from the occupancy)
         user_atomic_rows = cut_user_pieces(users[:chunk], L, not args.ungrouped) / chunk
 
     opt_desc = {"sgd": f"SGD lr={args.lr}", "momentum": f"SGD(momentum 0.9) lr={args.lr}",
@@ -512,9 +569,12 @@ def main():
                 "triples_per_step_per_gpu": chunk,
                 "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus,
                                      "sharded_over_ranks": bool(shard_refresh and not batched)},
-                "cadence": (f"{args.cadence}: one snapshot refresh + item reconciliation per "
-                            f"{chunk * world if args.cadence == 'job' else chunk} triples of the "
-                            f"{'whole job' if args.cadence == 'job' else 'rank'}") if world > 1 else "single GPU",
+                "cadence": ((f"rank: every rank launches a full refresh period of {chunk} triples per step "
+                             f"({pieces} launch(es)); snapshot refresh + cold-row reconciliation once per "
+                             f"rank-period, hot tier of {sync._hb.shape[0] if sync.hot_tier else 0} rows "
+                             "exchanged after every launch") if args.cadence == "rank" else
+                            (f"job: one snapshot refresh + item reconciliation per {chunk * world} triples of "
+                             "the whole job")) if world > 1 else "single GPU",
                 "steps_per_epoch": n_chunks,
                 "plan_epoch": {"ms": plan_ms, "inside_timed_region": plans_timed,
                                "amortised_share_added_ms_per_step":
@@ -522,6 +582,7 @@ def main():
                                "ms_per_step_measured": dt_measured * 1e3 / args.steps},
                 "parallelism": f"user-sharded x{world}, item table replicated, async delta "
                                f"all-reduce every {args.sync_every} step(s)" if world > 1 else "single GPU",
+                "parity": PARITY_OF_TIMED_SCHEDULE if (world == 1 and lag >= 1.0 and not batched) else None,
                 "mean_bpr_loss": float(sc[0] / max(sc[3], 1.0)),
                 "triples_counted_by_kernel": int(round(float(sc[3]))),
                 "item_table_abs_sum_before_after": [q_before[1], q_after[1]],
@@ -533,6 +594,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                # the figure north_star quotes: bytes READ per triple only (3 rows + 2 ids)
+                "read_only_frac": ((12 * d + 8) * chunk / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                   if kernel_ms > 0 and args.optimizer == "sgd" else None),
                 "traffic": traffic,
                 "traffic_measured_in_this_run": False,
                 "traffic_source": (f"replayed from profiles/{tfile.stem.replace('traffic_', '')}_pmc_traffic.md "
@@ -544,6 +608,12 @@ def main():
                 "launches": launches,
             },
         }
+        if sus_epochs > 0:
+            out["sustained"] = {
+                "epochs": sus_epochs, "steps": sus_epochs * n_chunks,
+                "ms_per_step": sus_dt * 1e3 / (sus_epochs * n_chunks),
+                "value": sus_epochs * n_chunks * chunk * world / sus_dt,
+                "note": "whole epochs by wall clock, every bpr_plan_epoch in place (nothing modelled)"}
         if not batched and kernel_ms > 0:
             # what bounds k_stream is the L2 atomic units, not HBM: full-line fp32 atomic requests
             lpt = 2 * lines_per_row + user_atomic_rows * lines_per_row

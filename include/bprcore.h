@@ -133,7 +133,11 @@ int bpr_sample_uniform(bpr_ctx* ctx, const int32_t* users, int64_t B, uint64_t s
  * over items 1..I-1 (accept [I] fp32, alias [I] int32, entry 0 unused; the host shim builds it):
  * candidate = column c if frac(r (I-1) / 2^32) < accept[c] else alias[c]; seen candidates are
  * rejected as before.  NULL, NULL = uniform (the default).  Affects every uniform draw of the ctx
- * (bpr_sample_uniform, bpr_step, bpr_train_*). */
+ * (bpr_sample_uniform, bpr_step, bpr_train_*).
+ * Deviation: when 4,096 candidates in a row were all seen (a user who has seen nearly every item)
+ * the exact fallback picks by rank UNIFORMLY among the user's unseen items — it does not carry the
+ * weights, the reference's multinomial over the masked weights would (neg_samplers.py:31-37).  The
+ * oracle restates the same rule; the chance of reaching the fallback is (seen weight share)^4096. */
 int bpr_bind_item_weights(bpr_ctx* ctx, const float* accept, const int32_t* alias);
 
 /* AdaptiveSampler.update_stats (neg_samplers.py:126-132): snapshot the item table as per-factor
@@ -314,7 +318,8 @@ int bpr_shuffle_epoch(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_
  * group walks with the user row held in registers: 1..30, or 0 (default) = chosen per launch —
  * 8 when runs of 8 fill the launch stream's CUs more than once; for smaller launches the shortest
  * runs of 4..8 triples that fit those CUs in one residency, one run per group (a small launch
- * ends when its slowest group does).  bpr_stream_run_len: what the last STREAM launch used. */
+ * ends when its slowest group does; with max_inflight > 0 the bound is min(those CUs' capacity,
+ * max_inflight) groups).  bpr_stream_run_len: what the last STREAM launch used. */
 int bpr_set_stream_opts(bpr_ctx* ctx, int32_t grouped_by_user, int32_t run_len);
 int bpr_stream_run_len(bpr_ctx* ctx);
 
@@ -330,6 +335,11 @@ int bpr_stream_run_len(bpr_ctx* ctx);
  * as updating Q directly, up to the association of fp32 sums.  hot_rows = 0 turns it off.  Takes
  * effect at the next bpr_plan_epoch. */
 int bpr_set_hot_rows(bpr_ctx* ctx, int32_t hot_rows, int32_t replicas);
+/* Heavy users (more seen items than `threshold`, default 256; -1 = none) get an I-bit seen bitmap in
+ * HBM, built synchronously by the first sampling STREAM launch after the seen CSR was bound; the
+ * bitmaps take at most `max_bytes` (default 1 GiB; 0 keeps the current cap) — the threshold is
+ * doubled until they fit. */
+int bpr_set_heavy_users(bpr_ctx* ctx, int32_t threshold, int64_t max_bytes);
 
 /* ---- two-tier item reconciliation, HOT tier (several GPUs; no reference counterpart — the
  * reference's latent DDP, experiments/launcher.py:35-73, would all-reduce every gradient of every

@@ -115,6 +115,8 @@ struct bpr_ctx {
   uint32_t* heavy_off = nullptr;   // [U] word offset of the user's row in heavy_bits, ~0u = light
   uint32_t* heavy_bits = nullptr;  // [n_heavy, words]
   int heavy_T = 0;                 // users with more seen items than this are heavy
+  int heavy_T_opt = 256;           // bpr_set_heavy_users: requested threshold (-1: no table)
+  int64_t heavy_max_bytes = (int64_t)1 << 30;  // ... and the most HBM the bitmaps may take
   int64_t heavy_n = 0;
   const int64_t* heavy_for = nullptr;  // the indptr the table was built from (NULL = not built)
   void* comm = nullptr;  // bpr_comm.hip: the RCCL communicator and the reconciliation buffers (NULL: one GPU)

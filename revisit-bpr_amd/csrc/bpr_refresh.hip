@@ -676,7 +676,7 @@ int heavy_build_impl(bpr_ctx* c) {
   heavy_free(c);
   c->heavy_for = c->indptr;
   const char* te = getenv("BPR_HEAVY_T");  // measurements: -1 = no heavy table
-  int T = te ? atoi(te) : 256;
+  int T = te ? atoi(te) : c->heavy_T_opt;
   if (T < 0 || c->indptr == nullptr) return BPR_OK;
   const uint32_t words = (uint32_t)(((c->I + 31) / 32 + 3) / 4 * 4);
   uint32_t* counter = nullptr;
@@ -691,7 +691,10 @@ int heavy_build_impl(bpr_ctx* c) {
     BPR_HIP_CHECK(hipMemcpyAsync(&n_heavy, counter, sizeof(uint32_t), hipMemcpyDeviceToHost,
                                  c->stream));
     BPR_HIP_CHECK(hipStreamSynchronize(c->stream));  // one-time setup per seen CSR
-    if ((uint64_t)n_heavy * words < ((uint64_t)1 << 31)) break;
+    // the bitmaps must fit the cap (bpr_set_heavy_users; at most 2^31 words): raise the threshold
+    // until they do
+    const uint64_t cap_words = std::min<uint64_t>((uint64_t)1 << 31, (uint64_t)c->heavy_max_bytes / 4);
+    if ((uint64_t)n_heavy * words < cap_words) break;
     T *= 2;
   }
   hipFree(counter);
@@ -812,6 +815,13 @@ int refresh_alloc(bpr_ctx* c) {
 }
 
 int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
+  if (c->refresh_pending && !split && f_lo == 0 && f_hi == c->d) {
+    // a lagged schedule ends every epoch with a split refresh in flight (StreamTrainer(refresh_lag=1));
+    // whoever asks for a synchronous snapshot next — StrictTrainer, bpr_train_strict's refresh_every,
+    // a plain bpr_adaptive_refresh — gets it: the pending one is committed first (its sort is waited
+    // for, its buffers become the front pair) and the new snapshot then replaces it
+    if (int rc = refresh_commit_impl(c)) return rc;
+  }
   if (c->refresh_pending || c->part_pending) {
     set_error("bpr_adaptive_refresh: a split or sharded refresh is pending (bpr_adaptive_refresh_commit / "
               "_publish first)");

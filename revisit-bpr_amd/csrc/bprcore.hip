@@ -324,9 +324,12 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     // d=128 0.0550 -> 0.0413 ms; runs shorter than 4 re-load the user row too often).
     if (a.run_len <= 0) {
       a.run_len = 8;
-      if (cap_groups <= 0 && (a.n + 7) / 8 < resident) {
+      // (max_inflight > 0 — what StreamTrainer passes — only changes this when the cap binds: the
+      // residency bound is min(chip, cap))
+      const int64_t room = cap_groups > 0 ? std::min<int64_t>(resident, cap_groups) : resident;
+      if ((a.n + 7) / 8 < room) {
         a.run_len = 4;
-        while (a.run_len < 8 && (a.n + a.run_len - 1) / a.run_len > resident) ++a.run_len;
+        while (a.run_len < 8 && (a.n + a.run_len - 1) / a.run_len > room) ++a.run_len;
       }
     }
     c->last_run_len = a.run_len;
@@ -1133,6 +1136,16 @@ int bpr_hot_exchange(bpr_ctx* c, float* hot_base, float* tot, int32_t fold_prev,
   hipLaunchKernelGGL(k_hot_step, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0,
                      c->stream, a);
   BPR_HIP_CHECK(hipGetLastError());
+  return BPR_OK;
+}
+
+int bpr_set_heavy_users(bpr_ctx* c, int32_t threshold, int64_t max_bytes) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_heavy_users: ctx is NULL");
+  if (threshold < -1 || max_bytes < 0)
+    return fail(BPR_ERR_INVALID, "bpr_set_heavy_users: threshold >= -1, max_bytes >= 0");
+  c->heavy_T_opt = threshold;
+  if (max_bytes > 0) c->heavy_max_bytes = max_bytes;
+  c->heavy_for = nullptr;  // rebuilt by the next sampling STREAM launch
   return BPR_OK;
 }
 

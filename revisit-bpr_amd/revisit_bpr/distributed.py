@@ -128,8 +128,23 @@ class LocalWorld:
     def member(self, rank: int) -> "_LocalComm":
         return _LocalComm(self, rank)
 
+    # The ranks may work on different HIP streams (every trainer of the overlapped schedule has its
+    # own CU-masked pair): contributions and sums carry events, readers wait for them.
+    @staticmethod
+    def _mark(tensors):
+        if tensors and tensors[0].is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(tensors[0].device))
+            return ev
+        return None
+
+    @staticmethod
+    def _wait(ev, tensors) -> None:
+        if ev is not None:
+            torch.cuda.current_stream(tensors[0].device).wait_event(ev)
+
     def _launch(self, rank, key, tensors) -> None:
-        self._pending.setdefault(key, {})[rank] = list(tensors)
+        self._pending.setdefault(key, {})[rank] = (list(tensors), self._mark(tensors))
 
     def _complete(self, rank, key, tensors) -> None:
         if key not in self._sums:
@@ -138,13 +153,18 @@ class LocalWorld:
                 raise RuntimeError(f"LocalWorld: exchange {key} read by rank {rank} before ranks "
                                    f"{sorted(set(range(self.world)) - set(parts))} contributed "
                                    "(ranks must be stepped round-robin)")
+            for r in range(self.world):
+                self._wait(parts[r][1], tensors)
             # the sum in rank order, the same on every reader (RCCL's ring order is its own)
-            tot = [torch.stack([parts[r][k] for r in range(self.world)]).sum(0)
+            tot = [torch.stack([parts[r][0][k] for r in range(self.world)]).sum(0)
                    for k in range(len(tensors))]
-            self._sums[key] = [tot, self.world]
-        tot, left = self._sums[key]
+            self._sums[key] = [tot, self.world, self._mark(tot)]
+        tot, left, ev = self._sums[key]
+        self._wait(ev, tensors)
         for t, v in zip(tensors, tot):
             t.copy_(v)
+            if v.is_cuda:  # the sum lives until the last reader's copy has run, on whatever stream
+                v.record_stream(torch.cuda.current_stream(v.device))
         if left <= 1:
             del self._sums[key]
         else:

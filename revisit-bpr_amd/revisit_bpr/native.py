@@ -108,6 +108,7 @@ SIGNATURES = {
     "bpr_item_fold_delta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64,
                                     c_void_p]),
     "bpr_set_hot_rows": (c_int, [c_void_p, c_int32, c_int32]),
+    "bpr_set_heavy_users": (c_int, [c_void_p, c_int32, c_int64]),
     "bpr_set_hot_items": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
     "bpr_hot_rows": (c_int, [c_void_p, c_void_p]),
     "bpr_hot_tier_begin": (c_int, [c_void_p, c_void_p]),

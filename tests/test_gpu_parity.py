@@ -986,6 +986,35 @@ def test_split_refresh_snapshots_the_table_at_begin(I, d, masked):
     assert np.array_equal(e.adaptive_snapshot()[0].cpu().numpy(), oracle.adaptive_order(QT2))
 
 
+def test_synchronous_refresh_after_a_pending_split_refresh():
+    """A lagged schedule ends every epoch with a split refresh in flight: the next
+    synchronous bpr_adaptive_refresh — StrictTrainer, bpr_train_strict's refresh_every — commits it
+    implicitly and then snapshots the table as it is now; nothing is left pending."""
+    I, d = 5000, 64
+    rng = np.random.default_rng(5)
+    Q0 = rng.normal(0, 0.1, (I, d)).astype(np.float32)
+    Q0[0] = 0
+    e = make_engine(np.zeros((8, d), np.float32), Q0)
+    e.adaptive_refresh()
+    e.adaptive_refresh_begin()
+    assert e.refresh_pending()
+    Q1 = (Q0 * -2.0 + 0.01).astype(np.float32)
+    Q1[0] = 0
+    e.Q.copy_(torch.from_numpy(Q1).cuda())
+    e.adaptive_refresh()  # was: BPR_ERR_INVALID ("a split or sharded refresh is pending")
+    assert not e.refresh_pending()
+    QT, _ = oracle.adaptive_stats(Q1)
+    assert np.array_equal(e.adaptive_snapshot()[0].cpu().numpy(), oracle.adaptive_order(QT))
+    # bpr_train_strict with refresh_every on a ctx that a lagged trainer left behind
+    e.adaptive_refresh_begin()
+    P, Q, indptr, indices, users, pos, _ = rand_problem(8, I, d, 5, seed=3, B=64)
+    e.bind_seen_csr(dev(indptr), dev(indices))
+    e.set_optimizer(kind=0, lr=0.01)
+    e.train_strict(dev(users), dev(pos), 16, sampler=2, adaptive_p=0.1, seed=1, refresh_every=2)
+    assert not e.refresh_pending()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("I,d,parts", [(20109, 128, 2), (3001, 32, 4), (45000, 16, 2), (20109, 128, 8)])
 def test_sharded_refresh_parts_equal_the_full_sort(I, d, parts):
     """bpr_adaptive_refresh_part sorts a slice of the factors into the back snapshot; all slices
