@@ -228,6 +228,7 @@ class ItemSync:
         # ---- hot tier
         self.engine = engine
         self.hot_tier = False
+        self.top_share = self.cold_top_share = 0.0
         self._hot_pending = False
         if hot_rows > 0 and self.world > 1:
             self._setup_hot(int(hot_rows), item_counts, local_items)
@@ -244,6 +245,8 @@ class ItemSync:
             self.comm.all_reduce_now(item_counts)
         cnt = item_counts.detach().to("cpu", torch.int64).clone()
         cnt[0] = 0
+        # share of the job's triples that update the most / the first not-hot popular row
+        self.top_share = float(cnt.max()) / max(float(cnt.sum()), 1.0)
         H = min(H, int((cnt > 0).sum()))
         if H <= 0:
             return
@@ -256,6 +259,9 @@ class ItemSync:
         e.hot_tier_begin(self._hb)
         self.hot_tier = True
         self.hot_items = order
+        rest = cnt.clone()
+        rest[order] = 0
+        self.cold_top_share = float(rest.max()) / max(float(cnt.sum()), 1.0)
 
     @property
     def timing(self) -> bool:

@@ -299,6 +299,28 @@ class Engine:
         self._sync_stream()
         native.check(self._lib.bpr_item_sync_finish(self._ctx))
 
+    def item_sync_rebase(self) -> None:
+        """After the item table was overwritten in place (checkpoint restore): the reconciliation
+        bases are cut again from the tables as they are (identical on every rank)."""
+        self._sync_stream()
+        native.check(self._lib.bpr_item_sync_rebase(self._ctx))
+
+    def comm_hot_tier(self, items: torch.Tensor, counts: Optional[torch.Tensor] = None) -> None:
+        """Two tiers inside the library: the hot set (same list on every rank) whose delta block
+        `hot_sync` exchanges after every launch; `item_sync` stays the cold rows' per-period step."""
+        import numpy as np
+
+        self._sync_stream()
+        it = np.ascontiguousarray(items.detach().cpu().numpy(), dtype=np.int32)
+        cn = None if counts is None else np.ascontiguousarray(counts.detach().cpu().numpy(), dtype=np.uint32)
+        native.check(self._lib.bpr_comm_hot_tier(
+            self._ctx, it.ctypes.data_as(ctypes.c_void_p), int(it.size),
+            None if cn is None else cn.ctypes.data_as(ctypes.c_void_p)))
+
+    def hot_sync(self) -> None:
+        self._sync_stream()
+        native.check(self._lib.bpr_hot_sync(self._ctx))
+
     def comm_destroy(self) -> None:
         native.check(self._lib.bpr_comm_destroy(self._ctx))
 

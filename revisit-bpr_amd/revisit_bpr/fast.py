@@ -34,6 +34,31 @@ def auto_refresh_cus(I: int, d: int, launch_triples: int, total_cus: int = 256) 
     return int(min(max(32 * round(want / 32), 64), total_cus // 2))
 
 
+def auto_schedule(I: int, d: int, launch_triples: int, total_cus: int = 256) -> tuple[float, int]:
+    """(refresh_lag, refresh_cus) for a shape, from a two-line cost model calibrated on MI355X
+    (profiles/shapes_r03.txt, shapes_r04.txt): the reference's schedule costs launch + sort on the
+    whole chip; the overlapped one max(launch on the CUs it keeps, sort on the CUs it gets) — a sort
+    that is only partly hidden still pays, a side stream that is too small does not (MSD d=256 with
+    the sort on 64 CUs: 387 M triples/s against 393 M at lag 0; on 96 CUs the sort fits).  Returns
+    lag 0 when no CU split beats the serial schedule."""
+    per_triple = 0.72e-6 if d <= 32 else 0.8e-6 if d <= 64 else 1.1e-6 if d <= 128 else \
+        1.8e-6 if d <= 256 else 3.5e-6 * d / 512
+    launch_ms = max(launch_triples, 1) * per_triple
+    sort_ms_cu = 5.05e-6 * I * d * (1.3 if I > 36864 else 1.0)
+    serial = launch_ms + sort_ms_cu / total_cus + 0.040  # three kernels and their boundaries
+    best = (serial, 0.0, 0)
+    for cus in (64, 96, 128):
+        if cus > total_cus // 2:
+            break
+        # the launch on the remaining CUs: +6 % per 64 CUs while the atomic units bound it
+        # (d <= 128), more once HBM does (d >= 256: measured +3 % .. +5 % at 64)
+        stretch = 1.0 + (0.06 if d <= 128 else 0.05) * cus / 64 * (1.0 if d <= 128 else 1.5)
+        step = max(launch_ms * stretch, sort_ms_cu / cus) + 0.026  # cut + the launch-to-launch gap
+        if step < best[0]:
+            best = (step, 1.0, cus)
+    return best[1], best[2]
+
+
 class StreamTrainer:
     def __init__(self, model, users: torch.Tensor, items: torch.Tensor, seen_indptr: torch.Tensor,
                  seen_indices: torch.Tensor, lr: float, sampler: str = "adaptive",

@@ -184,3 +184,14 @@ def test_c_abi_comm_single_rank():
     e.item_sync_finish if False else None
     with pytest.raises(Exception):
         e.item_sync()  # no communicator any more
+
+
+def test_check_rccl_tool_single_rank():
+    """tools/check_rccl.py — the one command for the first real node run — with the one rank a 1-GPU
+    box has: ItemSync over backend "nccl", then the two-tier protocol through the C ABI
+    (bpr_comm_init / bpr_comm_hot_tier / bpr_hot_sync / bpr_item_sync over RCCL) against the same
+    protocol run in-process."""
+    res = subprocess.run([sys.executable, str(ROOT / "tools" / "check_rccl.py")], capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert "OK two-tier" in res.stdout and "OK\n" in res.stdout

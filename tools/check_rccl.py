@@ -15,7 +15,6 @@ Also runs with one rank (world 1: plain copy) and with BPR_DIST_BACKEND=gloo for
 """
 import os
 import sys
-import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -72,9 +71,101 @@ def main():
         print("OK")
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+
+
+# ---- the two-tier protocol through the C ABI (bpr_comm_init / bpr_comm_hot_tier / bpr_hot_sync /
+# bpr_item_sync over RCCL) against the same protocol with every rank simulated in this process
+# (distributed.LocalWorld): the first real node run is this one command.
+def two_tier(world, rank, dev):
+    import numpy as np
+
+    from revisit_bpr import engine as eng
+    from revisit_bpr.distributed import ItemSync, LocalWorld
+
+    U, I, d, n_round, rounds, pieces, H = 2000, 1500, 128, 4096, 3, 2, 64
+    rng = np.random.default_rng(5)
+    P0 = rng.normal(0, 0.2, (U, d)).astype(np.float32)
+    Q0 = rng.normal(0, 0.2, (I, d)).astype(np.float32)
+    P0[0] = 0
+    Q0[0] = 0
+    lens = rng.integers(1, 12, U)
+    lens[0] = 0
+    rows = [np.sort(rng.choice(np.arange(1, I), size=int(k), replace=False)).astype(np.int32) for k in lens]
+    indptr = np.zeros(U + 1, np.int64)
+    indptr[1:] = np.cumsum(lens)
+    indices = np.concatenate(rows)
+    users = np.sort(rng.integers(1, U, world * n_round * rounds)).astype(np.int32)
+    pos = (1 + (rng.zipf(1.4, len(users)) % (I - 1))).astype(np.int32)
+    counts = torch.bincount(torch.from_numpy(pos).long(), minlength=I)
+    cnt = counts.clone()
+    cnt[0] = 0
+    hot = torch.argsort(cnt * (I + 1) + (I - torch.arange(I)), descending=True)[:H].to(torch.int32)
+    u_d, p_d = torch.from_numpy(users).to(dev), torch.from_numpy(pos).to(dev)
+
+    def engine():
+        e = eng.Engine(torch.from_numpy(P0).to(dev), torch.from_numpy(Q0).to(dev))
+        e.set_reg(0.01, 0.02, 0.03)
+        e.set_optimizer(eng.OPT_SGD, lr=0.05)
+        e.bind_seen_csr(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev))
+        e.set_stream_opts(True, 0)
+        return e
+
+    def launch(e, r, k, p):
+        lo = (k * world + r) * n_round
+        a, b = lo + n_round * p // pieces, lo + n_round * (p + 1) // pieces
+        e.train_stream(u_d[a:b], p_d[a:b], sampler=eng.NEG_UNIFORM, seed=7, offset=(r << 40) + a, max_inflight=1)
+
+    # the real thing: this rank, RCCL inside the library
+    e = engine()
+    uid = [eng.Engine.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)
+    e.comm_init(uid[0], rank, world)
+    e.comm_hot_tier(hot, counts)
+    for k in range(rounds):
+        for p in range(pieces):
+            launch(e, rank, k, p)
+            e.hot_sync()
+        e.item_sync()
+    e.item_sync_finish()
+    torch.cuda.synchronize()
+    # the same protocol with all ranks in this process
+    lw = LocalWorld(world)
+    es = [engine() for _ in range(world)]
+    ss = [ItemSync([es[r].Q], comm=lw.member(r), engine=es[r], hot_rows=H, item_counts=counts) for r in range(world)]
+    for k in range(rounds):
+        for p in range(pieces):
+            for r in range(world):
+                launch(es[r], r, k, p)
+                ss[r].hot_step()
+        for r in range(world):
+            ss[r].step()
+    for r in range(world):
+        ss[r].hot_finish()
+        ss[r].finish()
+    torch.cuda.synchronize()
+    err = (e.Q - es[rank].Q).abs().max().item()
+    errp = (e.P - es[rank].P).abs().max().item()
+    moved = (e.Q - torch.from_numpy(Q0).to(dev)).abs().max().item()
+    flag = torch.tensor([err, errp], device=dev)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(f"two-tier through the C ABI over RCCL, world {world}: max |Q - in-process protocol| = {flag[0].item():.3e}, "
+              f"|P| {flag[1].item():.3e} (tolerance 1e-5; the table moved by up to {moved:.3f})")
+        assert flag[0].item() < 1e-5 and flag[1].item() < 1e-5
+        print("OK two-tier")
+    e.comm_destroy()
+    for s_ in ss:
+        s_.close()
 
 
 if __name__ == "__main__":
-    t0 = time.time()
     main()
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    if os.environ.get("BPR_DIST_BACKEND", "nccl") == "nccl":  # RCCL inside the library needs a device per rank
+        two_tier(world, rank, torch.device("cuda", local))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()

@@ -46,7 +46,7 @@ def main():
         d = {k: getattr(data, k) for k in ("users", "items", "indptr", "indices", "eval_users",
                                            "eval_indptr", "eval_items")}
         d["num_users"], d["num_items"] = data.num_users, data.num_items
-        cfg = dict(cfg, d=128, B=256, epochs=int(os.environ.get("BPR_EPOCHS", "4")), lr=0.05,
+        cfg = dict(cfg, d=128, B=256, epochs=int(os.environ.get("BPR_EPOCHS", "4")), lr=float(os.environ.get('BPR_LR', '0.05')),
                    adaptive_p=0.01, reg={"user": 0.0016, "item": 0.0001, "neg": 0.00375})
     else:
         d = np.load(ROOT / "tests/golden/e2e_data.npz")
@@ -61,7 +61,10 @@ def main():
                     logits_model=MF(torch.nn.Embedding(U, cfg["d"], padding_idx=0),
                                     torch.nn.Embedding(I, cfg["d"], padding_idx=0))).to(dev)
         f = model.logits_model.get_features()
-        sync = ItemSync([f["item"].data]) if world > 1 else None
+        # BPR_HOT_ROWS / BPR_HOT_SPLIT: the two-tier reconciliation (hot block after every launch)
+        hot_rows, hot_split = int(os.environ.get("BPR_HOT_ROWS", "0")), int(os.environ.get("BPR_HOT_SPLIT", "1"))
+        sync = ItemSync([f["item"].data], engine=model.engine(), hot_rows=hot_rows,
+                        local_items=t["items"][mine]) if world > 1 else None
         if mode == "batched-adam":
             opt = torch.optim.Adam(model.parameters(), lr=float(os.environ.get("BPR_ADAM_LR", "0.002")))
             tr = BatchedStreamTrainer(model, opt, t["users"][mine].contiguous(),
@@ -81,7 +84,7 @@ def main():
                                item_sync=sync,
                                # BPR_CADENCE=rank: a full refresh period per rank and chunk (the
                                # default divides the period by the number of ranks)
-                               **({"world": 1} if os.environ.get("BPR_CADENCE") == "rank" else {}),
+                               cadence=os.environ.get("BPR_CADENCE", "job"), hot_split=hot_split,
                                **({"refresh_lag": 1.0, "refresh_cus": 64} if mode == "stream-lag" else {}),
                                **({"shard_refresh": True} if mode == "stream-shard" else {}))
         curve = []
@@ -98,6 +101,8 @@ def main():
                 m = evaluate_topk(f["user"].data, f["item"].data, None, t["eval_users"], t["eval_indptr"],
                                   t["eval_items"], t["indptr"], t["indices"], ks=(20, 100))
                 curve.append((m["ndcg@100"], m["recall@20"]))
+        if sync is not None:
+            sync.close()
         if rank == 0:
             print(json.dumps({"kind": kind, "seed": seed, "world": world, "mode": mode,
                               "ndcg@100": [c[0] for c in curve], "recall@20": [c[1] for c in curve]}),
