@@ -111,14 +111,14 @@ def parse_args():
     ap.add_argument("--batch-size", type=int, default=256,
                     help="reference batch size; only sets the refresh period I·ln(I)/B batches")
     ap.add_argument("--sync-every", type=int, default=1, help="item all-reduce period in steps (N>1)")
-    ap.add_argument("--cadence", choices=["job", "rank"], default="rank",
-                    help="N>1: 'rank' (default, r4) = every rank launches a FULL refresh period per step; the "
-                         "snapshot refresh and the cold rows' reconciliation happen once per rank-period, the "
-                         "--tier-rows most popular rows are exchanged after every launch (two-tier "
-                         "reconciliation, DESIGN.md §7; profiles/r04_cadence_study.txt holds the parity runs); "
-                         "'job' = every rank advances refresh period / N triples per step, so refresh and "
-                         "reconciliation keep the single-GPU cadence counted in triples of the whole job "
-                         "(launches shrink with N: r3's default)")
+    ap.add_argument("--cadence", choices=["auto", "job", "rank"], default="auto",
+                    help="N>1: how much a rank trains between two reconciliations (+ snapshot refreshes).  "
+                         "'auto' (default, r4): the largest chunk that keeps lr x N x chunk inside the staleness "
+                         "budget the multi-rank parity study measured (fast.STALENESS_BUDGET, "
+                         "profiles/r04_cadence_study.txt) — a FULL refresh period per rank at this benchmark's "
+                         "lr 0.001, period / N at lr 0.05; 'rank' = a full period per rank whatever the lr; "
+                         "'job' = period / N (r3's default: the single-GPU cadence counted in job triples).  "
+                         "The --tier-rows most popular rows are exchanged after every launch (two tiers)")
     ap.add_argument("--tier-rows", type=int, default=1024,
                     help="N>1, --cadence rank: rows of the hot tier (0 = one tier: r3's protocol)")
     ap.add_argument("--hot-split", type=int, default=1,
@@ -342,7 +342,7 @@ def main():
     sampler = {"adaptive": eng.NEG_ADAPTIVE, "uniform": eng.NEG_UNIFORM, "given": eng.NEG_GIVEN}[args.sampler]
 
     # snapshot schedule of the adaptive sampler
-    sched = SCHEDULE if world == 1 or args.cadence == "rank" else SCHEDULE_MULTI
+    sched = SCHEDULE if world == 1 or args.cadence != "job" else SCHEDULE_MULTI
     lag = sched["refresh_lag"] if args.refresh_lag is None else args.refresh_lag
     split = sched["refresh_split"] if args.refresh_split is None else args.refresh_split
     cus = sched["refresh_cus"] if args.refresh_cus is None else args.refresh_cus
@@ -353,7 +353,9 @@ def main():
     # one launch, each grouped by user (the STREAM kernel keeps the user row in registers)
     every = max(1, int(I * math.log(I) / args.batch_size))  # example.py:302
     period = min(every * args.batch_size, data.nnz)
-    ranks_per_period = world if args.cadence == "job" else 1
+    from revisit_bpr.fast import launches_per_period
+    ranks_per_period = (world if args.cadence == "job" else 1 if args.cadence == "rank" else
+                        launches_per_period(args.lr, world, period))
     chunk = max(1, period // (split * ranks_per_period))
     n_chunks = max(1, data.nnz // chunk)
     src_users = torch.from_numpy(data.users).to(dev)
@@ -376,7 +378,7 @@ def main():
         main_stream = eng.MaskedStream(dev, eng.cu_mask(total_cus - args.main_cus, args.main_cus, total_cus))
     sync = None
     if world > 1:
-        tier = args.tier_rows if (args.cadence == "rank" and not batched) else 0
+        tier = args.tier_rows if (args.cadence != "job" and not batched) else 0
         sync = ItemSync([Q], engine=e, hot_rows=tier, local_items=src_items)
     pieces = args.hot_split if (sync is not None and sync.hot_tier) else 1
     scalars = torch.zeros(4, device=dev)
@@ -569,12 +571,12 @@ def main():
                 "triples_per_step_per_gpu": chunk,
                 "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus,
                                      "sharded_over_ranks": bool(shard_refresh and not batched)},
-                "cadence": ((f"rank: every rank launches a full refresh period of {chunk} triples per step "
-                             f"({pieces} launch(es)); snapshot refresh + cold-row reconciliation once per "
-                             f"rank-period, hot tier of {sync._hb.shape[0] if sync.hot_tier else 0} rows "
-                             "exchanged after every launch") if args.cadence == "rank" else
-                            (f"job: one snapshot refresh + item reconciliation per {chunk * world} triples of "
-                             "the whole job")) if world > 1 else "single GPU",
+                "cadence": (f"{args.cadence}: {ranks_per_period} chunk(s) of {chunk} triples per rank and refresh "
+                            f"period (lr x N x chunk = {args.lr * world * chunk:.0f}, budget "
+                            f"{__import__('revisit_bpr.fast', fromlist=['x']).STALENESS_BUDGET:.0f}); per chunk one "
+                            f"snapshot refresh + one cold-row reconciliation, {pieces} launch(es), hot tier of "
+                            f"{sync._hb.shape[0] if sync.hot_tier else 0} rows exchanged after every launch"
+                            ) if world > 1 else "single GPU",
                 "steps_per_epoch": n_chunks,
                 "plan_epoch": {"ms": plan_ms, "inside_timed_region": plans_timed,
                                "amortised_share_added_ms_per_step":

@@ -59,6 +59,25 @@ def auto_schedule(I: int, d: int, launch_triples: int, total_cus: int = 256) -> 
     return best[1], best[2]
 
 
+# Staleness budget of a multi-rank job (profiles/r04_cadence_study.txt).  A rank sees the
+# other ranks' item updates — and re-sorts its sampler snapshot — once per chunk, folded one chunk
+# late: up to 2 x world x chunk triples of the job are applied against rows and a snapshot that do
+# not know them yet.  The study (full ML-20M shape, 1/2/4/8 ranks, three learning rates) puts the
+# edge of the +-0.002 nDCG@100 band at  lr x world x chunk ~ 4,000  (lr is per triple: the loss is a
+# sum): at lr 0.05 that asks for less than period / world — the floor, the single-GPU cadence counted
+# in job triples — and at the reference configs' lr 0.001 a full period per rank fits with room to spare.
+STALENESS_BUDGET = 4_000.0
+
+
+def launches_per_period(lr: float, world: int, period: int, budget: Optional[float] = None) -> int:
+    """Chunks a rank cuts a refresh period into so that lr x world x chunk stays inside the budget:
+    1 (a full period per rank: "rank" cadence) .. world (period / world: "job" cadence)."""
+    if world <= 1:
+        return 1
+    budget = STALENESS_BUDGET if budget is None else budget
+    return int(min(max(math.ceil(period * lr * world / budget), 1), world))
+
+
 class StreamTrainer:
     def __init__(self, model, users: torch.Tensor, items: torch.Tensor, seen_indptr: torch.Tensor,
                  seen_indices: torch.Tensor, lr: float, sampler: str = "adaptive",
@@ -94,7 +113,9 @@ class StreamTrainer:
                             the whole job (launches shrink with the number of ranks).
                             "rank": every rank launches a FULL period; refresh and cold reconciliation
                             once per rank-period, the hot rows (item_sync's hot tier) after every
-                            launch — what keeps full-size launches stable.
+                            launch.
+                            "auto": between the two — the largest chunk that keeps
+                            lr x world x chunk inside STALENESS_BUDGET (`launches_per_period`).
           hot_split k       a chunk runs as k launches with a hot-tier exchange after each.
           rounds            chunks per epoch over all ranks (None: a MAX all-reduce decides)."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
@@ -117,10 +138,11 @@ class StreamTrainer:
         # and the item reconciliation keep their single-GPU cadence
         if world is None:
             world = item_sync.world if item_sync is not None else 1
-        if cadence not in ("job", "rank"):
-            raise ValueError("cadence must be 'job' or 'rank'")
+        if cadence not in ("job", "rank", "auto"):
+            raise ValueError("cadence must be 'job', 'rank' or 'auto'")
         self.cadence = cadence
-        per_period = max(world, 1) if cadence == "job" else 1
+        per_period = (max(world, 1) if cadence == "job" else 1 if cadence == "rank" else
+                      launches_per_period(lr, max(world, 1), every * batch_size, STALENESS_BUDGET))
         self.chunk = max(1, min(every * batch_size // (per_period * refresh_split), self.n))
         self.hot_split = max(1, int(hot_split))
         U = self.engine.U

@@ -1,6 +1,7 @@
 """bench.py end to end (small --scale): the single-GPU line the driver records, and the N > 1 path
 (two ranks sharing cuda:0 over gloo — RCCL needs one device per rank; the protocol is the same:
-job cadence, sharded snapshot refresh + all-gather, delta all-reduce on the side stream)."""
+the staleness-budget cadence with the two-tier reconciliation, and r3's job cadence with the
+sharded snapshot refresh + all-gather)."""
 import json
 import os
 import subprocess
@@ -33,17 +34,27 @@ def test_bench_single_gpu_line():
     assert j["cpu_baseline"]["cores"] >= 1 and j["cpu_baseline"]["value"] > 0
     sched = j["config"]["refresh_schedule"]
     assert sched["lag"] == 1.0 and sched["side_stream_cus"] >= 64  # the schedule the gates hold
-    assert j["config"]["triples_counted_by_kernel"] == 6 * j["config"]["triples_per_step_per_gpu"]
+    sus = j["sustained"]  # whole epochs, every plan in place
+    assert j["config"]["triples_counted_by_kernel"] == (6 + sus["steps"]) * j["config"]["triples_per_step_per_gpu"]
+    assert sus["epochs"] == 3 and sus["value"] > 1e6 and 0 < r["read_only_frac"] < r["frac"]
+    assert j["config"]["parity"]["tolerance_north_star"] == 0.002
 
 
-def test_bench_two_ranks_over_gloo():
+@pytest.mark.parametrize("cadence", ["auto", "job"])
+def test_bench_two_ranks_over_gloo(cadence):
     env = dict(os.environ, BPR_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29671", str(ROOT / "bench.py"), "--gpus", "2",
-           "--scale", "0.05", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+           "--scale", "0.05", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--cadence", cadence,
+           "--sustained-epochs", "1"]
     j = _line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900))
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 1e6
-    assert j["config"]["cadence"].startswith("job")
-    assert j["config"]["refresh_schedule"]["sharded_over_ranks"] is True
+    assert j["config"]["cadence"].startswith(cadence)
     assert j["item_sync"]["all_reduces"] >= 6
-    assert j["config"]["triples_counted_by_kernel"] == 6 * j["config"]["triples_per_step_per_gpu"]
+    if cadence == "job":
+        assert j["config"]["refresh_schedule"]["sharded_over_ranks"] is True
+    else:  # lr 0.001: a full period per rank, hot tier exchanged after every launch
+        assert "1 chunk(s)" in j["config"]["cadence"] and j["item_sync"]["hot"]["all_reduces"] >= 6
+        assert j["config"]["refresh_schedule"]["lag"] == 1.0
+    steps = 6 + j["sustained"]["steps"]
+    assert j["config"]["triples_counted_by_kernel"] == steps * j["config"]["triples_per_step_per_gpu"]

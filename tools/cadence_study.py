@@ -57,7 +57,11 @@ def run(data, dim, dev, t, world, seed, a, lr, epochs):
     trs, models = [], []
     every = max(1, int(I * np.log(I) / 256))
     n_r = [int((own == r).sum()) for r in range(world)]
-    per_period = world if a.cadence == "job" else 1
+    from revisit_bpr import fast
+    if a.budget is not None:
+        fast.STALENESS_BUDGET = a.budget
+    per_period = (world if a.cadence == "job" else 1 if a.cadence == "rank" else
+                  fast.launches_per_period(lr, world, every * 256, fast.STALENESS_BUDGET))
     chunk = [max(1, min(every * 256 // per_period, n)) for n in n_r]
     rounds = max(-(-n // c) for n, c in zip(n_r, chunk))
     for r in range(world):
@@ -70,7 +74,7 @@ def run(data, dim, dev, t, world, seed, a, lr, epochs):
         sync = None
         if world > 1:
             sync = ItemSync([f["item"].data], comm=lw.member(r), engine=model.engine(),
-                            hot_rows=a.hot_rows if a.cadence == "rank" or a.hot_job else 0,
+                            hot_rows=a.hot_rows if a.cadence != "job" or a.hot_job else 0,
                             item_counts=counts, scale=(1.0 / world if a.cold_scale == "mean" else 1.0))
         tr = StreamTrainer(model, t["users"][mine].contiguous(), t["items"][mine].contiguous(),
                            t["indptr"], t["indices"], lr=lr, sampler=a.sampler, adaptive_p=a.adaptive_p,
@@ -123,7 +127,8 @@ def main():
     ap.add_argument("--epochs", type=int, default=4)
     ap.add_argument("--eval-every", type=int, default=1)
     ap.add_argument("--seeds", type=int, default=10)
-    ap.add_argument("--cadence", default="rank", choices=["rank", "job"])
+    ap.add_argument("--cadence", default="rank", choices=["rank", "job", "auto"])
+    ap.add_argument("--budget", type=float, default=None, help="--cadence auto: override fast.STALENESS_BUDGET")
     ap.add_argument("--hot-rows", type=int, default=1024)
     ap.add_argument("--hot-job", action="store_true", help="hot tier also at the job cadence")
     ap.add_argument("--hot-split", type=int, default=1)
