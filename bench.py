@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 ATOMIC_LINES_PEAK = 9.5e9
 # default snapshot schedule of the adaptive sampler: the one the parity gates hold
 # (tests/test_gpu_e2e_parity.py, tests/test_gpu_fullscale_parity.py)
-SCHEDULE = {"refresh_lag": 1.0, "refresh_split": 1, "refresh_cus": -1}  # -1: fast.auto_refresh_cus (64 here)
+SCHEDULE = {"refresh_lag": 1.0, "refresh_split": 1, "refresh_cus": -1}  # -1: fast.auto_schedule (64 CUs here)
 # N > 1 (cadence "job": every rank's launch is 1/N of a refresh period, far shorter than the sort):
 # the snapshot is sorted between launches, every rank sorting d/N of its factors
 SCHEDULE_MULTI = {"refresh_lag": 0.0, "refresh_split": 1, "refresh_cus": 0}
@@ -150,6 +150,10 @@ def parse_args():
     ap.add_argument("--item-skew", type=float, default=None,
                     help="override the item popularity exponent (debug: 0 = uniform popularity)")
     ap.add_argument("--ungrouped", action="store_true", help="all-atomic user rows (debug)")
+    ap.add_argument("--jit-plan", type=int, default=1,
+                    help="1 (default): with the overlapped snapshot schedule the epoch is never planned as a whole "
+                         "— every chunk is planned by bpr_plan_chunk on the side stream, one step ahead; 0: "
+                         "bpr_plan_epoch at every epoch boundary (r3)")
     ap.add_argument("--sustained-epochs", type=int, default=3,
                     help="after the timed region: this many WHOLE epochs (plan + every step) timed by wall "
                          "clock, reported as `sustained` (0 = skip)")
@@ -360,7 +364,7 @@ def main():
     n_chunks = max(1, data.nnz // chunk)
     src_users = torch.from_numpy(data.users).to(dev)
     src_items = torch.from_numpy(data.items).to(dev)
-    users, items = torch.empty_like(src_users), torch.empty_like(src_items)
+    users_e, items_e = torch.empty_like(src_users), torch.empty_like(src_items)
     e.set_stream_opts(not args.ungrouped, args.run_len)
     if args.hot_rows is not None:
         e.set_hot_rows(args.hot_rows, args.hot_replicas)
@@ -368,11 +372,16 @@ def main():
     if lag > 0.0 and cus != 0:
         total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         if cus < 0:
-            from revisit_bpr.fast import auto_refresh_cus
-            cus = auto_refresh_cus(I, d, chunk, total_cus)
-        side_stream = eng.MaskedStream(dev, eng.cu_mask(0, cus, total_cus))
-        main_stream = eng.MaskedStream(dev, eng.cu_mask(cus, total_cus - cus, total_cus))
-        e.set_side_stream(side_stream)
+            # by shape (fast.auto_schedule: 64 CUs for the ML-20M workload, 96 for MSD d=256); it may
+            # also say that no split of the chip beats the reference's serial schedule
+            from revisit_bpr.fast import auto_schedule
+            a_lag, cus = auto_schedule(I, d, chunk, total_cus)
+            if a_lag == 0.0 and args.refresh_lag is None:
+                lag, cus = 0.0, 0
+        if cus > 0:
+            side_stream = eng.MaskedStream(dev, eng.cu_mask(0, cus, total_cus))
+            main_stream = eng.MaskedStream(dev, eng.cu_mask(cus, total_cus - cus, total_cus))
+            e.set_side_stream(side_stream)
     if main_stream is None and args.main_cus > 0:
         total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         main_stream = eng.MaskedStream(dev, eng.cu_mask(total_cus - args.main_cus, args.main_cus, total_cus))
@@ -388,7 +397,22 @@ def main():
 
     fused = lag >= 1.0 and world == 1  # the launch's epilogue cuts the next snapshot's keys
 
+    # --jit-plan (default with the overlapped schedule): no bpr_plan_epoch at all — chunk k + 1 is
+    # planned by bpr_plan_chunk on the side stream behind the sort of step k (the plan does not depend
+    # on the model), into the buffer launch k - 1 read; bpr_adaptive_refresh_commit waits for both
+    jit = bool(args.jit_plan) and sampler == eng.NEG_ADAPTIVE and lag >= 1.0 and not batched
+    cbuf = [(torch.empty(chunk, dtype=torch.int32, device=dev), torch.empty(chunk, dtype=torch.int32, device=dev))
+            for _ in range(2)] if jit else None
+    planned = set()
+
+    def plan_chunk(kk: int, on_side: bool):
+        e.plan_chunk(src_users, src_items, chunk, seed + kk // n_chunks, kk % n_chunks, out=cbuf[kk & 1],
+                     on_side=on_side)
+
     def launch(k: int, lo: int, hi: int, base: int, cut: bool = False):
+        users, items = (cbuf[k & 1][0], cbuf[k & 1][1]) if jit else (users_e, items_e)
+        if jit:  # a chunk buffer: positions relative to the chunk
+            lo, hi, base = lo - base, hi - base, 0
         if batched:
             e.train_stream_batched(users[lo:hi], items[lo:hi], args.batch_size,
                                    sampler=sampler, neg=given_neg, adaptive_p=args.adaptive_p,
@@ -409,11 +433,14 @@ def main():
     def step(k: int):
         c = k % n_chunks
         lo = c * chunk
-        if c == 0:  # new epoch: re-plan (part of the job)
+        if jit:
+            if k not in planned:  # the first step, or a jump: plan it on the launch stream
+                plan_chunk(k, False)
+        elif c == 0:  # new epoch: re-plan (part of the job)
             if batched:
-                e.shuffle_epoch(src_users, src_items, seed + k // n_chunks, out=(users, items))
+                e.shuffle_epoch(src_users, src_items, seed + k // n_chunks, out=(users_e, items_e))
             else:
-                e.plan_epoch(src_users, src_items, chunk, seed + k // n_chunks, out=(users, items))
+                e.plan_epoch(src_users, src_items, chunk, seed + k // n_chunks, out=(users_e, items_e))
         if sampler != eng.NEG_ADAPTIVE:
             launch(k, lo, lo + chunk, lo)
         elif lag == 0.0:
@@ -431,6 +458,10 @@ def main():
             if cut > lo:
                 launch(k, lo, cut, lo)
             e.adaptive_refresh_begin()
+            if jit:
+                plan_chunk(k + 1, True)
+                planned.clear()
+                planned.add(k + 1)
             if cut < lo + chunk:
                 launch(k, cut, lo + chunk, lo, cut=fused)
         if sync is not None and (k + 1) % args.sync_every == 0:
@@ -493,13 +524,15 @@ def main():
         tp = time.perf_counter()
         for r in range(3):
             if batched:
-                e.shuffle_epoch(src_users, src_items, seed + 1000 + r, out=(users, items))
+                e.shuffle_epoch(src_users, src_items, seed + 1000 + r, out=(users_e, items_e))
             else:
-                e.plan_epoch(src_users, src_items, chunk, seed + 1000 + r, out=(users, items))
+                e.plan_epoch(src_users, src_items, chunk, seed + 1000 + r, out=(users_e, items_e))
         torch.cuda.synchronize()
         plan_ms = (time.perf_counter() - tp) * 1e3 / 3
     plans_timed = sum(1 for k in range(first, first + args.steps) if k % n_chunks == 0)
     dt_measured = dt
+    if jit:  # every chunk's plan ran inside the region (on the side stream): nothing to add
+        plans_timed = args.steps / n_chunks
     dt += max(0.0, args.steps / n_chunks - plans_timed) * plan_ms * 1e-3
     kernel_ms, launches = e.timing_read()
     e.timing_enable(False)
@@ -522,7 +555,8 @@ def main():
     user_atomic_rows = 0.0
     if not batched:
         L = e.stream_run_len()  # what the library's last launch used (it picks it from the occupancy)
-        user_atomic_rows = cut_user_pieces(users[:chunk], L, not args.ungrouped) / chunk
+        planned_users = cbuf[(first + args.steps - 1) & 1][0] if jit else users_e[:chunk]
+        user_atomic_rows = cut_user_pieces(planned_users, L, not args.ungrouped) / chunk
 
     opt_desc = {"sgd": f"SGD lr={args.lr}", "momentum": f"SGD(momentum 0.9) lr={args.lr}",
                 "adam": f"Adam lr={args.lr} betas={tuple(args.betas)}",
@@ -538,10 +572,12 @@ def main():
         # summary of separate rocprofv3 --pmc passes of this same command (profiles/*_pmc_traffic.md:
         # FETCH_SIZE x2 correction + WRITE_SIZE); null when the run is not the profiled configuration
         traffic = None
-        tfiles = sorted((ROOT / "profiles").glob("traffic_r*.json"))
+        # (one file per profiled shape: traffic_rNN.json = ml-20m d=128, traffic_rNN_msd_d256.json = BASELINE configs[3])
+        suffix = {("ml-20m", 128): "", ("msd", 256): "_msd_d256"}.get((args.workload, d))
+        tfiles = sorted(f for f in (ROOT / "profiles").glob("traffic_r*.json")
+                        if suffix is not None and f.stem.count("_") == (1 if suffix == "" else 3) and f.stem.endswith(suffix or f.stem[-3:]))
         tfile = tfiles[-1] if tfiles else ROOT / "profiles" / "none"
-        if tfile.exists() and args.workload == "ml-20m" and d == 128 and args.sampler == "adaptive" \
-                and args.scale == 1.0 and not batched:
+        if tfile.exists() and args.sampler == "adaptive" and args.scale == 1.0 and not batched:
             tj = json.loads(tfile.read_text())
             if tj.get("triples_per_launch") == chunk:
                 traffic = tj["traffic_bytes_per_launch"]
@@ -578,7 +614,9 @@ def main():
                             f"{sync._hb.shape[0] if sync.hot_tier else 0} rows exchanged after every launch"
                             ) if world > 1 else "single GPU",
                 "steps_per_epoch": n_chunks,
-                "plan_epoch": {"ms": plan_ms, "inside_timed_region": plans_timed,
+                "plan_epoch": {"mode": ("per chunk, one step ahead, on the side stream behind the sort "
+                                        "(bpr_plan_chunk): inside every step") if jit else "bpr_plan_epoch per epoch",
+                               "ms": plan_ms, "inside_timed_region": plans_timed,
                                "amortised_share_added_ms_per_step":
                                    max(0.0, args.steps / n_chunks - plans_timed) * plan_ms / args.steps,
                                "ms_per_step_measured": dt_measured * 1e3 / args.steps},
@@ -601,7 +639,7 @@ def main():
                                    if kernel_ms > 0 and args.optimizer == "sgd" else None),
                 "traffic": traffic,
                 "traffic_measured_in_this_run": False,
-                "traffic_source": (f"replayed from profiles/{tfile.stem.replace('traffic_', '')}_pmc_traffic.md "
+                "traffic_source": (f"replayed from profiles/{tfile.stem.replace('traffic_', '').split('_')[0]}_pmc_traffic.md "
                                    "(separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
                                    "MI355X, bytes per launch, gfx950 x2 read correction)") if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_triple * chunk,

@@ -310,6 +310,17 @@ int bpr_train_stream_batched(bpr_ctx* ctx, const int32_t* users, const int32_t* 
 int bpr_shuffle_epoch(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_in, int64_t n,
                       uint64_t seed, int32_t* users_out, int32_t* pos_out);
 
+/* ONE chunk of that plan without planning the epoch: the triples of chunk `index` (the same member
+ * set bpr_plan_epoch(seed) puts there, grouped by user; the order of a user's triples may differ),
+ * found through the INVERSE of the permutation — pi^-1 of [index * chunk, (index + 1) * chunk) — and
+ * sorted by user: ~200 k keys instead of the whole epoch.  users_out / pos_out [min(chunk, n - index *
+ * chunk)].  The plan does not depend on the model: with on_side != 0 it is queued on the split
+ * refresh's side stream behind the sort in flight (bpr_adaptive_refresh_begin must have been
+ * called), and bpr_adaptive_refresh_commit then waits for both — the chunk after next is planned in
+ * the time the sorter idles, nothing is planned on the launch stream (fast.StreamTrainer(jit_plan)). */
+int bpr_plan_chunk(bpr_ctx* ctx, const int32_t* users_in, const int32_t* pos_in, int64_t n, int64_t chunk,
+                   uint64_t seed, int64_t index, int32_t* users_out, int32_t* pos_out, int32_t on_side);
+
 /* STREAM options.  grouped_by_user = 1 promises that inside every chunk handed to
  * bpr_train_stream the triples of a user are contiguous (the output of bpr_plan_epoch): a user
  * whose triples all fall in one run of `run_len` consecutive triples is then owned by one

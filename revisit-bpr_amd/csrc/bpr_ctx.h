@@ -94,6 +94,12 @@ struct bpr_ctx {
   const int32_t* plan_users = nullptr;  // outputs of the last bpr_plan_epoch (caller-owned)
   const int32_t* plan_pos = nullptr;
   int64_t plan_n = 0, plan_chunk = 0;
+  // bpr_plan_chunk scratch: keys / values of one chunk before the by-user sort
+  uint32_t* pc_keys = nullptr;
+  int32_t* pc_vals = nullptr;
+  void* pc_tmp = nullptr;
+  size_t pc_tmp_bytes = 0;
+  int64_t pc_cap = 0;
   // hot item rows (bpr_set_hot_rows): the most popular rows take their STREAM updates in replica
   // delta rows, folded into Q right after every STREAM launch (all zero in between)
   int hot_rows_opt = 256, hot_reps_opt = 1;
@@ -145,6 +151,8 @@ void heavy_free(bpr_ctx* c);        // bpr_refresh.hip
 int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n);  // bpr_refresh.hip
 int hot_set_items_impl(bpr_ctx* c, const int32_t* items, int H, const uint32_t* counts);  // bpr_refresh.hip
 void hot_free(bpr_ctx* c);                                       // bpr_refresh.hip
+int plan_chunk_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n, int64_t chunk,
+                    uint64_t seed, int64_t index, int32_t* users_out, int32_t* pos_out, hipStream_t st);
 int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n,
                     int64_t chunk, uint64_t seed, int32_t* users_out, int32_t* pos_out);
 }  // namespace bpr

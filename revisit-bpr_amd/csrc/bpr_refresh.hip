@@ -377,6 +377,38 @@ __global__ void k_plan_users(const K* __restrict__ keys, int64_t n, int ubits,
     users_out[t] = (int32_t)((uint64_t)keys[t] & mask);
 }
 
+// the inverse permutation (same network run backwards, same cycle-walk): pi^-1(pi(t)) = t
+__device__ __forceinline__ uint64_t feistel_inv(uint64_t y, uint64_t n, int half_bits, uint64_t seed) {
+  const uint32_t mask = (half_bits >= 32) ? 0xFFFFFFFFu : ((1u << half_bits) - 1u);
+  do {
+    uint32_t l = (uint32_t)(y >> half_bits) & mask, r = (uint32_t)y & mask;
+#pragma unroll
+    for (int round = 3; round >= 0; --round) {
+      const uint32_t k = (uint32_t)(seed >> (16 * (round & 1))) + 0x9E3779B9u * (uint32_t)(round + 1) +
+                         (uint32_t)(seed >> 32);
+      const uint32_t pr = l;                      // the forward round's input r
+      const uint32_t pl = r ^ (mix32(pr ^ k) & mask);
+      l = pl;
+      r = pr;
+    }
+    y = ((uint64_t)l << half_bits) | r;
+  } while (y >= n);
+  return y;
+}
+
+// bpr_plan_chunk: the members of ONE chunk of the epoch plan, found through the inverse permutation
+// (chunk c = pi^-1 of [c * chunk, (c + 1) * chunk)) instead of by sorting the whole epoch
+__global__ void k_plan_chunk(const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+                             int64_t n, int64_t j0, int64_t m, int half_bits, uint64_t seed,
+                             uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t t = feistel_inv((uint64_t)(j0 + k), (uint64_t)n, half_bits, seed);
+    keys[k] = (uint32_t)users[t];
+    vals[k] = pos[t];
+  }
+}
+
 static int bits_for(uint64_t v) {  // bits needed to represent values 0..v
   int b = 1;
   while ((v >> b) != 0) ++b;
@@ -446,6 +478,42 @@ int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
   return BPR_OK;
 }
 
+
+// One chunk of the plan (the same member set as chunk `index` of bpr_plan_epoch with the same seed,
+// grouped by user), on `st`.  The plan does not depend on the model, so it can be computed for the
+// chunk after next on the split refresh's side stream, in the time the sort leaves idle.
+int plan_chunk_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n, int64_t chunk,
+                    uint64_t seed, int64_t index, int32_t* users_out, int32_t* pos_out, hipStream_t st) {
+  const int64_t j0 = index * chunk;
+  if (j0 >= n) return BPR_OK;
+  const int64_t m = std::min<int64_t>(chunk, n - j0);
+  int half_bits = (bits_for((uint64_t)(n - 1)) + 1) / 2;
+  if (half_bits < 1) half_bits = 1;
+  const int ubits = bits_for((uint64_t)(c->U - 1));
+  if (c->pc_cap < m) {
+    hipFree(c->pc_keys); hipFree(c->pc_vals); hipFree(c->pc_tmp);
+    c->pc_keys = nullptr; c->pc_vals = nullptr; c->pc_tmp = nullptr;
+    c->pc_cap = 0;
+    BPR_HIP_CHECK(hipMalloc(&c->pc_keys, sizeof(uint32_t) * m));
+    BPR_HIP_CHECK(hipMalloc(&c->pc_vals, sizeof(int32_t) * m));
+    size_t bytes = 0;
+    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->pc_keys,
+                                                     reinterpret_cast<uint32_t*>(users_out), c->pc_vals,
+                                                     pos_out, (int)m, 0, 32, st));
+    BPR_HIP_CHECK(hipMalloc(&c->pc_tmp, bytes > 0 ? bytes : 16));
+    c->pc_tmp_bytes = bytes;
+    c->pc_cap = m;
+  }
+  const unsigned grid = (unsigned)std::min<int64_t>((m + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_plan_chunk, dim3(grid), dim3(256), 0, st, users_in, pos_in, n, j0, m, half_bits,
+                     seed, c->pc_keys, c->pc_vals);
+  size_t bytes = c->pc_tmp_bytes;
+  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->pc_tmp, bytes, c->pc_keys,
+                                                   reinterpret_cast<uint32_t*>(users_out), c->pc_vals,
+                                                   pos_out, (int)m, 0, ubits, st));
+  BPR_HIP_CHECK(hipGetLastError());
+  return BPR_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Hot item rows: popularity of the training positives -> the H most popular rows get replica
@@ -727,6 +795,9 @@ void refresh_free(bpr_ctx* c) {
   c->plan_tmp = nullptr;
   c->plan_cap = 0;
   if (c->side != nullptr) hipStreamSynchronize(c->side);
+  hipFree(c->pc_keys); hipFree(c->pc_vals); hipFree(c->pc_tmp);
+  c->pc_keys = nullptr; c->pc_vals = nullptr; c->pc_tmp = nullptr;
+  c->pc_cap = 0;
   for (int k = 0; k < 2; ++k) {
     hipFree(c->order_alloc[k]);
     hipFree(c->sigma_buf[k]);

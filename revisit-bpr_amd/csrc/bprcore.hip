@@ -1172,6 +1172,28 @@ int bpr_plan_epoch(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, i
   return plan_epoch_impl(c, users_in, pos_in, n, chunk, seed, users_out, pos_out);
 }
 
+int bpr_plan_chunk(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n, int64_t chunk,
+                   uint64_t seed, int64_t index, int32_t* users_out, int32_t* pos_out, int32_t on_side) {
+  if (int rc = check_bound(c, "bpr_plan_chunk")) return rc;
+  if (n < 1 || n >= ((int64_t)1 << 31) || chunk < 1 || index < 0 || !users_in || !pos_in || !users_out ||
+      !pos_out)
+    return fail(BPR_ERR_INVALID, "bpr_plan_chunk: bad argument");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (c->hot_key_ptr != pos_in || c->hot_key_n != n) {  // new training set: measure popularity (as
+    if (int rc = hot_build_impl(c, pos_in, n)) return rc;  // bpr_plan_epoch does)
+  }
+  if (!on_side) return plan_chunk_impl(c, users_in, pos_in, n, chunk, seed, index, users_out, pos_out, c->stream);
+  // behind the split refresh's sort on the side stream; what bpr_adaptive_refresh_commit waits for
+  // then covers this chunk too (one event, no extra packet on the launch stream)
+  if (c->side == nullptr || !c->refresh_pending)
+    return fail(BPR_ERR_INVALID, "bpr_plan_chunk: on_side needs a split refresh in flight "
+                                 "(bpr_adaptive_refresh_begin first)");
+  if (int rc = plan_chunk_impl(c, users_in, pos_in, n, chunk, seed, index, users_out, pos_out, c->side))
+    return rc;
+  BPR_HIP_CHECK(hipEventRecord(c->ev_sorted, c->side));
+  return BPR_OK;
+}
+
 int bpr_flush_lazy(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_flush_lazy")) return rc;
   c->keys_cut = false;

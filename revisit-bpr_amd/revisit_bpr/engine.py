@@ -542,6 +542,16 @@ class Engine:
                                               po.data_ptr()))
         return uo, po
 
+    def plan_chunk(self, users: torch.Tensor, pos: torch.Tensor, chunk: int, seed: int, index: int,
+                   out: tuple[torch.Tensor, torch.Tensor], on_side: bool = False) -> None:
+        """Chunk `index` of the plan `plan_epoch(seed)` would make (same members, grouped by user),
+        alone; on_side: queued on the split refresh's side stream behind the sort in flight."""
+        if not on_side:
+            self._sync_stream()
+        native.check(self._lib.bpr_plan_chunk(self._ctx, users.data_ptr(), pos.data_ptr(), users.numel(),
+                                              chunk, seed, index, out[0].data_ptr(), out[1].data_ptr(),
+                                              int(on_side)))
+
     def flush_lazy(self) -> None:
         self._sync_stream()
         native.check(self._lib.bpr_flush_lazy(self._ctx))

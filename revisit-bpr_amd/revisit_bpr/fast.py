@@ -53,7 +53,7 @@ def auto_schedule(I: int, d: int, launch_triples: int, total_cus: int = 256) -> 
         # the launch on the remaining CUs: +6 % per 64 CUs while the atomic units bound it
         # (d <= 128), more once HBM does (d >= 256: measured +3 % .. +5 % at 64)
         stretch = 1.0 + (0.06 if d <= 128 else 0.05) * cus / 64 * (1.0 if d <= 128 else 1.5)
-        step = max(launch_ms * stretch, sort_ms_cu / cus) + 0.026  # cut + the launch-to-launch gap
+        step = max(launch_ms * stretch, 0.9 * sort_ms_cu / cus) + 0.026  # cut + the launch-to-launch gap
         if step < best[0]:
             best = (step, 1.0, cus)
     return best[1], best[2]
@@ -86,7 +86,7 @@ class StreamTrainer:
                  item_sync=None, sync_every: int = 1, world: Optional[int] = None,
                  refresh_lag: float = 0.0, refresh_split: int = 1, refresh_cus: int = 0,
                  shard_refresh: bool = False, cadence: str = "job", hot_split: int = 1,
-                 rounds: Optional[int] = None) -> None:
+                 rounds: Optional[int] = None, jit_plan: bool = False) -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
         adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302.
@@ -117,7 +117,12 @@ class StreamTrainer:
                             "auto": between the two — the largest chunk that keeps
                             lr x world x chunk inside STALENESS_BUDGET (`launches_per_period`).
           hot_split k       a chunk runs as k launches with a hot-tier exchange after each.
-          rounds            chunks per epoch over all ranks (None: a MAX all-reduce decides)."""
+          rounds            chunks per epoch over all ranks (None: a MAX all-reduce decides).
+
+        jit_plan (refresh_lag = 1 only): the epoch is never planned as a whole — chunk k + 1 is planned
+        by `bpr_plan_chunk` on the side stream behind the sort of chunk k (the plan does not depend on
+        the model; the sorter idles ~40 us per step), and `adaptive_refresh_commit` waits for both.
+        Same chunks as `bpr_plan_epoch` makes (same members, grouped by user)."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
             raise ValueError("users / items must be int32 device tensors")
         if not 0.0 <= refresh_lag <= 1.0 or refresh_split < 1:
@@ -165,8 +170,15 @@ class StreamTrainer:
         self.seed, self.rank = seed, rank
         self.epoch = 0
         self.drawn = 0
-        self._pu = torch.empty_like(self.users)
-        self._pi = torch.empty_like(self.items)
+        self.jit_plan = bool(jit_plan) and self.refresh_lag >= 1.0
+        if self.jit_plan:  # two chunk buffers: launch k reads one while chunk k + 1 is planned into the other
+            self._cb = [(torch.empty(self.chunk, dtype=torch.int32, device=users.device),
+                         torch.empty(self.chunk, dtype=torch.int32, device=users.device)) for _ in range(2)]
+            self._pu = self._pi = None
+            self._gk, self._planned = 0, None
+        else:
+            self._pu = torch.empty_like(self.users)
+            self._pi = torch.empty_like(self.items)
         self._scalars = torch.zeros(4, dtype=torch.float32, device=users.device)
         self.item_sync, self.sync_every = item_sync, sync_every
         # shards are balanced by interactions, not equal: every rank runs the same number of
@@ -180,13 +192,15 @@ class StreamTrainer:
     # The epoch is written as a generator that yields after every launch (+ hot-tier exchange) and
     # after every chunk: `train_epoch` just runs it; a LocalWorld simulation (several ranks in one
     # process, revisit_bpr.distributed) resumes the ranks' generators round-robin.
-    def _launch(self, lo: int, hi: int, cut: bool = False):
+    def _launch(self, lo: int, hi: int, cut: bool = False, base: int = 0):
         hot = self.item_sync is not None and self.item_sync.hot_tier
         k = self.hot_split if hot else 1
+        pu, pi = self._cb[self._gk & 1] if self.jit_plan else (self._pu, self._pi)
+        lo, hi = lo - base, hi - base  # (jit_plan: positions inside the chunk buffer)
         for p in range(k):  # every rank runs k pieces, empty ones included: the exchanges line up
             a, b = lo + (hi - lo) * p // k, lo + (hi - lo) * (p + 1) // k
             if b > a:
-                self.engine.train_stream(self._pu[a:b], self._pi[a:b], sampler=self.sampler,
+                self.engine.train_stream(pu[a:b], pi[a:b], sampler=self.sampler,
                                          adaptive_p=self.adaptive_p, seed=self.seed,
                                          offset=(self.rank << 40) + self.drawn,
                                          max_inflight=self.max_inflight, scalars=self._scalars,
@@ -195,6 +209,10 @@ class StreamTrainer:
             if hot:
                 self.item_sync.hot_step()
             yield
+
+    def _plan(self, epoch: int, index: int, slot: int, on_side: bool) -> None:
+        self.engine.plan_chunk(self.users, self.items, self.chunk, self.seed + epoch, index,
+                               out=self._cb[slot & 1], on_side=on_side)
 
     def _chunk(self, lo: int, hi: int):
         e, lag = self.engine, self.refresh_lag
@@ -219,9 +237,21 @@ class StreamTrainer:
         cut = lo if lag >= 1.0 else min(hi, lo + max(1, int(round((1.0 - lag) * (hi - lo)))))
         if cut > lo:
             yield from self._launch(lo, cut)
+        base = 0
+        if self.jit_plan:
+            index = lo // self.chunk
+            if self._planned != (self.epoch, index):  # the first chunk: on the launch stream
+                self._plan(self.epoch, index, self._gk, False)
+            base = lo
         e.adaptive_refresh_begin()
+        if self.jit_plan:  # the next chunk, behind the sort just queued
+            nxt = (self.epoch, index + 1) if (index + 1) * self.chunk < self.n else (self.epoch + 1, 0)
+            self._plan(nxt[0], nxt[1], self._gk + 1, True)
+            self._planned = nxt
         if cut < hi:
-            yield from self._launch(cut, hi, cut=fused)
+            yield from self._launch(cut, hi, cut=fused, base=base)
+        if self.jit_plan:
+            self._gk += 1
 
     def stream_scope(self):
         """Context in which this trainer's calls must run: its CU-masked launch stream, if any."""
@@ -252,8 +282,9 @@ class StreamTrainer:
         """One epoch as a generator (see `_launch`); resume it inside `stream_scope()`."""
         e = self.engine
         self.model._reset_reg()
-        e.plan_epoch(self.users, self.items, self.chunk, self.seed + self.epoch,
-                     out=(self._pu, self._pi))
+        if not self.jit_plan:
+            e.plan_epoch(self.users, self.items, self.chunk, self.seed + self.epoch,
+                         out=(self._pu, self._pi))
         self._scalars.zero_()
         hot = self.item_sync is not None and self.item_sync.hot_tier
         for k in range(self.rounds):

@@ -116,6 +116,8 @@ SIGNATURES = {
     "bpr_hot_tier_end": (c_int, [c_void_p]),
     "bpr_plan_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_void_p,
                                c_void_p]),
+    "bpr_plan_chunk": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_int64, c_void_p,
+                               c_void_p, c_int32]),
     "bpr_flush_lazy": (c_int, [c_void_p]),
     "bpr_flush_items": (c_int, [c_void_p]),
     "bpr_get_step_host": (c_int, [c_void_p, POINTER(c_int64)]),

@@ -673,6 +673,39 @@ def test_stream_grouped_sequential_equals_b1_sgd(d, run_len):
     assert close(sc.cpu().numpy()[:3], sco[:3], 1e-4)
 
 
+@pytest.mark.parametrize("n,chunk,U", [(100_000, 9_984, 5000), (9_550_138 // 40, 199_168 // 8, 136_678), (777, 100, 60)])
+def test_plan_chunk_is_the_chunk_of_the_epoch_plan(n, chunk, U):
+    """bpr_plan_chunk(index) — the members of one chunk found through the INVERSE permutation and
+    sorted by user — is chunk `index` of bpr_plan_epoch with the same seed: the same multiset of
+    (user, positive) pairs, grouped by user; on the launch stream and queued on the split refresh's
+    side stream behind a sort in flight (the commit then waits for it)."""
+    rng = np.random.default_rng(n)
+    I, d = 300, 32
+    users = rng.integers(1, U, n).astype(np.int32)
+    pos = rng.integers(1, I, n).astype(np.int32)
+    e = make_engine(np.zeros((U, d), np.float32), rng.normal(0, 0.1, (I, d)).astype(np.float32))
+    u_d, p_d = dev(users), dev(pos)
+    for seed in (1, 7):
+        eu, ep = (t.cpu().numpy() for t in e.plan_epoch(u_d, p_d, chunk, seed=seed))
+        n_chunks = -(-n // chunk)
+        e.adaptive_refresh()
+        for index in range(n_chunks):
+            m = min(chunk, n - index * chunk)
+            out = (torch.empty(m, dtype=torch.int32, device="cuda"), torch.empty(m, dtype=torch.int32, device="cuda"))
+            on_side = index % 2 == 1
+            if on_side:
+                e.adaptive_refresh_begin()
+            e.plan_chunk(u_d, p_d, chunk, seed, index, out, on_side=on_side)
+            if on_side:
+                e.adaptive_refresh_commit()  # the launch stream now waits for the sort AND the plan
+            cu, cp = out[0].cpu().numpy(), out[1].cpu().numpy()
+            assert np.all(np.diff(cu) >= 0), "grouped by user"
+            want_u, want_p = eu[index * chunk:index * chunk + m], ep[index * chunk:index * chunk + m]
+            assert np.array_equal(cu, want_u)  # both are sorted by user: the user column is identical
+            key = lambda a, b: np.sort(a.astype(np.int64) * I + b)
+            assert np.array_equal(key(cu, cp), key(want_u, want_p)), (seed, index)
+
+
 def test_stream_grouped_matches_atomic_mode_at_full_concurrency():
     """Same planned chunk, full chip: register-resident user rows (grouped) and all-atomic user
     rows give the same tables up to second order in lr (both are asynchronous SGD)."""

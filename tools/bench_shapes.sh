@@ -9,10 +9,12 @@ for w in "netflix --dim 64" "ml-20m --dim 128" "msd --dim 256" "yelp --dim 128";
   run --workload $w --sampler uniform
   run --workload $w --sampler adaptive --refresh-lag 0
   run --workload $w --sampler adaptive --refresh-lag 1 --refresh-cus 64
+  run --workload $w --sampler adaptive   # the default: schedule by shape (fast.auto_schedule)
 done
 for d in 32 64 256 512; do
   run --workload ml-20m --dim $d --sampler adaptive --refresh-lag 0
   run --workload ml-20m --dim $d --sampler adaptive --refresh-lag 1 --refresh-cus 64
+  run --workload ml-20m --dim $d --sampler adaptive
 done
 echo "# launches of period / N triples (the per-rank step of an N-rank job at the job cadence), refresh between launches"
 for n in 2 4 8; do run --workload ml-20m --dim 128 --sampler adaptive --refresh-lag 0 --refresh-split $n; done

@@ -66,4 +66,22 @@ json.dump({"round": tag, "kernel": "k_stream<32,4,ADAPTIVE,bitmap>", "workload":
            "read_bytes_corrected": rd, "write_bytes": wr, "traffic_bytes_per_launch": rd + wr,
            "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950, calibrated in profiles/%s_pmc_traffic.md); write = WRITE_SIZE x 1024" % tag},
           open(P / f"traffic_{tag}.json", "w"), indent=1)
+# BASELINE configs[3]: MSD shape, d = 256 (k_stream<64,4,...>), when its passes were collected
+if (G / "pmc_fetch_msd" / "bench_counter_collection.csv").exists():
+    rm = {}
+    for name in ("pmc_fetch_msd", "pmc_write_msd"):
+        for (k, c), (n, v) in agg(G / name / "bench_counter_collection.csv").items():
+            if "k_stream<" in k:
+                rm[c] = v / n
+    chunk_msd = int(41141 * __import__("math").log(41141) / 256) * 256
+    rd, wr = 2 * rm["FETCH_SIZE"] * 1024, rm["WRITE_SIZE"] * 1024
+    alg = chunk_msd * (24 * 256 + 8)
+    with open(P / f"{tag}_pmc_traffic.md", "a") as f:
+        f.write(f"\n## MSD shape, d = 256 (BASELINE configs[3]): k_stream per launch ({chunk_msd} triples): read "
+                f"{rd / 1e6:.1f} MB (corrected), written {wr / 1e6:.1f} MB, total {(rd + wr) / 1e6:.1f} MB; "
+                f"algorithmic 24d+8 = 6152 B/triple -> {alg / 1e6:.1f} MB; traffic/algorithmic = {(rd + wr) / alg:.3f}\n")
+    json.dump({"round": tag, "kernel": "k_stream<64,4,ADAPTIVE,bitmap>", "workload": "msd d=256 adaptive",
+               "triples_per_launch": chunk_msd, "fetch_size_kb_raw": rm["FETCH_SIZE"], "write_size_kb": rm["WRITE_SIZE"],
+               "read_bytes_corrected": rd, "write_bytes": wr, "traffic_bytes_per_launch": rd + wr,
+               "correction": "as traffic_%s.json" % tag}, open(P / f"traffic_{tag}_msd_d256.json", "w"), indent=1)
 print(out[-3], out[-2], sep="\n")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/ is built from, in one GPU-box call:  bash tools/profile_round.sh r03
 # (then, back in the build container: python tools/make_profile_summary.py r03)
-T=${1:-r03}
+T=${1:-r04}
 R=/root/repo; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench_final.log 2>&1; tail -1 $O/bench_final.log > $O/bench_${T}_final.json
@@ -11,8 +11,12 @@ rm -rf $O/prof_$T $O/pmc_fetch $O/pmc_write $O/prof_${T}_adam $O/calib_fetch $O/
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o bench -- python $R/bench.py --steps 96 --warmup 8 --no-cpu-baseline > $O/prof_${T}_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}_sync -o bench -- python $R/bench.py --steps 96 --warmup 8 --no-cpu-baseline --refresh-lag 0 > $O/prof_${T}_sync.log 2>&1
 # HBM-side traffic of the dominant kernel: separate --pmc passes
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python $R/bench.py --steps 24 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python $R/bench.py --steps 24 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python $R/bench.py --steps 24 --warmup 4 --no-cpu-baseline --sustained-epochs 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python $R/bench.py --steps 24 --warmup 4 --no-cpu-baseline --sustained-epochs 0 > /dev/null 2>&1
+# the same two passes for BASELINE configs[3] (MSD shape, d = 256: the HBM-bound case)
+rm -rf $O/pmc_fetch_msd $O/pmc_write_msd
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_msd -o bench -- python $R/bench.py --workload msd --dim 256 --steps 12 --warmup 4 --no-cpu-baseline --sustained-epochs 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_msd -o bench -- python $R/bench.py --workload msd --dim 256 --steps 12 --warmup 4 --no-cpu-baseline --sustained-epochs 0 > /dev/null 2>&1
 # calibration of the two counters on known byte counts
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -o calib -- $R/tools/ubench/pmc_calib > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/calib_write -o calib -- $R/tools/ubench/pmc_calib > /dev/null 2>&1
