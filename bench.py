@@ -150,10 +150,11 @@ def parse_args():
     ap.add_argument("--item-skew", type=float, default=None,
                     help="override the item popularity exponent (debug: 0 = uniform popularity)")
     ap.add_argument("--ungrouped", action="store_true", help="all-atomic user rows (debug)")
-    ap.add_argument("--jit-plan", type=int, default=1,
-                    help="1 (default): with the overlapped snapshot schedule the epoch is never planned as a whole "
-                         "— every chunk is planned by bpr_plan_chunk on the side stream, one step ahead; 0: "
-                         "bpr_plan_epoch at every epoch boundary (r3)")
+    ap.add_argument("--jit-plan", type=int, default=0,
+                    help="1: with the overlapped snapshot schedule the epoch is never planned as a whole — every "
+                         "chunk is planned by bpr_plan_chunk on the side stream, one step ahead (measured SLOWER: "
+                         "624 M vs 748 M triples/s, profiles/r04_jit_plan.md); 0 (default): bpr_plan_epoch at "
+                         "every epoch boundary")
     ap.add_argument("--sustained-epochs", type=int, default=3,
                     help="after the timed region: this many WHOLE epochs (plan + every step) timed by wall "
                          "clock, reported as `sustained` (0 = skip)")

@@ -95,8 +95,8 @@ struct bpr_ctx {
   const int32_t* plan_pos = nullptr;
   int64_t plan_n = 0, plan_chunk = 0;
   // bpr_plan_chunk scratch: keys / values of one chunk before the by-user sort
-  uint32_t* pc_keys = nullptr;
-  int32_t* pc_vals = nullptr;
+  uint32_t *pc_keys = nullptr, *pc_keys2 = nullptr, *pc_cnt = nullptr;
+  int32_t *pc_vals = nullptr, *pc_vals2 = nullptr;
   void* pc_tmp = nullptr;
   size_t pc_tmp_bytes = 0;
   int64_t pc_cap = 0;

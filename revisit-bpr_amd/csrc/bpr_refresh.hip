@@ -409,6 +409,130 @@ __global__ void k_plan_chunk(const int32_t* __restrict__ users, const int32_t* _
   }
 }
 
+// ---- grouping one chunk by user in three small kernels (the chunk is planned on the CU-masked side
+// stream, where every kernel launch costs ~12 us: a device-wide radix sort of 199 k keys is NINE of
+// them).  Users fall into nb <= 2048 buckets of 2^shift consecutive ids: (1) members + bucket
+// histogram, (2) scatter into the buckets' ranges, (3) one workgroup per bucket orders its members by
+// user with a counting sort over the bucket's 2^shift ids in LDS.  Output: users ascending, the
+// order of one user's triples as the atomics fell.
+constexpr int PC_MAX_BUCKETS = 2048, PC_MAX_LOCAL = 1024;
+
+__global__ __launch_bounds__(256) void k_pc_members(const int32_t* __restrict__ users,
+                                                    const int32_t* __restrict__ pos, int64_t n, int64_t j0,
+                                                    int m, int half_bits, uint64_t seed, int shift,
+                                                    uint32_t* __restrict__ mu, int32_t* __restrict__ mp,
+                                                    uint32_t* __restrict__ cnt) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
+    const uint64_t t = feistel_inv((uint64_t)(j0 + k), (uint64_t)n, half_bits, seed);
+    const uint32_t u = (uint32_t)users[t];
+    mu[k] = u;
+    mp[k] = pos[t];
+    atomicAdd(&cnt[u >> shift], 1u);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pc_scatter(const uint32_t* __restrict__ mu,
+                                                    const int32_t* __restrict__ mp, int m, int shift, int nb,
+                                                    const uint32_t* __restrict__ cnt, uint32_t* __restrict__ cur,
+                                                    uint32_t* __restrict__ base_out, uint32_t* __restrict__ bu,
+                                                    int32_t* __restrict__ bp) {
+  __shared__ uint32_t base[PC_MAX_BUCKETS];
+  __shared__ uint32_t part[256];
+  // exclusive scan of the bucket counts, redundantly in every workgroup (nb <= 2048: 8 per thread)
+  const int per = (nb + 255) / 256;
+  uint32_t acc = 0;
+  for (int q = 0; q < per; ++q) {
+    const int b = threadIdx.x * per + q;
+    acc += b < nb ? cnt[b] : 0u;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int k = 0; k < 256; ++k) {
+      const uint32_t v = part[k];
+      part[k] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (int q = 0; q < per; ++q) {
+    const int b = threadIdx.x * per + q;
+    if (b < nb) {
+      base[b] = run;
+      if (blockIdx.x == 0) base_out[b] = run;
+      run += cnt[b];
+    }
+  }
+  __syncthreads();
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
+    const uint32_t u = mu[k];
+    const uint32_t b = u >> shift;
+    const uint32_t slot = base[b] + atomicAdd(&cur[b], 1u);
+    bu[slot] = u;
+    bp[slot] = mp[k];
+  }
+}
+
+__global__ __launch_bounds__(128) void k_pc_group(const uint32_t* __restrict__ bu, const int32_t* __restrict__ bp,
+                                                  int shift, uint32_t* __restrict__ cnt, uint32_t* __restrict__ cur,
+                                                  const uint32_t* __restrict__ base, int32_t* __restrict__ users_out,
+                                                  int32_t* __restrict__ pos_out) {
+  __shared__ uint32_t c[PC_MAX_LOCAL], o[PC_MAX_LOCAL];
+  const int b = blockIdx.x;
+  const uint32_t lo = base[b], sz = cnt[b];
+  const int L = 1 << shift;
+  const uint32_t mask = (uint32_t)L - 1u;
+  for (int k = threadIdx.x; k < L; k += blockDim.x) c[k] = 0u;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < sz; k += blockDim.x) atomicAdd(&c[bu[lo + k] & mask], 1u);
+  __syncthreads();
+  // exclusive scan over the bucket's ids (<= 1024): a segment per thread, the 128 segment sums by one
+  __shared__ uint32_t seg[128];
+  const int per = (L + 127) / 128;
+  {
+    uint32_t acc = 0;
+    for (int q = 0; q < per; ++q) {
+      const int k = threadIdx.x * per + q;
+      acc += k < L ? c[k] : 0u;
+    }
+    seg[threadIdx.x] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int k = 0; k < 128; ++k) {
+      const uint32_t v = seg[k];
+      seg[k] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  {
+    uint32_t run = seg[threadIdx.x];
+    for (int q = 0; q < per; ++q) {
+      const int k = threadIdx.x * per + q;
+      if (k < L) {
+        o[k] = run;
+        run += c[k];
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < sz; k += blockDim.x) {
+    const uint32_t u = bu[lo + k];
+    const uint32_t slot = lo + atomicAdd(&o[u & mask], 1u);
+    users_out[slot] = (int32_t)u;
+    pos_out[slot] = bp[lo + k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // the counters of this bucket are zero again for the next chunk
+    cnt[b] = 0u;
+    cur[b] = 0u;
+  }
+}
+
 static int bits_for(uint64_t v) {  // bits needed to represent values 0..v
   int b = 1;
   while ((v >> b) != 0) ++b;
@@ -492,10 +616,16 @@ int plan_chunk_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
   const int ubits = bits_for((uint64_t)(c->U - 1));
   if (c->pc_cap < m) {
     hipFree(c->pc_keys); hipFree(c->pc_vals); hipFree(c->pc_tmp);
-    c->pc_keys = nullptr; c->pc_vals = nullptr; c->pc_tmp = nullptr;
+    hipFree(c->pc_keys2); hipFree(c->pc_vals2); hipFree(c->pc_cnt);
+    c->pc_keys = c->pc_keys2 = nullptr; c->pc_vals = c->pc_vals2 = nullptr; c->pc_tmp = nullptr;
+    c->pc_cnt = nullptr;
     c->pc_cap = 0;
     BPR_HIP_CHECK(hipMalloc(&c->pc_keys, sizeof(uint32_t) * m));
     BPR_HIP_CHECK(hipMalloc(&c->pc_vals, sizeof(int32_t) * m));
+    BPR_HIP_CHECK(hipMalloc(&c->pc_keys2, sizeof(uint32_t) * m));
+    BPR_HIP_CHECK(hipMalloc(&c->pc_vals2, sizeof(int32_t) * m));
+    BPR_HIP_CHECK(hipMalloc(&c->pc_cnt, sizeof(uint32_t) * 3 * PC_MAX_BUCKETS));
+    BPR_HIP_CHECK(hipMemsetAsync(c->pc_cnt, 0, sizeof(uint32_t) * 3 * PC_MAX_BUCKETS, st));
     size_t bytes = 0;
     BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->pc_keys,
                                                      reinterpret_cast<uint32_t*>(users_out), c->pc_vals,
@@ -505,6 +635,22 @@ int plan_chunk_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
     c->pc_cap = m;
   }
   const unsigned grid = (unsigned)std::min<int64_t>((m + 255) / 256, 1024);
+  // three kernels when the users fit 2048 buckets of <= 1024 ids (U <= 2 M: every BASELINE shape);
+  // BPR_PLAN_CHUNK_SORT=1 forces the device-wide sort (tests)
+  const int shift = std::max(0, ubits - 11);
+  static const bool force_sort = getenv("BPR_PLAN_CHUNK_SORT") != nullptr;
+  if ((1 << shift) <= PC_MAX_LOCAL && !force_sort) {
+    const int nb = (int)(((c->U - 1) >> shift) + 1);
+    uint32_t *cnt = c->pc_cnt, *cur = c->pc_cnt + PC_MAX_BUCKETS, *base = c->pc_cnt + 2 * PC_MAX_BUCKETS;
+    hipLaunchKernelGGL(k_pc_members, dim3(grid), dim3(256), 0, st, users_in, pos_in, n, j0, (int)m, half_bits,
+                       seed, shift, c->pc_keys, c->pc_vals, cnt);
+    hipLaunchKernelGGL(k_pc_scatter, dim3(std::min(grid, 256u)), dim3(256), 0, st, c->pc_keys, c->pc_vals, (int)m,
+                       shift, nb, cnt, cur, base, c->pc_keys2, c->pc_vals2);
+    hipLaunchKernelGGL(k_pc_group, dim3(nb), dim3(128), 0, st, c->pc_keys2, c->pc_vals2, shift, cnt, cur, base,
+                       users_out, pos_out);
+    BPR_HIP_CHECK(hipGetLastError());
+    return BPR_OK;
+  }
   hipLaunchKernelGGL(k_plan_chunk, dim3(grid), dim3(256), 0, st, users_in, pos_in, n, j0, m, half_bits,
                      seed, c->pc_keys, c->pc_vals);
   size_t bytes = c->pc_tmp_bytes;
@@ -796,7 +942,9 @@ void refresh_free(bpr_ctx* c) {
   c->plan_cap = 0;
   if (c->side != nullptr) hipStreamSynchronize(c->side);
   hipFree(c->pc_keys); hipFree(c->pc_vals); hipFree(c->pc_tmp);
-  c->pc_keys = nullptr; c->pc_vals = nullptr; c->pc_tmp = nullptr;
+  hipFree(c->pc_keys2); hipFree(c->pc_vals2); hipFree(c->pc_cnt);
+  c->pc_keys = c->pc_keys2 = nullptr; c->pc_vals = c->pc_vals2 = nullptr; c->pc_tmp = nullptr;
+  c->pc_cnt = nullptr;
   c->pc_cap = 0;
   for (int k = 0; k < 2; ++k) {
     hipFree(c->order_alloc[k]);
