@@ -58,10 +58,13 @@ SCHEDULE_MULTI = {"refresh_lag": 0.0, "refresh_split": 1, "refresh_cus": 0}
 PARITY_OF_TIMED_SCHEDULE = {
     "tolerance_north_star": 0.002,
     "small_set_vs_reference_over_epoch_orders": {
-        "source": "profiles/e2e_parity_r04.txt (4,000 x 1,500 golden protocol, d=32, lr 0.05, 12 epochs)",
-        "note": "filled from the r4 run of tools/e2e_many_seeds.py; r3: plateau +0.0013 nDCG@100 / "
-                "+0.0009 Recall@20, epoch 4 +0.0036 / +0.0038 (the older snapshot learns the steep part "
-                "faster on this small set)"},
+        "source": "profiles/e2e_parity_r04.txt (4,000 x 1,500 golden protocol, d=32, lr 0.05, 12 epochs; n = 200 ours, "
+                  "64 reference runs over epoch orders)",
+        "ndcg@100": {"epoch2": [0.0033, 21.1], "epoch4": [0.0029, 7.3], "epoch12": [0.0012, 2.5]},
+        "recall@20": {"epoch2": [0.0033, 17.4], "epoch4": [0.0032, 6.3], "epoch12": [0.0012, 2.3]},
+        "format": "[diff, z]",
+        "note": "the older snapshot learns the steep part faster on this small set (a launch is a tenth of an "
+                "epoch); the reference-schedule path reads +0.0003 / -0.0005 at epoch 12"},
     "small_set_vs_reference_fixed_order": {
         "source": "profiles/r03_e2e_many_seeds.txt (n = 200 ours, 30 reference runs)",
         "ndcg@100": {"epoch2": [0.0041, 17.3], "epoch4": [0.0032, 6.3], "epoch12": [0.0018, 3.8]},
