@@ -124,6 +124,11 @@ def parse_args():
                          "The --tier-rows most popular rows are exchanged after every launch (two tiers)")
     ap.add_argument("--tier-rows", type=int, default=1024,
                     help="N>1, --cadence rank: rows of the hot tier (0 = one tier: r3's protocol)")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="N > 1 on ONE GPU: run the step a rank of an N-rank job runs — the chunk the cadence "
+                         "picks for N ranks, the hot-tier pass after every launch, the cold fold + delta pass and "
+                         "the un-fused snapshot cut per chunk — with the collectives left out (they run on a side "
+                         "stream; DESIGN.md §7 models them).  Measurement aid for the parts table")
     ap.add_argument("--hot-split", type=int, default=1,
                     help="N>1, hot tier: launches per step, with a hot-tier exchange after each")
     ap.add_argument("--no-shard-refresh", action="store_true",
@@ -362,8 +367,10 @@ def main():
     every = max(1, int(I * math.log(I) / args.batch_size))  # example.py:302
     period = min(every * args.batch_size, data.nnz)
     from revisit_bpr.fast import launches_per_period
-    ranks_per_period = (world if args.cadence == "job" else 1 if args.cadence == "rank" else
-                        launches_per_period(args.lr, world, period))
+    emu = args.emulate_ranks if (args.emulate_ranks > 1 and world == 1) else 0
+    cad_world = emu if emu else world
+    ranks_per_period = (cad_world if args.cadence == "job" else 1 if args.cadence == "rank" else
+                        launches_per_period(args.lr, cad_world, period))
     chunk = max(1, period // (split * ranks_per_period))
     n_chunks = max(1, data.nnz // chunk)
     src_users = torch.from_numpy(data.users).to(dev)
@@ -390,16 +397,16 @@ def main():
         total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         main_stream = eng.MaskedStream(dev, eng.cu_mask(total_cus - args.main_cus, args.main_cus, total_cus))
     sync = None
-    if world > 1:
+    if world > 1 or emu:
         tier = args.tier_rows if (args.cadence != "job" and not batched) else 0
-        sync = ItemSync([Q], engine=e, hot_rows=tier, local_items=src_items)
+        sync = ItemSync([Q], engine=e, hot_rows=tier, local_items=src_items, force_tiers=bool(emu))
     pieces = args.hot_split if (sync is not None and sync.hot_tier) else 1
     scalars = torch.zeros(4, device=dev)
     seed = args.seed
     given_neg = (torch.randint(1, I, (chunk,), device=dev, dtype=torch.int32)
                  if sampler == eng.NEG_GIVEN else None)  # measurement aid only
 
-    fused = lag >= 1.0 and world == 1  # the launch's epilogue cuts the next snapshot's keys
+    fused = lag >= 1.0 and world == 1 and not emu  # the launch's epilogue cuts the next snapshot's keys
 
     # --jit-plan (default with the overlapped schedule): no bpr_plan_epoch at all — chunk k + 1 is
     # planned by bpr_plan_chunk on the side stream behind the sort of step k (the plan does not depend
@@ -612,11 +619,12 @@ def main():
                 "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus,
                                      "sharded_over_ranks": bool(shard_refresh and not batched)},
                 "cadence": (f"{args.cadence}: {ranks_per_period} chunk(s) of {chunk} triples per rank and refresh "
-                            f"period (lr x N x chunk = {args.lr * world * chunk:.0f}, budget "
+                            f"period (lr x N x chunk = {args.lr * cad_world * chunk:.0f}, N = {cad_world}"
+                            f"{' EMULATED on one GPU, collectives left out' if emu else ''}, budget "
                             f"{__import__('revisit_bpr.fast', fromlist=['x']).STALENESS_BUDGET:.0f}); per chunk one "
                             f"snapshot refresh + one cold-row reconciliation, {pieces} launch(es), hot tier of "
                             f"{sync._hb.shape[0] if sync.hot_tier else 0} rows exchanged after every launch"
-                            ) if world > 1 else "single GPU",
+                            ) if (world > 1 or emu) else "single GPU",
                 "steps_per_epoch": n_chunks,
                 "plan_epoch": {"mode": ("per chunk, one step ahead, on the side stream behind the sort "
                                         "(bpr_plan_chunk): inside every step") if jit else "bpr_plan_epoch per epoch",

@@ -207,7 +207,7 @@ class ItemSync:
     def __init__(self, tensors: list[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
                  scale: float = 1.0, comm=None, engine=None, hot_rows: int = 0,
                  item_counts: Optional[torch.Tensor] = None,
-                 local_items: Optional[torch.Tensor] = None) -> None:
+                 local_items: Optional[torch.Tensor] = None, force_tiers: bool = False) -> None:
         self.tensors = [t.detach() for t in tensors if t is not None]
         self.group = group
         self.scale = scale  # 1.0: apply every rank's update; 1/world: DDP-style mean
@@ -230,7 +230,9 @@ class ItemSync:
         self.hot_tier = False
         self.top_share = self.cold_top_share = 0.0
         self._hot_pending = False
-        if hot_rows > 0 and self.world > 1:
+        # force_tiers: run both tiers' passes on ONE rank (collectives are no-ops) — bench.py
+        # --emulate-ranks measures what a rank's step costs beside its launch without a node
+        if hot_rows > 0 and (self.world > 1 or force_tiers):
             self._setup_hot(int(hot_rows), item_counts, local_items)
 
     def _setup_hot(self, H: int, item_counts, local_items) -> None:

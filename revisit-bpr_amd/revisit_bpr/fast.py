@@ -64,18 +64,24 @@ def auto_schedule(I: int, d: int, launch_triples: int, total_cus: int = 256) -> 
 # late: up to 2 x world x chunk triples of the job are applied against rows and a snapshot that do
 # not know them yet.  The study (full ML-20M shape, 1/2/4/8 ranks, three learning rates) puts the
 # edge of the +-0.002 nDCG@100 band at  lr x world x chunk ~ 4,000  (lr is per triple: the loss is a
-# sum): at lr 0.05 that asks for less than period / world — the floor, the single-GPU cadence counted
-# in job triples — and at the reference configs' lr 0.001 a full period per rank fits with room to spare.
+# sum): at lr 0.05 that is period / (2.5 world) — less than the single-GPU cadence counted in job
+# triples, which does miss the band at 8 ranks — and at the reference configs' lr 0.001 a full period
+# per rank fits with room to spare.
 STALENESS_BUDGET = 4_000.0
+
+
+MAX_CHUNKS_PER_RANK_SHARE = 4  # chunks may shrink to period / (4 x world), no further
 
 
 def launches_per_period(lr: float, world: int, period: int, budget: Optional[float] = None) -> int:
     """Chunks a rank cuts a refresh period into so that lr x world x chunk stays inside the budget:
-    1 (a full period per rank: "rank" cadence) .. world (period / world: "job" cadence)."""
+    1 (a full period per rank: "rank" cadence) .. world (period / world: "job" cadence, the
+    single-GPU cadence counted in job triples) .. 4 x world (aggressive learning rates: lr 0.05 at
+    8 ranks misses the band at the job cadence, profiles/r04_cadence_study.txt)."""
     if world <= 1:
         return 1
     budget = STALENESS_BUDGET if budget is None else budget
-    return int(min(max(math.ceil(period * lr * world / budget), 1), world))
+    return int(min(max(math.ceil(period * lr * world / budget), 1), MAX_CHUNKS_PER_RANK_SHARE * world))
 
 
 class StreamTrainer:

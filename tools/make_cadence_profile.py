@@ -12,7 +12,8 @@ HEAD = """# r4 multi-rank cadence study (VERDICT r3 item 1) — tools/cadence_st
 # adaptive sampler p = 0.01, L2 (0.0016, 0.0001, 0.00375), snapshot schedule lag 1 (what bench.py times).
 # Epochs per learning rate: lr 0.05: 4; lr 0.0094: 20 (evaluated every 5); lr 0.001: 160 (every 40).
 # Columns: cadence (job = period / N triples per rank and chunk; rank = a full period per rank; auto = the
-# staleness budget lr x N x chunk <= 4,000), H = rows of the hot tier (0 = one tier), s = launches per chunk with a
+# staleness budget lr x N x chunk <= 4,000: 1 .. 4 N chunks per period; 'auto(<=N)' = its first version, capped at
+# period / N), H = rows of the hot tier (0 = one tier), s = launches per chunk with a
 # hot exchange after each, world = ranks; nDCG@100 per evaluated epoch (seed mean), dnDCG = difference to the
 # 1-rank runs of the same invocation.
 """
@@ -23,7 +24,12 @@ def main():
     for f in sorted(glob.glob("gpurun_out/r04_study/lr*.txt")):
         for line in open(f):
             if line.startswith("# lr"):
-                rows.append(line[2:].rstrip())
+                line = line[2:].rstrip()
+                if "auto4N" in f:  # the shipped rule: up to 4 N chunks per period
+                    line = line.replace("cadence auto", "cadence auto(<=4N)")
+                elif "lr05_auto_H" in f:  # the first version of the rule: at most N chunks (= job cadence)
+                    line = line.replace("cadence auto", "cadence auto(<=N)")
+                rows.append(line)
     key = lambda r: (float(re.search(r"lr ([0-9.]+)", r).group(1)), r.split(" | ")[0], int(re.search(r"world (\d+)", r).group(1)))
     rows.sort(key=key)
     out = [HEAD]
