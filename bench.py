@@ -129,6 +129,9 @@ def parse_args():
                          "picks for N ranks, the hot-tier pass after every launch, the cold fold + delta pass and "
                          "the un-fused snapshot cut per chunk — with the collectives left out (they run on a side "
                          "stream; DESIGN.md §7 models them).  Measurement aid for the parts table")
+    ap.add_argument("--fuse-sync", type=int, default=1,
+                    help="N>1 (or --emulate-ranks): 1 = hot-tier step + cold step + snapshot cut as one pass "
+                         "(bpr_sync_cut); 0 = four kernels")
     ap.add_argument("--hot-split", type=int, default=1,
                     help="N>1, hot tier: launches per step, with a hot-tier exchange after each")
     ap.add_argument("--no-shard-refresh", action="store_true",
@@ -407,6 +410,11 @@ def main():
                  if sampler == eng.NEG_GIVEN else None)  # measurement aid only
 
     fused = lag >= 1.0 and world == 1 and not emu  # the launch's epilogue cuts the next snapshot's keys
+    # several ranks: the reconciliation passes and the cut are ONE pass after the launch (--fuse-sync 0: r4's
+    # first version, four kernels)
+    fused_sync = (lag >= 1.0 and sync is not None and sync.hot_tier and sync.can_fuse and args.sync_every == 1
+                  and bool(args.fuse_sync))
+    synced = [False]
 
     # --jit-plan (default with the overlapped schedule): no bpr_plan_epoch at all — chunk k + 1 is
     # planned by bpr_plan_chunk on the side stream behind the sort of step k (the plan does not depend
@@ -438,7 +446,10 @@ def main():
                                offset=(rank << 40) + k * chunk + (a - base),
                                max_inflight=args.max_inflight, scalars=scalars,
                                cut=cut and p == pieces - 1)
-                if sync is not None and sync.hot_tier:
+                if fused_sync and cut and p == pieces - 1:
+                    sync.step_cut()  # hot step + cold step + snapshot cut: one pass (bpr_sync_cut)
+                    synced[0] = True
+                elif sync is not None and sync.hot_tier:
                     sync.hot_step()
 
     def step(k: int):
@@ -474,11 +485,12 @@ def main():
                 planned.clear()
                 planned.add(k + 1)
             if cut < lo + chunk:
-                launch(k, cut, lo + chunk, lo, cut=fused)
-        if sync is not None and (k + 1) % args.sync_every == 0:
+                launch(k, cut, lo + chunk, lo, cut=fused or fused_sync)
+        if sync is not None and (k + 1) % args.sync_every == 0 and not synced[0]:
             if batched:
                 e.flush_items()
             sync.step()
+        synced[0] = False
 
     def barrier():
         torch.cuda.synchronize()

@@ -380,6 +380,15 @@ int bpr_hot_tier_begin(bpr_ctx* ctx, float* hot_base);
 int bpr_hot_exchange(bpr_ctx* ctx, float* hot_base, float* tot, int32_t fold_prev, int32_t cut,
                      float* cold_base);
 int bpr_hot_tier_end(bpr_ctx* ctx);
+/* Everything a rank does to the item table between two launches, in ONE pass (r4): the hot-tier
+ * exchange step (as bpr_hot_exchange with cut = 1), the cold tier's step (cold_mode 2: as
+ * bpr_item_fold_delta; 1: as bpr_item_delta; 0: none) and the cut of the next adaptive snapshot's
+ * keys (as bpr_train_stream_cut's epilogue: the next bpr_adaptive_refresh_begin only queues the
+ * sort).  Call it right after a bpr_train_stream_cut issued under the hot tier — that launch leaves
+ * its epilogue (the loss partials) to this pass — and all-reduce hot_tot and cold_tot afterwards.
+ * Four kernels and their boundaries (53 us measured) become one. */
+int bpr_sync_cut(bpr_ctx* ctx, float* hot_base, float* hot_tot, int32_t hot_fold_prev, float* cold_base,
+                 float* cold_own, float* cold_tot, float scale, int32_t cold_mode);
 
 /* Epoch order for STREAM mode — replaces DataLoader(shuffle=True, generator=manual_seed(seed))
  * (example.py:307-321; experiments/bpr/exp.py:109-118): a seeded pseudo-random partition of the n

@@ -115,6 +115,11 @@ struct bpr_ctx {
   // hot_tier is on the launches leave their deltas in the block for bpr_hot_exchange
   bool hot_explicit = false;
   bool hot_tier = false;
+  // bpr_train_stream_cut under the hot tier: the launch's epilogue (loss partials) is left to the
+  // bpr_sync_cut that must follow
+  int defer_blocks = 0;
+  float* defer_out = nullptr;
+  bool defer_pending = false;
   int32_t* hot_canon = nullptr;  // [hot_H]
   int64_t hot_key_n = 0;
   // heavy users' seen bitmaps (built once per seen CSR, by the first sampling STREAM launch)

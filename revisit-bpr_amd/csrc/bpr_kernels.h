@@ -224,6 +224,122 @@ __global__ __launch_bounds__(256) void k_stream_epilogue_cut(const EpilogueCutAr
   }
 }
 
+// The multi-GPU form of that pass (r4, bpr_sync_cut): between two launches a rank of an N-rank job
+// folds the hot exchange in flight and cuts the next one (k_hot_step), folds the cold reconciliation
+// in flight and cuts the next delta (k_item_fold_delta), and cuts the keys of its next snapshot
+// (k_transpose) — four kernels and four boundaries, 53 us measured (bench.py --emulate-ranks 8).
+// Every one of them is an elementwise pass over the item table: here they are ONE, tile by tile as
+// the cut needs it.  Per element of a HOT row (slot s, canonical index c):
+//     hb[c] += htot[c] (fold_prev);  dl = sum of delta replicas, delta = 0;  htot[c] = dl;
+//     q = hb[c] + dl;  cold base = q, cold own = tot = 0   (hot rows travel in the hot tier only)
+// of a COLD row:   cold_mode 2: st = scale*tot; base += st; q += st - own; own = tot = q - base
+//                  cold_mode 1: own = tot = q - base          (0: no cold tier this step)
+// and T[f, i] = q.  The statistics row sums the launch's loss partials (deferred epilogue).
+// (Streaming / nontemporal accesses to the four reconciliation buffers were tried: 29 us instead
+// of 21 for the pass, same gaps.  Plain.)
+struct SyncCutArgs {
+  EpilogueCutArgs e;
+  const int32_t* canon;
+  float* hb;
+  float* htot;
+  float* base;
+  float* own;
+  float* tot;
+  float scale;
+  int32_t hot_tier, hot_fold_prev, cold_mode;
+};
+
+__global__ __launch_bounds__(256) void k_sync_cut(const SyncCutArgs a) {
+  const EpilogueCutArgs& e = a.e;
+  if (blockIdx.y == gridDim.y - 1) {  // the statistics row
+    if (blockIdx.x != 0) return;
+    for (int k = threadIdx.x; k < 2 * e.d; k += 256) e.sig_acc[k] = 0.0;
+    if (e.out == nullptr) return;
+    __shared__ double red[256][4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < e.n_blocks; b += 256)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += (double)e.partials[(int64_t)b * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
+      __syncthreads();
+    }
+    if (threadIdx.x < 4) e.out[threadIdx.x] += (float)red[0][threadIdx.x];
+    return;
+  }
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t i0 = (int64_t)blockIdx.x * 32;
+  const int f0 = blockIdx.y * 32;
+  const int d = e.d;
+  const int64_t hd = (int64_t)e.H * d;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int64_t i = i0 + ty + r;
+    const int f = f0 + tx;
+    float v = 0.f;
+    if (i < e.I && f < d) {
+      const int64_t q = i * d + f;
+      v = e.Q[q];
+      const int32_t s = e.hot_slot != nullptr ? e.hot_slot[i] : -1;
+      if (s >= 0) {
+        float dl = 0.f;
+        for (int rep = 0; rep < e.R; ++rep) {
+          float* p = e.delta + rep * hd + (int64_t)s * d + f;
+          dl += *p;
+          *p = 0.f;
+        }
+        if (a.hot_tier) {
+          const int64_t c = (int64_t)a.canon[s] * d + f;
+          float b = a.hb[c];
+          if (a.hot_fold_prev) b += a.htot[c];
+          a.hb[c] = b;
+          a.htot[c] = dl;
+          v = b + dl;
+          if (a.cold_mode != 0) {
+            a.base[q] = v;
+            a.own[q] = 0.f;
+            a.tot[q] = 0.f;
+          }
+        } else {
+          v += dl;
+        }
+        e.Q[q] = v;
+      }
+      if (s < 0 || !a.hot_tier) {
+        if (a.cold_mode == 2) {
+          const float st = a.scale * a.tot[q];
+          const float nb = a.base[q] + st;
+          const float nq = v + (st - a.own[q]);
+          const float dl = nq - nb;
+          a.base[q] = nb;
+          a.own[q] = dl;
+          a.tot[q] = dl;
+          v = nq;
+          e.Q[q] = v;
+        } else if (a.cold_mode == 1) {
+          const float dl = v - a.base[q];
+          a.own[q] = dl;
+          a.tot[q] = dl;
+        }
+      }
+    }
+    tile[ty + r][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int f = f0 + ty + r;
+    const int64_t i = i0 + tx;
+    if (f < d && i < e.I) e.T[(int64_t)f * e.I + i] = tile[tx][ty + r];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // STREAM: the throughput kernel.
 //

@@ -344,11 +344,9 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     const unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
     a.bm_words = lds_words;
     const bool hot = a.hot_slot != nullptr;
-    if (cut && hot && c->hot_tier) {
-      set_error("bpr_train_stream_cut: the hot tier is on — the fold belongs to bpr_hot_exchange, the "
-                "cut to bpr_adaptive_refresh_begin after it");
-      return BPR_ERR_INVALID;
-    }
+    // hot tier + cut: fold, reconciliation passes and snapshot cut are ONE pass, bpr_sync_cut, which the
+    // caller issues next; the launch leaves it its loss partials too
+    const bool defer = cut && hot && c->hot_tier;
     if (cut && c->ev_keys == nullptr) {
       BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
       BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
@@ -367,7 +365,11 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       };
       pick(go);
     }
-    if (cut) {
+    if (defer) {
+      c->defer_blocks = (int)grid;
+      c->defer_out = out_scalars;
+      c->defer_pending = true;
+    } else if (cut) {
       // the epilogue also cuts the next snapshot's keys (k_stream_epilogue_cut) — into the key
       // buffer the split refresh that may still be sorting does NOT read (bpr_ctx.h keysT_buf)
       EpilogueCutArgs ea;
@@ -1146,6 +1148,40 @@ int bpr_set_heavy_users(bpr_ctx* c, int32_t threshold, int64_t max_bytes) {
   c->heavy_T_opt = threshold;
   if (max_bytes > 0) c->heavy_max_bytes = max_bytes;
   c->heavy_for = nullptr;  // rebuilt by the next sampling STREAM launch
+  return BPR_OK;
+}
+
+int bpr_sync_cut(bpr_ctx* c, float* hot_base, float* hot_tot, int32_t hot_fold_prev, float* cold_base,
+                 float* cold_own, float* cold_tot, float scale, int32_t cold_mode) {
+  if (int rc = check_bound(c, "bpr_sync_cut")) return rc;
+  if (cold_mode < 0 || cold_mode > 2 || (cold_mode != 0 && (!cold_base || !cold_own || !cold_tot)))
+    return fail(BPR_ERR_INVALID, "bpr_sync_cut: cold_mode 0 | 1 | 2 with base / own / tot");
+  if (c->hot_tier && (hot_base == nullptr || hot_tot == nullptr))
+    return fail(BPR_ERR_INVALID, "bpr_sync_cut: the hot tier is on: hot_base / hot_tot needed");
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = refresh_alloc(c)) return rc;
+  if (c->ev_keys == nullptr) {
+    BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
+    BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
+  }
+  SyncCutArgs a;
+  memset(&a, 0, sizeof(a));
+  const bool hot = c->hot_H > 0;
+  a.e.partials = c->dev_scalars;
+  a.e.n_blocks = c->defer_pending ? c->defer_blocks : 0;
+  a.e.out = c->defer_pending ? c->defer_out : nullptr;
+  a.e.Q = c->Q; a.e.delta = c->hot_delta; a.e.hot_slot = hot ? c->hot_slot : nullptr;
+  a.e.T = c->keysT; a.e.sig_acc = c->sig_acc;
+  a.e.H = hot ? c->hot_H : 0; a.e.R = c->hot_R; a.e.d = c->d; a.e.I = (int32_t)c->I;
+  a.canon = c->hot_canon; a.hb = hot_base; a.htot = hot_tot;
+  a.base = cold_base; a.own = cold_own; a.tot = cold_tot; a.scale = scale;
+  a.hot_tier = c->hot_tier ? 1 : 0; a.hot_fold_prev = hot_fold_prev != 0; a.cold_mode = cold_mode;
+  dim3 eg((unsigned)((c->I + 31) / 32), (unsigned)((c->d + 31) / 32) + 1u);
+  hipExtLaunchKernelGGL(k_sync_cut, eg, dim3(256), 0, c->stream, nullptr, c->ev_keys, 0, a);
+  BPR_HIP_CHECK(hipGetLastError());
+  c->defer_pending = false;
+  c->keys_cut = true;   // the next bpr_adaptive_refresh_begin only queues the sort
+  c->keys_event = true;
   return BPR_OK;
 }
 

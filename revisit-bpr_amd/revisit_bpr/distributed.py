@@ -357,6 +357,38 @@ class ItemSync:
                                  cold_base=self.base[0])
         self._hot_pending = False
 
+    @property
+    def can_fuse(self) -> bool:
+        """`step_cut` is available: a ROCm engine whose item table is tensors[0]."""
+        return self.engine is not None and self._lib is not None and bool(self.tensors) and \
+            self.engine.Q.data_ptr() == self.tensors[0].data_ptr()
+
+    @torch.no_grad()
+    def step_cut(self) -> None:
+        """`hot_step()` + `step()` + the cut of the engine's next adaptive snapshot as ONE pass over the
+        item table (`bpr_sync_cut`), right after a `train_stream(cut=True)`: the three elementwise
+        kernels a rank runs between two launches, and their boundaries, become one.  The same two
+        all-reduces are launched afterwards, in the same order."""
+        if self._hot_pending:
+            self.comm.complete([self._htot], "hot")
+        if self._pending:
+            self.comm.complete(self._tot, "cold")
+        hot = self.hot_tier
+        self.engine.sync_cut(self._hb if hot else None, self._htot if hot else None, self._hot_pending,
+                             self.base[0], self._own[0], self._tot[0], self.scale, 2 if self._pending else 1)
+        for t, b, own, tot in list(zip(self.tensors, self.base, self._own, self._tot))[1:]:  # item bias
+            if self._pending:
+                self._check(self._lib.bpr_item_fold_delta(t.data_ptr(), b.data_ptr(), own.data_ptr(),
+                                                          tot.data_ptr(), self.scale, t.numel(),
+                                                          torch.cuda.current_stream().cuda_stream))
+            else:
+                self._delta(t, b, own, tot)
+        if hot:
+            self.comm.launch([self._htot], "hot")
+            self._hot_pending = True
+        self.comm.launch(self._tot, "cold")
+        self._pending = True
+
     def close(self) -> None:
         """Leave the hot tier (launches fold their hot block themselves again)."""
         if self.hot_tier:

@@ -527,6 +527,14 @@ class Engine:
         native.check(self._lib.bpr_hot_exchange(self._ctx, hot_base.data_ptr(), tot.data_ptr(),
                                                 int(fold_prev), int(cut), _ptr(cold_base)))
 
+    def sync_cut(self, hot_base, hot_tot, hot_fold_prev: bool, cold_base, cold_own, cold_tot, scale: float,
+                 cold_mode: int) -> None:
+        """`bpr_sync_cut`: hot-tier step + cold-tier step + the cut of the next snapshot's keys in one
+        pass over the item table (after a `train_stream(cut=True)` under the hot tier)."""
+        self._sync_stream()
+        native.check(self._lib.bpr_sync_cut(self._ctx, _ptr(hot_base), _ptr(hot_tot), int(hot_fold_prev),
+                                            _ptr(cold_base), _ptr(cold_own), _ptr(cold_tot), scale, cold_mode))
+
     def hot_tier_end(self) -> None:
         native.check(self._lib.bpr_hot_tier_end(self._ctx))
 

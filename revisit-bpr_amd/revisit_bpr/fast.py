@@ -186,6 +186,7 @@ class StreamTrainer:
             self._pu = torch.empty_like(self.users)
             self._pi = torch.empty_like(self.items)
         self._scalars = torch.zeros(4, dtype=torch.float32, device=users.device)
+        self._synced = False  # this chunk's reconciliation already ran (fused into the launch's cut)
         self.item_sync, self.sync_every = item_sync, sync_every
         # shards are balanced by interactions, not equal: every rank runs the same number of
         # rounds per epoch (a rank out of triples still joins the item reconciliations)
@@ -212,6 +213,13 @@ class StreamTrainer:
                                          max_inflight=self.max_inflight, scalars=self._scalars,
                                          cut=cut and p == k - 1)
                 self.drawn += b - a
+                if cut and p == k - 1 and self.item_sync is not None:
+                    # several ranks: the launch left its epilogue to ONE pass that also runs the
+                    # hot-tier step, the cold step and the cut of the next snapshot (bpr_sync_cut)
+                    self.item_sync.step_cut()
+                    self._synced = True
+                    yield
+                    continue
             if hot:
                 self.item_sync.hot_step()
             yield
@@ -235,7 +243,10 @@ class StreamTrainer:
         # with one launch per snapshot (lag 1) and nothing touching the item table between two
         # launches (no item reconciliation) the keys of the NEXT snapshot are cut by the epilogue
         # of this launch: `begin` then only queues the sort
-        fused = lag >= 1.0 and self.item_sync is None
+        # ... and with an item reconciliation: when that reconciliation and the cut are one pass
+        # (ItemSync.step_cut after the launch: one reconciliation per chunk, engine-backed)
+        fused = lag >= 1.0 and (self.item_sync is None or
+                                (self.item_sync.can_fuse and self.sync_every == 1 and self.item_sync.hot_tier))
         if e.refresh_pending():
             e.adaptive_refresh_commit()  # the snapshot cut before the previous launch
         else:
@@ -310,8 +321,9 @@ class StreamTrainer:
                     if hot:
                         self.item_sync.hot_step()
                     yield
-            if self.item_sync is not None and (k + 1) % self.sync_every == 0:
+            if self.item_sync is not None and (k + 1) % self.sync_every == 0 and not self._synced:
                 self.item_sync.step()
+            self._synced = False
             yield
         if self.item_sync is not None:
             self.item_sync.hot_finish()

@@ -114,6 +114,8 @@ SIGNATURES = {
     "bpr_hot_tier_begin": (c_int, [c_void_p, c_void_p]),
     "bpr_hot_exchange": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "bpr_hot_tier_end": (c_int, [c_void_p]),
+    "bpr_sync_cut": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_float,
+                             c_int32]),
     "bpr_plan_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_void_p,
                                c_void_p]),
     "bpr_plan_chunk": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_int64, c_void_p,

@@ -31,8 +31,12 @@ def _problem(U, I, d, n, seed):
     return P, Q, indptr, np.concatenate(rows), users, pos
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("world,hot_split,H,d", [(2, 1, 16, 64), (3, 2, 40, 128), (4, 3, 8, 256)])
-def test_two_tier_equals_the_dense_protocol(world, hot_split, H, d):
+def test_two_tier_equals_the_dense_protocol(world, hot_split, H, d, fused):
+    """fused: the last launch of a round leaves its epilogue to ONE pass — hot-tier step + cold step +
+    the cut of the next snapshot's keys (bpr_sync_cut, ItemSync.step_cut) — instead of three kernels;
+    same tables, and the snapshot sorted from that cut is the oracle's order of the table."""
     from revisit_bpr import engine as eng
     from revisit_bpr.distributed import ItemSync, LocalWorld
 
@@ -57,10 +61,10 @@ def test_two_tier_equals_the_dense_protocol(world, hot_split, H, d):
         a, b = lo + n_round * p // hot_split, lo + n_round * (p + 1) // hot_split
         return a, b
 
-    def launch(e, r, k, p):
+    def launch(e, r, k, p, cut=False):
         a, b = piece(r, k, p)
         e.train_stream(u_d[a:b], p_d[a:b], sampler=eng.NEG_UNIFORM, seed=7, offset=(r << 40) + a,
-                       max_inflight=1)
+                       max_inflight=1, cut=cut)
 
     # ---- the product: ItemSync with the hot tier over LocalWorld
     lw = LocalWorld(world)
@@ -69,13 +73,26 @@ def test_two_tier_equals_the_dense_protocol(world, hot_split, H, d):
              for r in range(world)]
     assert all(s.hot_tier for s in syncs) and es[0].hot_rows() == H
     hot = syncs[0].hot_items.numpy()
+    import oracle
+
     for k in range(rounds):
         for p in range(hot_split):
             for r in range(world):
-                launch(es[r], r, k, p)
-                syncs[r].hot_step()
+                last = fused and p == hot_split - 1
+                launch(es[r], r, k, p, cut=last)
+                if last:
+                    syncs[r].step_cut()
+                else:
+                    syncs[r].hot_step()
         for r in range(world):
-            syncs[r].step()
+            if not fused:
+                syncs[r].step()
+        if fused:  # the cut rode on the fused pass: begin only queues the sort
+            q_now = es[0].Q.cpu().numpy()
+            es[0].adaptive_refresh_begin()
+            es[0].adaptive_refresh_commit()
+            QT, _ = oracle.adaptive_stats(q_now)
+            assert np.array_equal(es[0].adaptive_snapshot()[0].cpu().numpy(), oracle.adaptive_order(QT)), k
     for r in range(world):
         syncs[r].hot_finish()
         syncs[r].finish()
