@@ -27,6 +27,8 @@ def main():
                 line = line[2:].rstrip()
                 if "auto4N" in f:  # the shipped rule: up to 4 N chunks per period
                     line = line.replace("cadence auto", "cadence auto(<=4N)")
+                elif "autofused" in f:  # the shipped trainer: reconciliation passes + cut as one pass (bpr_sync_cut)
+                    line = line.replace("cadence auto", "cadence auto(fused pass)")
                 elif "lr05_auto_H" in f:  # the first version of the rule: at most N chunks (= job cadence)
                     line = line.replace("cadence auto", "cadence auto(<=N)")
                 rows.append(line)
