@@ -160,3 +160,70 @@ def test_uneven_shards_keep_collectives_matched():
     out = mgr.dict()
     mp.spawn(_worker_rounds, args=(2, _free_port(), out), nprocs=2, join=True)
     assert dict(out) == {0: (4, 250, 250.0, 390.0), 1: (4, 390, 250.0, 390.0)}
+
+
+def test_local_world_runs_the_item_sync_protocol_in_one_process():
+    """distributed.LocalWorld: N ranks of ItemSync in ONE process, the all-reduce resolved when the
+    last rank has contributed — the same tables as the protocol's algebra written out (every rank's
+    delta of step k reaches the others one step later, the bases stay bit-identical), for the fused
+    step() and for start() / finish(); reading a sum before every rank contributed raises."""
+    from revisit_bpr.distributed import LocalWorld
+
+    world, I, d, steps = 4, 37, 8, 5
+    g = torch.Generator().manual_seed(3)
+    Q0 = torch.randn(I, d, generator=g)
+    upd = [[torch.randn(I, d, generator=g) * 0.01 for _ in range(world)] for _ in range(steps)]
+    lw = LocalWorld(world)
+    Qs = [Q0.clone() for _ in range(world)]
+    syncs = [ItemSync([Qs[r]], comm=lw.member(r)) for r in range(world)]
+    assert all(s.world == world and s.rank == r for r, s in enumerate(syncs))
+    for k in range(steps):
+        for r in range(world):
+            Qs[r] += upd[k][r]
+            syncs[r].step()
+    for r in range(world):
+        syncs[r].finish()
+    want = Q0 + sum(sum(u) for u in upd)
+    for r in range(world):
+        assert torch.allclose(Qs[r], want, atol=1e-5)
+        assert torch.equal(syncs[r].base[0], syncs[0].base[0])
+    # one step late: after step k (before finish) rank r holds its own updates up to k and the
+    # others' up to k - 1
+    lw = LocalWorld(2)
+    Qs = [Q0.clone() for _ in range(2)]
+    syncs = [ItemSync([Qs[r]], comm=lw.member(r)) for r in range(2)]
+    for k in range(2):
+        for r in range(2):
+            Qs[r] += upd[k][r]
+            syncs[r].step()
+    assert torch.allclose(Qs[0], Q0 + upd[0][0] + upd[1][0] + upd[0][1], atol=1e-6)
+    assert torch.allclose(Qs[1], Q0 + upd[0][1] + upd[1][1] + upd[0][0], atol=1e-6)
+    # a rank that reads before the others contributed
+    lw = LocalWorld(2)
+    a = ItemSync([Q0.clone()], comm=lw.member(0))
+    ItemSync([Q0.clone()], comm=lw.member(1))
+    a.start()
+    with pytest.raises(RuntimeError, match="round-robin"):
+        a.finish()
+
+
+def test_staleness_budget_and_schedule_rules():
+    """fast.launches_per_period: lr x world x chunk <= STALENESS_BUDGET — a full
+    period per rank at the benchmark config's lr 0.001 for up to 8 ranks, 1 / 2 / 4 chunks at the
+    reference's tuned lr 0.0094, period / 2.5 N at lr 0.05 (capped at 4 N); fast.auto_schedule: the
+    overlapped snapshot schedule on 64 CUs for the ML-20M shape, on 96 for MSD d = 256."""
+    from revisit_bpr import fast
+
+    period = 199_168
+    assert [fast.launches_per_period(0.001, w, period) for w in (1, 2, 4, 8)] == [1, 1, 1, 1]
+    assert [fast.launches_per_period(0.0094, w, period) for w in (1, 2, 4, 8)] == [1, 1, 2, 4]
+    assert [fast.launches_per_period(0.05, w, period) for w in (1, 2, 4, 8)] == [1, 5, 10, 20]
+    assert fast.launches_per_period(1.0, 8, period) == 4 * 8
+    for lr in (0.001, 0.0094, 0.05):
+        for w in (2, 4, 8):
+            k = fast.launches_per_period(lr, w, period)
+            assert k == 4 * w or lr * w * (period / k) <= fast.STALENESS_BUDGET
+    assert fast.auto_schedule(20109, 128, period) == (1.0, 64)
+    assert fast.auto_schedule(41141, 256, 436_992) == (1.0, 96)
+    lag, cus = fast.auto_schedule(4800, 64, 40_704)
+    assert lag == 1.0 and cus == 64
