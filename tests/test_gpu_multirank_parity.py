@@ -236,7 +236,7 @@ def test_eight_rank_job_over_gloo():
     launch, cold all-reduce and snapshot refresh per chunk), and the curve is the one-process curve
     (2 seeds: a plumbing check with a loose band — the statistical gate is the test above)."""
     env = dict(os.environ, BPR_DIST_BACKEND="gloo", BPR_CADENCE="auto", BPR_HOT_ROWS="1024", BPR_LR="0.0094",
-               BPR_EPOCHS="12")
+               BPR_EPOCHS="9")
     args = ["adaptive", "1,2", "stream-lag", "full"]
     one = subprocess.run([sys.executable, str(ROOT / "tools" / "parity_multi.py"), *args], env=env,
                          capture_output=True, text=True, timeout=900)
@@ -251,7 +251,7 @@ def test_eight_rank_job_over_gloo():
     assert len(a) == 2 and len(b) == 2 and all(r["world"] == 8 for r in b)
     da = np.mean([r["ndcg@100"][-1] for r in a])
     db = np.mean([r["ndcg@100"][-1] for r in b])
-    print(f"8 processes over gloo vs 1: nDCG@100 after 12 epochs {db:.4f} vs {da:.4f}")
-    # (epoch 12 of 20 is on the rising part of the curve, where 8 ranks trail one by up to 0.01:
+    print(f"8 processes over gloo vs 1: nDCG@100 after 9 epochs {db:.4f} vs {da:.4f}")
+    # (epoch 9 of 20 is on the rising part of the curve, where 8 ranks trail one by up to 0.01:
     # profiles/r04_cadence_study.txt, dnDCG at epoch 10; the plateau is the gate above)
-    assert da > 0.3 and abs(db - da) < 0.02, (da, db)
+    assert da > 0.25 and abs(db - da) < 0.02, (da, db)
