@@ -166,6 +166,9 @@ def parse_args():
                          "chunk is planned by bpr_plan_chunk on the side stream, one step ahead (measured SLOWER: "
                          "624 M vs 748 M triples/s, profiles/r04_jit_plan.md); 0 (default): bpr_plan_epoch at "
                          "every epoch boundary")
+    ap.add_argument("--async-cut", type=int, default=0,
+                    help="1: the cut of the next snapshot runs on the side stream beside the next launch "
+                         "(bpr_train_stream_acut) instead of between two launches")
     ap.add_argument("--sustained-epochs", type=int, default=3,
                     help="after the timed region: this many WHOLE epochs (plan + every step) timed by wall "
                          "clock, reported as `sustained` (0 = skip)")
@@ -415,6 +418,9 @@ def main():
     fused_sync = (lag >= 1.0 and sync is not None and sync.hot_tier and sync.can_fuse and args.sync_every == 1
                   and bool(args.fuse_sync))
     synced = [False]
+    # --async-cut: the snapshot cut leaves the launch stream (bpr_train_stream_acut: a read-only pass on the
+    # side stream beside the next launch); the hot rows are folded before the tables are read
+    acut = bool(args.async_cut) and fused
 
     # --jit-plan (default with the overlapped schedule): no bpr_plan_epoch at all — chunk k + 1 is
     # planned by bpr_plan_chunk on the side stream behind the sort of step k (the plan does not depend
@@ -445,7 +451,7 @@ def main():
                                adaptive_p=args.adaptive_p, seed=seed,
                                offset=(rank << 40) + k * chunk + (a - base),
                                max_inflight=args.max_inflight, scalars=scalars,
-                               cut=cut and p == pieces - 1)
+                               cut=(("async" if acut else True) if (cut and p == pieces - 1) else False))
                 if fused_sync and cut and p == pieces - 1:
                     sync.step_cut()  # hot step + cold step + snapshot cut: one pass (bpr_sync_cut)
                     synced[0] = True
@@ -524,6 +530,8 @@ def main():
         if sync is not None:
             sync.hot_finish()
             sync.finish()
+        if acut:
+            e.hot_fold()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         barrier()
@@ -540,6 +548,8 @@ def main():
             if sync is not None:
                 sync.hot_finish()
                 sync.finish()
+            if acut:
+                e.hot_fold()
             torch.cuda.synchronize()
             sus_dt = time.perf_counter() - ts
             barrier()

@@ -285,6 +285,19 @@ int bpr_train_stream(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int
 int bpr_train_stream_cut(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
                          int64_t n, int32_t sampler, float adaptive_p, uint64_t seed,
                          uint64_t offset, int64_t max_inflight, float* out_scalars);
+/* The same launch with the cut taken OFF the launch stream (r4): the keys of the next snapshot are cut
+ * by a read-only pass on the split refresh's side stream, behind this launch and BESIDE the next one —
+ * the launch stream runs launch after launch with nothing in between.  Two consequences, both inside
+ * the asynchrony the STREAM mode already has: the snapshot's point in time is "after
+ * this launch, plus whatever the next launch did in the ~20 us the cut takes"; and the hot rows'
+ * deltas are NOT folded into the item table by the launch — every other entry point of the ctx folds
+ * them first (the table is whole for whoever looks through the library), and a caller who reads the
+ * item table's storage directly (eval, checkpoint) calls bpr_hot_fold before.  out_scalars is added
+ * to by the side-stream pass: read it after bpr_hot_fold or a device synchronisation. */
+int bpr_train_stream_acut(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
+                          int64_t n, int32_t sampler, float adaptive_p, uint64_t seed,
+                          uint64_t offset, int64_t max_inflight, float* out_scalars);
+int bpr_hot_fold(bpr_ctx* ctx);
 
 /* BATCHED STREAM — the single-launch throughput path for every optimizer kind (SGD, momentum /
  * Nesterov, Adam, RMSprop; configs/RQ3/time-split/ada-sampling-adam.yaml.j2:169-175 and 14 of the

@@ -117,6 +117,13 @@ struct bpr_ctx {
   bool hot_tier = false;
   // bpr_train_stream_cut under the hot tier: the launch's epilogue (loss partials) is left to the
   // bpr_sync_cut that must follow
+  // bpr_train_stream_acut: the cut of the next snapshot runs on the side stream beside the NEXT
+  // launch and folds nothing — the hot deltas stay in the block until somebody needs the table
+  // whole (hot_fold_impl: every other entry point, bpr_hot_fold)
+  bool hot_unfolded = false;
+  bool acut_call = false;
+  int acut_parity = 0;
+  hipEvent_t ev_launch = nullptr;
   int defer_blocks = 0;
   float* defer_out = nullptr;
   bool defer_pending = false;
@@ -155,6 +162,7 @@ int heavy_build_impl(bpr_ctx* c);   // bpr_refresh.hip
 void heavy_free(bpr_ctx* c);        // bpr_refresh.hip
 int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n);  // bpr_refresh.hip
 int hot_set_items_impl(bpr_ctx* c, const int32_t* items, int H, const uint32_t* counts);  // bpr_refresh.hip
+int hot_fold_impl(bpr_ctx* c);  // bprcore.hip: fold deltas left by bpr_train_stream_acut (no-op otherwise)
 void hot_free(bpr_ctx* c);                                       // bpr_refresh.hip
 int plan_chunk_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n, int64_t chunk,
                     uint64_t seed, int64_t index, int32_t* users_out, int32_t* pos_out, hipStream_t st);

@@ -10,7 +10,7 @@ namespace bpr {
 
 int fail(int code, const std::string& msg);                 // sets bpr_last_error, returns code
 OptDev opt_dev(const bpr_ctx* c, int64_t t);                // device view of the ctx's optimizer
-int check_bound(const bpr_ctx* c, const char* who);         // tables bound?
+int check_bound(const bpr_ctx* c, const char* who, bool whole_table = true);  // tables bound? (+ folds hot deltas an async cut left)
 int check_opt_state(const bpr_ctx* c, const char* who);     // state tensors the kind needs bound?
 int check_triples(const bpr_ctx* c, const char* who, const int32_t* users, const int32_t* pos,
                   int64_t B);

@@ -164,6 +164,9 @@ struct EpilogueCutArgs {
   float* T;
   double* sig_acc;
   int32_t n_blocks, H, R, d, I;
+  // 0: read-only cut (bpr_train_stream_acut): the keys are Q + delta, nothing is folded — this pass
+  // then runs on the side stream WHILE the next launch already updates the table
+  int32_t fold;
 };
 
 __global__ __launch_bounds__(256) void k_stream_epilogue_cut(const EpilogueCutArgs a) {
@@ -207,10 +210,10 @@ __global__ __launch_bounds__(256) void k_stream_epilogue_cut(const EpilogueCutAr
         for (int rep = 0; rep < a.R; ++rep) {
           float* p = a.delta + rep * hd + (int64_t)s * d + f;
           sum += *p;
-          *p = 0.f;
+          if (a.fold) *p = 0.f;
         }
         v += sum;
-        a.Q[i * d + f] = v;
+        if (a.fold) a.Q[i * d + f] = v;
       }
     }
     tile[ty + r][tx] = v;

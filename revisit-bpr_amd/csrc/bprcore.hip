@@ -49,11 +49,31 @@ static unsigned grid_for(int64_t n_groups, int G, int64_t cap_groups) {
   return (unsigned)blocks;
 }
 
-int check_bound(const bpr_ctx* c, const char* who) {
+int check_bound(const bpr_ctx* c, const char* who, bool whole_table) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, std::string(who) + ": ctx is NULL");
   if (c->P == nullptr || c->Q == nullptr)
     return fail(BPR_ERR_INVALID, std::string(who) + ": tables not bound (bpr_bind_tables)");
+  // every entry point sees the item table whole — but bpr_train_stream_acut itself and the calls of
+  // its pipeline that never look at the table (commit; begin when the keys are already cut)
+  if (whole_table && c->hot_unfolded && !c->acut_call) return hot_fold_impl(const_cast<bpr_ctx*>(c));
   return BPR_OK;
+}
+
+// Fold the hot deltas an asynchronous cut left in the block (after that cut has read them).
+int hot_fold_impl(bpr_ctx* c) {
+  if (!c->hot_unfolded) return BPR_OK;
+  c->hot_unfolded = false;
+  if (c->hot_H <= 0) return BPR_OK;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (c->ev_keys != nullptr) BPR_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_keys, 0));
+  EpilogueArgs ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.Q = c->Q; ea.delta = c->hot_delta; ea.hot_items = c->hot_items;
+  ea.H = c->hot_H; ea.R = c->hot_R; ea.d = c->d;
+  ea.fold_blocks = (int)std::min<int64_t>(((int64_t)c->hot_H * c->d + 255) / 256, 64);
+  hipLaunchKernelGGL(k_stream_epilogue, dim3(1 + ea.fold_blocks), dim3(256), 0, c->stream, ea);
+  BPR_HIP_CHECK(hipGetLastError());
+  return BPR_OK;  // (Q + delta is what it was: keys cut from it stay valid)
 }
 
 static int ensure_strict_scratch(bpr_ctx* c) {
@@ -241,7 +261,7 @@ static int stream_cus(bpr_ctx* c) {
 // in flight).  A cap below one 256-thread block shrinks the block (whole waves), so
 // max_inflight = 1 at G = 64 really is ONE wave walking the stream sequentially.
 static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_groups,
-                         float* out_scalars, bool cut) {
+                         float* out_scalars, bool cut, bool acut = false) {
   if (a.n <= 0) return BPR_OK;
   if (cut)
     if (int rc = refresh_alloc(c)) return rc;
@@ -351,19 +371,49 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
       BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
     }
+    if (acut) {
+      if (c->ev_launch == nullptr) BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_launch, hipEventDisableTiming));
+      if (c->side == nullptr) {
+        BPR_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        c->side_owned = true;
+      }
+      // the launch after next reuses this launch's partials: two sets, used alternately
+      if (a.partials != nullptr) a.partials = c->dev_scalars + (size_t)c->acut_parity * 4 * (STREAM_MAX_GRID + 1);
+      c->acut_parity ^= 1;
+    }
     {
       Timer tm(c, true);
       (void)tm;
+      hipEvent_t stop = acut ? c->ev_launch : nullptr;
       auto go = [&](auto smp, auto sn) {
         constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
         if (c->d == G * E)
-          hipLaunchKernelGGL((k_stream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
-                             c->stream, a);
+          hipExtLaunchKernelGGL((k_stream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
+                                c->stream, nullptr, stop, 0, a);
         else
-          hipLaunchKernelGGL((k_stream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
-                             c->stream, a);
+          hipExtLaunchKernelGGL((k_stream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
+                                c->stream, nullptr, stop, 0, a);
       };
       pick(go);
+    }
+    if (acut) {
+      // the cut of the next snapshot on the SIDE stream, behind this launch and beside the next
+      // one: read-only (keys = Q + hot deltas, nothing folded), it also sums the loss partials
+      EpilogueCutArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.partials = a.partials; ea.n_blocks = (int)grid; ea.out = out_scalars;
+      ea.Q = c->Q; ea.delta = c->hot_delta; ea.hot_slot = hot ? c->hot_slot : nullptr;
+      ea.T = c->keysT; ea.sig_acc = c->sig_acc;
+      ea.H = hot ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d; ea.I = (int32_t)c->I;
+      ea.fold = 0;
+      dim3 eg((unsigned)((c->I + 31) / 32), (unsigned)((c->d + 31) / 32) + 1u);
+      BPR_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_launch, 0));
+      hipExtLaunchKernelGGL(k_stream_epilogue_cut, eg, dim3(256), 0, c->side, nullptr, c->ev_keys, 0, ea);
+      BPR_HIP_CHECK(hipGetLastError());
+      c->keys_cut = true;
+      c->keys_event = true;
+      c->hot_unfolded = hot;
+      return BPR_OK;
     }
     if (defer) {
       c->defer_blocks = (int)grid;
@@ -378,6 +428,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       ea.Q = c->Q; ea.delta = c->hot_delta; ea.hot_slot = hot ? c->hot_slot : nullptr;
       ea.T = c->keysT; ea.sig_acc = c->sig_acc;
       ea.H = hot ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d; ea.I = (int32_t)c->I;
+      ea.fold = 1;
       dim3 eg((unsigned)((c->I + 31) / 32), (unsigned)((c->d + 31) / 32) + 1u);
       // the split refresh's side stream waits for this cut: the event rides on the kernel's own
       // completion signal (hipExtLaunchKernelGGL stop event) instead of a marker packet behind it
@@ -474,7 +525,7 @@ int bpr_ctx_create(bpr_ctx** out, int device_id, void* hip_stream) {
   if (c == nullptr) return fail(BPR_ERR_NOMEM, "bpr_ctx_create: out of host memory");
   c->device = device_id;
   c->stream = (hipStream_t)hip_stream;
-  if (hipMalloc(&c->dev_scalars, sizeof(float) * 4 * (size_t)(STREAM_MAX_GRID + 1)) != hipSuccess) {
+  if (hipMalloc(&c->dev_scalars, sizeof(float) * 2 * 4 * (size_t)(STREAM_MAX_GRID + 1)) != hipSuccess) {
     delete c;
     return fail(BPR_ERR_HIP, "bpr_ctx_create: hipMalloc failed");
   }
@@ -492,6 +543,7 @@ int bpr_ctx_destroy(bpr_ctx* c) {
   side_free(c);
   vs_free(c);
   hipFree(c->dev_scalars);
+  if (c->ev_launch) hipEventDestroy(c->ev_launch);
   for (auto e : c->ev_start) hipEventDestroy(e);
   for (auto e : c->ev_stop) hipEventDestroy(e);
   delete c;
@@ -680,7 +732,7 @@ int bpr_adaptive_refresh(bpr_ctx* c) {
 }
 
 int bpr_adaptive_refresh_begin(bpr_ctx* c) {
-  if (int rc = check_bound(c, "bpr_adaptive_refresh_begin")) return rc;
+  if (int rc = check_bound(c, "bpr_adaptive_refresh_begin", c == nullptr || !c->keys_cut)) return rc;
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->vs_active)
     if (int rc = vs_flush(c, false, true)) return rc;
@@ -688,7 +740,7 @@ int bpr_adaptive_refresh_begin(bpr_ctx* c) {
 }
 
 int bpr_adaptive_refresh_commit(bpr_ctx* c) {
-  if (int rc = check_bound(c, "bpr_adaptive_refresh_commit")) return rc;
+  if (int rc = check_bound(c, "bpr_adaptive_refresh_commit", false)) return rc;
   BPR_HIP_CHECK(hipSetDevice(c->device));
   return refresh_commit_impl(c);
 }
@@ -887,8 +939,12 @@ int bpr_get_grad(bpr_ctx* c, float* gP, float* gQ, float* gbias) {
 
 static int train_stream_impl(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg,
                              int64_t n, int32_t sampler, float adaptive_p, uint64_t seed,
-                             uint64_t offset, int64_t max_inflight, float* out_scalars, bool cut) {
-  if (int rc = check_triples(c, "bpr_train_stream", users, pos, n)) return rc;
+                             uint64_t offset, int64_t max_inflight, float* out_scalars, bool cut,
+                             bool acut = false) {
+  if (c != nullptr) c->acut_call = acut;  // (check_bound folds pending hot deltas for everybody else)
+  const int rc0 = check_triples(c, "bpr_train_stream", users, pos, n);
+  if (c != nullptr) c->acut_call = false;
+  if (rc0) return rc0;
   c->keys_cut = false;  // the item table moves
   if (int rc = check_sampler(c, "bpr_train_stream", sampler, adaptive_p, neg, n)) return rc;
   if (c->opt_kind != BPR_OPT_SGD)
@@ -931,7 +987,11 @@ static int train_stream_impl(bpr_ctx* c, const int32_t* users, const int32_t* po
     a.hot_H = c->hot_H;
     a.hot_rmask = c->hot_R - 1;
   }
-  return launch_stream(c, a, sampler, max_inflight, out_scalars, cut);
+  if (acut && (c->hot_tier || c->vs_active))
+    return fail(BPR_ERR_INVALID, "bpr_train_stream_acut: not under the hot tier / batched STREAM bookkeeping");
+  if (acut)
+    if (int rc = refresh_alloc(c)) return rc;
+  return launch_stream(c, a, sampler, max_inflight, out_scalars, cut && !acut, acut);
 }
 
 int bpr_train_stream(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t n,
@@ -949,6 +1009,20 @@ int bpr_train_stream_cut(bpr_ctx* c, const int32_t* users, const int32_t* pos, i
                                  "on its epilogue)");
   return train_stream_impl(c, users, pos, neg, n, sampler, adaptive_p, seed, offset, max_inflight,
                            out_scalars, true);
+}
+
+int bpr_train_stream_acut(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg,
+                          int64_t n, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
+                          int64_t max_inflight, float* out_scalars) {
+  if (n <= 0)
+    return fail(BPR_ERR_INVALID, "bpr_train_stream_acut: needs a non-empty launch");
+  return train_stream_impl(c, users, pos, neg, n, sampler, adaptive_p, seed, offset, max_inflight,
+                           out_scalars, true, true);
+}
+
+int bpr_hot_fold(bpr_ctx* c) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_hot_fold: ctx is NULL");
+  return hot_fold_impl(c);
 }
 
 int bpr_step(bpr_ctx* c, const int32_t* users, const int32_t* pos, int32_t* neg, int64_t B,

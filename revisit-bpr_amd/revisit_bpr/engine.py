@@ -434,13 +434,16 @@ class Engine:
                      cut: bool = False) -> None:
         """STREAM mode over users/pos (int32, on device) in one launch; `scalars` (if given) is
         added to.  cut=True: the launch's epilogue also cuts the keys of the next adaptive snapshot
-        (``bpr_train_stream_cut``) — the next `adaptive_refresh_begin` only queues the sort."""
+        (``bpr_train_stream_cut``) — the next `adaptive_refresh_begin` only queues the sort.
+        cut="async": that cut runs on the side stream beside the NEXT launch and folds nothing
+        (``bpr_train_stream_acut``); call `hot_fold()` before reading the item table's storage."""
         self._sync_stream()
         if users.dtype != torch.int32 or pos.dtype != torch.int32:
             raise ValueError("train_stream takes int32 id tensors (no hidden copies on the hot path)")
         if sampler == NEG_GIVEN and neg is None:
             raise ValueError("sampler NEG_GIVEN needs `neg`")
-        fn = self._lib.bpr_train_stream_cut if cut else self._lib.bpr_train_stream
+        fn = (self._lib.bpr_train_stream_acut if cut == "async" else
+              self._lib.bpr_train_stream_cut if cut else self._lib.bpr_train_stream)
         native.check(fn(self._ctx, users.data_ptr(), pos.data_ptr(), _ptr(neg), users.numel(),
                         sampler, adaptive_p, seed, offset, max_inflight, _ptr(scalars)))
 
@@ -494,6 +497,12 @@ class Engine:
     def stream_run_len(self) -> int:
         """Run length the last STREAM launch used (run_len = 0 lets the library pick it)."""
         return int(self._lib.bpr_stream_run_len(self._ctx))
+
+    def hot_fold(self) -> None:
+        """Fold the hot rows' deltas an asynchronous cut left in the block (no-op otherwise): after it
+        the item table's storage is whole for a direct reader (eval, checkpoint)."""
+        self._sync_stream()
+        native.check(self._lib.bpr_hot_fold(self._ctx))
 
     def set_hot_rows(self, hot_rows: int = 256, replicas: int = 1) -> None:
         """Replica delta rows for the most popular item rows in STREAM mode (0 = off); takes

@@ -92,7 +92,7 @@ class StreamTrainer:
                  item_sync=None, sync_every: int = 1, world: Optional[int] = None,
                  refresh_lag: float = 0.0, refresh_split: int = 1, refresh_cus: int = 0,
                  shard_refresh: bool = False, cadence: str = "job", hot_split: int = 1,
-                 rounds: Optional[int] = None, jit_plan: bool = False) -> None:
+                 rounds: Optional[int] = None, jit_plan: bool = False, async_cut: bool = False) -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
         adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302.
@@ -128,7 +128,11 @@ class StreamTrainer:
         jit_plan (refresh_lag = 1 only): the epoch is never planned as a whole — chunk k + 1 is planned
         by `bpr_plan_chunk` on the side stream behind the sort of chunk k (the plan does not depend on
         the model; the sorter idles ~40 us per step), and `adaptive_refresh_commit` waits for both.
-        Same chunks as `bpr_plan_epoch` makes (same members, grouped by user)."""
+        Same chunks as `bpr_plan_epoch` makes (same members, grouped by user).
+
+        async_cut (refresh_lag = 1, one GPU): the cut of the next snapshot leaves the launch stream —
+        a read-only pass on the side stream beside the NEXT launch (`bpr_train_stream_acut`); the
+        launch stream runs launch after launch.  The hot rows are folded at the end of the epoch."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
             raise ValueError("users / items must be int32 device tensors")
         if not 0.0 <= refresh_lag <= 1.0 or refresh_split < 1:
@@ -187,6 +191,7 @@ class StreamTrainer:
             self._pi = torch.empty_like(self.items)
         self._scalars = torch.zeros(4, dtype=torch.float32, device=users.device)
         self._synced = False  # this chunk's reconciliation already ran (fused into the launch's cut)
+        self.async_cut = bool(async_cut) and self.refresh_lag >= 1.0 and item_sync is None
         self.item_sync, self.sync_every = item_sync, sync_every
         # shards are balanced by interactions, not equal: every rank runs the same number of
         # rounds per epoch (a rank out of triples still joins the item reconciliations)
@@ -211,7 +216,7 @@ class StreamTrainer:
                                          adaptive_p=self.adaptive_p, seed=self.seed,
                                          offset=(self.rank << 40) + self.drawn,
                                          max_inflight=self.max_inflight, scalars=self._scalars,
-                                         cut=cut and p == k - 1)
+                                         cut=("async" if self.async_cut else True) if (cut and p == k - 1) else False)
                 self.drawn += b - a
                 if cut and p == k - 1 and self.item_sync is not None:
                     # several ranks: the launch left its epilogue to ONE pass that also runs the
@@ -290,6 +295,9 @@ class StreamTrainer:
     def epoch_end(self) -> dict:
         if self._main is not None:
             torch.cuda.current_stream(self.users.device).wait_stream(self._main.torch)
+        if self.async_cut:  # the tables are read next: fold what the asynchronous cuts left, wait for their sums
+            self.engine.hot_fold()
+            torch.cuda.synchronize(self.users.device)
         sc = self._scalars.tolist()
         cnt = max(sc[3], 1.0)
         return {"bpr_loss": sc[0] / cnt, "l2_reg": sc[1] / cnt, "logits_diff": sc[2] / cnt,

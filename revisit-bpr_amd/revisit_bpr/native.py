@@ -94,6 +94,9 @@ SIGNATURES = {
                                  c_uint64, c_uint64, c_int64, c_void_p]),
     "bpr_train_stream_cut": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
                                      c_uint64, c_uint64, c_int64, c_void_p]),
+    "bpr_train_stream_acut": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
+                                      c_uint64, c_uint64, c_int64, c_void_p]),
+    "bpr_hot_fold": (c_int, [c_void_p]),
     "bpr_train_stream_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                          c_int32, c_float, c_uint64, c_uint64, c_int64, c_void_p]),
     "bpr_shuffle_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_void_p,

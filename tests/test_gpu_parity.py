@@ -1224,6 +1224,48 @@ def test_stream_cut_at_full_concurrency_sees_the_final_table(d, sampler, n):
     assert torch.isfinite(e.Q).all() and torch.isfinite(sc).all()
 
 
+def test_async_cut_reads_the_table_whole_and_folds_on_demand():
+    """bpr_train_stream_acut: the cut is a read-only pass on the side stream (keys = Q + hot deltas) and
+    the launch folds nothing.  With nothing running beside it the snapshot it yields is exactly the
+    oracle's order of the table the launch left; any other entry point (here: the synchronous
+    refresh, the item table read through hot_fold) sees the table whole; the loss statistics arrive
+    through the side stream; and a run of asynchronous launches moves the table like a run of
+    synchronous ones (same negatives given: the same sums up to fp32 association)."""
+    rng = np.random.default_rng(8)
+    U, I, d, n = 4000, 2500, 128, 60_000
+    P = rng.normal(0, 0.1, (U, d)).astype(np.float32)
+    Q = rng.normal(0, 0.1, (I, d)).astype(np.float32)
+    P[0] = 0
+    Q[0] = 0
+    users = rng.integers(1, U, n).astype(np.int32)
+    pos = (1 + (rng.zipf(1.3, n) % (I - 1))).astype(np.int32)
+    neg = rng.integers(1, I, n).astype(np.int32)
+    indptr = np.zeros(U + 1, np.int64)
+    res = []
+    for mode in ("async", True):
+        e = make_engine(P, Q, None, (0.01, 0.02, 0.03))
+        e.bind_seen_csr(dev(indptr), dev(np.zeros(0, np.int32)))
+        e.set_optimizer(kind=0, lr=0.01)
+        e.set_stream_opts(True, 0)
+        pu, pi = e.plan_epoch(dev(users), dev(pos), n, seed=3)  # builds the hot block
+        sc = torch.zeros(4, device="cuda")
+        e.adaptive_refresh()
+        for k in range(3):
+            e.train_stream(pu, pi, sampler=0, neg=dev(neg), scalars=sc, cut=mode, max_inflight=1)
+            torch.cuda.synchronize()  # nothing beside the cut: the snapshot is exact
+            e.adaptive_refresh_begin()
+            e.adaptive_refresh_commit()
+            order = e.adaptive_snapshot()[0].cpu().numpy()   # (an entry point: folds what is pending)
+            e.hot_fold()
+            torch.cuda.synchronize()
+            QT, _ = oracle.adaptive_stats(e.Q.cpu().numpy())
+            assert np.array_equal(order, oracle.adaptive_order(QT)), (mode, k)
+        assert int(sc[3]) == 3 * n
+        res.append((e.P.cpu().numpy(), e.Q.cpu().numpy(), sc.cpu().numpy()))
+    assert close(res[0][0], res[1][0], 1e-6) and close(res[0][1], res[1][1], 1e-6)
+    assert close(res[0][2], res[1][2], 1e-4)
+
+
 # ---- heavy users: precomputed seen bitmaps in HBM -------------------------------------------------
 @pytest.mark.parametrize("seen,heavy_t", [("", None), ("list", None), ("", "-1"), ("", "40"), ("list", "600")])
 @pytest.mark.parametrize("d", [64, 256])
