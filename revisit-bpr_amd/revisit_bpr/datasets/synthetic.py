@@ -12,7 +12,10 @@ Generator (seeded, numpy only):
 """
 from __future__ import annotations
 
+import hashlib
+import os
 from dataclasses import dataclass
+from pathlib import Path
 
 import numpy as np
 
@@ -100,13 +103,36 @@ def generate(users: int, items: int, actions: int, median_per_user: float = 37.0
         eval_indptr=eval_indptr, eval_items=he_i.astype(np.int32))
 
 
+_LATENT_VERSION = 1  # bump when generate_latent's draws change (names the cache files)
+_ARRAYS = ("users", "items", "indptr", "indices", "eval_users", "eval_indptr", "eval_items")
+
+
 def generate_latent(users: int, items: int, actions: int, factors: int = 8, strength: float = 1.5,
                     median_per_user: float = 20.0, min_per_user: int = 5, seed: int = 13,
                     item_skew: float = 1.0, item_shift: float = 30.0, holdout: float = 0.2,
-                    eval_users: int = -1) -> Interactions:
+                    eval_users: int = -1, cache_dir=None) -> Interactions:
     """Small sets with learnable structure (for nDCG parity runs): user u picks its n_u items
     without replacement with probability ∝ popularity_i · exp(strength · <z_u, y_i>) (Gumbel top-k),
-    z, y ~ N(0, I_factors / factors).  O(users x items) time (blocked over users)."""
+    z, y ~ N(0, I_factors / factors).  O(users x items) time (blocked over users): the ML-20M-sized
+    set takes a minute or more, so `cache_dir` keeps the arrays of one argument set in an .npz there
+    (written under a temporary name and renamed: safe with several processes asking at once)."""
+    if cache_dir is not None:
+        key = repr((_LATENT_VERSION, users, items, actions, factors, strength, median_per_user, min_per_user, seed,
+                    item_skew, item_shift, holdout, eval_users))
+        path = Path(cache_dir) / f"bpr_latent_{hashlib.sha1(key.encode()).hexdigest()[:16]}.npz"
+        if path.exists():
+            try:
+                with np.load(path) as z:
+                    return Interactions(num_users=int(z["num_users"]), num_items=int(z["num_items"]),
+                                        **{k: z[k] for k in _ARRAYS})
+            except Exception:  # a damaged file: make it again
+                pass
+        data = generate_latent(users, items, actions, factors, strength, median_per_user, min_per_user, seed,
+                               item_skew, item_shift, holdout, eval_users)
+        tmp = path.with_name(f"{path.stem}.{os.getpid()}.tmp.npz")
+        np.savez(tmp, num_users=data.num_users, num_items=data.num_items, **{k: getattr(data, k) for k in _ARRAYS})
+        os.replace(tmp, path)
+        return data
     rng = np.random.default_rng(seed)
     U, I = users + 1, items + 1
     mean = actions / users

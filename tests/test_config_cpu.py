@@ -104,3 +104,20 @@ def test_reference_bpr_configs_load_unchanged():
         assert hasattr(exp, "run") and all(hasattr(m, "compute") for m in exp._metrics.values())
         loaded += 1
     assert loaded >= 15, (loaded, skipped)
+
+
+def test_generate_latent_cache_round_trip(tmp_path):
+    """`cache_dir` returns the arrays generate_latent computes (same values and dtypes), from the
+    file on the second call; other arguments get another file."""
+    args = dict(factors=8, seed=3, eval_users=100)
+    a = synthetic.generate_latent(3000, 500, 60000, **args)
+    b = synthetic.generate_latent(3000, 500, 60000, cache_dir=tmp_path, **args)
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert len(files) == 1 and files[0].startswith("bpr_latent_") and files[0].endswith(".npz")
+    c = synthetic.generate_latent(3000, 500, 60000, cache_dir=tmp_path, **args)
+    for k in ("users", "items", "indptr", "indices", "eval_users", "eval_indptr", "eval_items"):
+        for other in (b, c):
+            assert np.array_equal(getattr(a, k), getattr(other, k)) and getattr(a, k).dtype == getattr(other, k).dtype, k
+    assert (a.num_users, a.num_items) == (c.num_users, c.num_items) and isinstance(c.num_users, int)
+    synthetic.generate_latent(3000, 500, 60000, cache_dir=tmp_path, **dict(args, seed=4))
+    assert len(list(tmp_path.iterdir())) == 2

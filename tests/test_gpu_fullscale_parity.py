@@ -17,6 +17,7 @@ Acceptance (BASELINE.json: nDCG@100 within +-0.002): |difference of seed means| 
 standard errors at the last epoch, and <= 0.004 + 2 se on the way up (epoch 3).  Statistical test:
 runs last (tests/conftest.py)."""
 import math
+import tempfile
 
 import numpy as np
 import pytest
@@ -35,7 +36,7 @@ def problem():
 
     data = synthetic.generate_latent(136677, 20108, 9_700_000, factors=16, strength=1.2,
                                      median_per_user=37, min_per_user=5, seed=13, eval_users=10_000,
-                                     item_skew=1.2, item_shift=60.0)
+                                     item_skew=1.2, item_shift=60.0, cache_dir=tempfile.gettempdir())
     dev = torch.device("cuda")
     t = {k: torch.from_numpy(getattr(data, k)).to(dev)
          for k in ("users", "items", "indptr", "indices", "eval_users", "eval_indptr", "eval_items")}

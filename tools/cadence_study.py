@@ -13,6 +13,7 @@ seed standard error and the difference to the 1-rank runs of the same invocation
 import argparse
 import json
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -35,7 +36,7 @@ def load(which: str):
     if which == "full":
         return synthetic.generate_latent(136677, 20108, 9_700_000, factors=16, strength=1.2,
                                          median_per_user=37, min_per_user=5, seed=13,
-                                         eval_users=10_000, item_skew=1.2, item_shift=60.0), 128
+                                         eval_users=10_000, item_skew=1.2, item_shift=60.0, cache_dir=tempfile.gettempdir()), 128
     d = np.load(ROOT / "tests/golden/e2e_data.npz")  # the 4,000-user parity set
 
     class D:

@@ -6,6 +6,7 @@ ranks share one GPU (functional/parity check of the protocol; RCCL needs a devic
 import json
 import os
 import sys
+import tempfile
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -42,7 +43,7 @@ def main():
 
         data = synthetic.generate_latent(136677, 20108, 9_700_000, factors=16, strength=1.2,
                                          median_per_user=37, min_per_user=5, seed=13,
-                                         eval_users=10_000, item_skew=1.2, item_shift=60.0)
+                                         eval_users=10_000, item_skew=1.2, item_shift=60.0, cache_dir=tempfile.gettempdir())
         d = {k: getattr(data, k) for k in ("users", "items", "indptr", "indices", "eval_users",
                                            "eval_indptr", "eval_items")}
         d["num_users"], d["num_items"] = data.num_users, data.num_items
