@@ -546,8 +546,11 @@ struct VStreamArgs {
 // three rows) instead of three times with all three rows live in registers around them: the
 // optimizer replay inlined six times cost 256 VGPRs (one wave per SIMD); the kernel is bound by
 // the latency of its dependent memory round trips, i.e. by how many triples are in flight.
+#ifndef VS_BLOCKS_E4
+#define VS_BLOCKS_E4 4  // blocks of 256 per CU at E <= 4 (= waves per SIMD)
+#endif
 template <int G, int E, int SAMPLER, int SEEN, int KIND>
-__global__ __launch_bounds__(256, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void k_vstream(const VStreamArgs a) {
+__global__ __launch_bounds__(256, (E <= 4 ? VS_BLOCKS_E4 : (E <= 8 ? 2 : 1))) void k_vstream(const VStreamArgs a) {
   constexpr int DP = G * E;
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);

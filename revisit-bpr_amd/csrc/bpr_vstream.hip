@@ -177,7 +177,10 @@ static int launch_vstream(bpr_ctx* c, VStreamArgs a, int sampler, int64_t cap_gr
     // BPR_SEEN=csr stages nothing (every lookup searches the CSR: tests).
     const char* force_env = getenv("BPR_SEEN");
     const std::string force = force_env ? force_env : "";
-    constexpr int LIST_CAP = 512;
+#ifndef VS_LIST_CAP
+#define VS_LIST_CAP 512
+#endif
+    constexpr int LIST_CAP = VS_LIST_CAP;
     const int lds_words = (sampler != NEG_GIVEN && force != "csr") ? LIST_CAP : 0;
     // per group: the seen list + the triple's three rows as of t-1 (bpr_vstream.h)
     const size_t shmem = (size_t)(block / G) * (size_t)(lds_words + 3 * G * E) * sizeof(uint32_t);

@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=4)
     ap.add_argument("--eval-every", type=int, default=1)
     ap.add_argument("--seeds", type=int, default=10)
+    ap.add_argument("--first-seed", type=int, default=1, help="seeds first-seed .. first-seed + seeds - 1")
     ap.add_argument("--cadence", default="rank", choices=["rank", "job", "auto"])
     ap.add_argument("--budget", type=float, default=None, help="--cadence auto: override fast.STALENESS_BUDGET")
     ap.add_argument("--hot-rows", type=int, default=1024)
@@ -145,7 +146,7 @@ def main():
          ("users", "items", "indptr", "indices", "eval_users", "eval_indptr", "eval_items")}
     res = {}
     for world in [int(w) for w in a.ranks.split(",")]:
-        for seed in range(1, a.seeds + 1):
+        for seed in range(a.first_seed, a.first_seed + a.seeds):
             t0 = time.time()
             curve, spread = run(data, dim, dev, t, world, seed, a, a.lr, a.epochs)
             res.setdefault(world, []).append(curve)
