@@ -55,6 +55,8 @@ struct bpr_ctx {
   float *vGP = nullptr, *vGQ = nullptr, *vGb = nullptr;
   uint64_t *vHP = nullptr, *vHQ = nullptr;
   bool vs_active = false;
+  uint8_t* v_alone = nullptr;  // [v_alone_cap] per-triple "user alone in its virtual batch" (k_valone)
+  int64_t v_alone_cap = 0;
   // private scratch — adaptive sampler snapshot.  Two snapshots: `order` / `sigma` point at the
   // FRONT one (what the samplers read); a refresh sorts into the back one and swaps.
   int32_t* order = nullptr;  // [d, I], inside order_alloc with BPR_ORDER_PAD entries of slack on

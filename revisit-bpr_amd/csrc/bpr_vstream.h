@@ -396,10 +396,29 @@ __device__ __forceinline__ uint64_t vs_view(float (&w)[E], float& wb, const VTab
 // CAS is tried on it directly (the CAS itself validates it: one round trip saved on the common
 // path — a user row, a cold item row); a "join" is always decided on a fresh header, so that the
 // add lands in the accumulator that is current NOW.
+//
+// r4 — OWNED rows (`owned`: the user table while the launch runs with k_valone's flags).  Every
+// change to an owned row — joins too — happens under the row's lock, so no add can slip past the
+// exchange that consumes an accumulator, and a row may be left with NOTHING pending:
+//  * a triple whose row is ALONE in its virtual batch (`alone`: no other triple of batch t touches
+//    it) takes its step at once — the pending step (if any), then step t, one load and one store
+//    of (w, m, v) — instead of parking the gradient for the next visitor to exchange out and apply:
+//    a third of the protocol's atomic bytes, and the next view finds the row current.  The
+//    arithmetic is the deferred path's (the same vs_apply on the same operands): the sequential
+//    limit is unchanged bit for bit;
+//  * a straggler that arrives when the row's last step is already applied (t <= gstep == last)
+//    applies its gradient there and then as one more optimizer step at index gstep (for SGD the
+//    same as joining; with state, one extra decay — the deferred path counts a straggler one step
+//    late instead);
+//  * everything else as before (join a pending step, or close it and open step t), with the lock
+//    taken by setting the lock bit alone.
+// Item rows keep the lock-free join: they are never left applied inside a launch, and the flush
+// sums both accumulators of a pending row, so a late add is counted, not lost.
 template <int G, int E, int KIND>
 __device__ __forceinline__ void vs_contribute(const VTable& T, uint32_t row, int d, int gl,
                                               int lane, int64_t t, const float (&g)[E], float gb,
-                                              bool act, const VOpt& o, uint64_t hint) {
+                                              bool act, const VOpt& o, uint64_t hint, bool owned,
+                                              bool alone) {
   constexpr bool STATEFUL = KIND != OPT_SGD;
   const size_t off = (size_t)row * (size_t)d;
   bool done = !act;
@@ -410,7 +429,8 @@ __device__ __forceinline__ void vs_contribute(const VTable& T, uint32_t row, int
       if (!guess || t <= h.gstep() || h.locked()) h.raw = ld_hdr(T.H + row);
       guess = false;
       const int64_t gs = h.gstep();
-      if (t <= gs) {
+      const bool late = t <= gs;
+      if (late && !owned) {
         // the row's pending step is mine, or already a later one (I am a straggler: join it)
         float* acc = T.Gacc + ((size_t)h.slot() * (size_t)T.rows + row) * (size_t)d;
 #pragma unroll
@@ -422,27 +442,34 @@ __device__ __forceinline__ void vs_contribute(const VTable& T, uint32_t row, int
           atomic_add_f32(T.Gb + (size_t)h.slot() * (size_t)T.rows + row, gb);
         done = true;
       } else if (!h.locked()) {
-        const int ns = h.slot() ^ 1;
+        const bool applied = gs == h.last();  // nothing pending on this row
+        const bool join = late && !applied;   // (owned) join the pending step, under the lock
+        const bool direct = owned && (late ? applied : alone);
+        const int64_t te = late ? gs : t;
+        const int ns = (join || direct) ? h.slot() : (h.slot() ^ 1);
         int won = 0;
         if (gl == 0) {
           uint64_t expect = h.raw;
-          won = __hip_atomic_compare_exchange_strong(T.H + row, &expect,
-                                                     vhdr_pack(h.last(), t, ns, 1),
-                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT)
+          won = __hip_atomic_compare_exchange_strong(
+                    T.H + row, &expect, owned ? (h.raw | 1ull) : vhdr_pack(h.last(), te, ns, 1),
+                    __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                     ? 1 : 0;
         }
         won = group_bcast<G>(won, 0, lane);
         if (won) {
-          const int64_t a = h.last();
-          int64_t new_last = a;
-          if (gs > a) {  // close step gs: ONE optimizer step with the summed gradient
+          int64_t cur = h.last();
+          const bool close = !late && gs > cur;  // a pending step older than mine
+          if (close || direct) {
+            // close step gs (ONE optimizer step with the summed gradient), then — direct — step te
+            // with this triple's own gradient.  (A loop, not two inlined applies: the second copy
+            // of the optimizer math cost 25 % of the launch — profiles/r04_vstream_direct.md.)
             float* old = T.Gacc + ((size_t)h.slot() * (size_t)T.rows + row) * (size_t)d;
             float go[E], w[E], m[E], v[E];
+            float gbo = 0.f;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
               const int f = e * G + gl;
-              go[e] = (f < d) ? xchg_zero(old + f) : 0.f;
+              go[e] = (close && f < d) ? xchg_zero(old + f) : 0.f;
               m[e] = v[e] = 0.f;
             }
             load_row_sc1<G, E>(w, T.W + off, d, gl);
@@ -450,39 +477,53 @@ __device__ __forceinline__ void vs_contribute(const VTable& T, uint32_t row, int
               if (T.M != nullptr) load_row_sc1<G, E>(m, T.M + off, d, gl);
               if (T.V != nullptr) load_row_sc1<G, E>(v, T.V + off, d, gl);
             }
-            vs_apply<KIND, E>(w, m, v, go, a, gs, o);
+            float wb = 0.f, bm = 0.f, bv = 0.f;
+            const bool bias = T.b != nullptr && gl == 0;
+            if (bias) {
+              wb = ld_sc1(T.b + row);
+              if constexpr (STATEFUL) {
+                if (T.mb != nullptr) bm = ld_sc1(T.mb + row);
+                if (T.vb != nullptr) bv = ld_sc1(T.vb + row);
+              }
+              if (close) gbo = xchg_zero(T.Gb + (size_t)h.slot() * (size_t)T.rows + row);
+            }
+#pragma unroll 1
+            for (int ph = close ? 0 : 1; ph < (direct ? 2 : 1); ++ph) {
+              const int64_t st = ph == 0 ? gs : te;
+              if (ph == 1) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) go[e] = g[e];
+                gbo = gb;
+              }
+              vs_apply<KIND, E>(w, m, v, go, cur, st, o);
+              if (bias) vs_apply1<KIND>(wb, bm, bv, gbo, cur, st, o);
+              cur = st;
+            }
             store_row_sc1<G, E>(T.W + off, w, d, gl);
             if constexpr (STATEFUL) {
               if (T.M != nullptr) store_row_sc1<G, E>(T.M + off, m, d, gl);
               if (T.V != nullptr) store_row_sc1<G, E>(T.V + off, v, d, gl);
             }
-            if (T.b != nullptr && gl == 0) {
-              float wb = ld_sc1(T.b + row), bm = 0.f, bv = 0.f;
-              if constexpr (STATEFUL) {
-                if (T.mb != nullptr) bm = ld_sc1(T.mb + row);
-                if (T.vb != nullptr) bv = ld_sc1(T.vb + row);
-              }
-              const float gbo = xchg_zero(T.Gb + (size_t)h.slot() * (size_t)T.rows + row);
-              vs_apply1<KIND>(wb, bm, bv, gbo, a, gs, o);
+            if (bias) {
               st_sc1(T.b + row, wb);
               if constexpr (STATEFUL) {
                 if (T.mb != nullptr) st_sc1(T.mb + row, bm);
                 if (T.vb != nullptr) st_sc1(T.vb + row, bv);
               }
             }
-            new_last = gs;
           }
-          // open step t with my own gradient
-          float* acc = T.Gacc + ((size_t)ns * (size_t)T.rows + row) * (size_t)d;
+          if (!direct) {  // my gradient into step te's accumulator (joined, or opened just now)
+            float* acc = T.Gacc + ((size_t)ns * (size_t)T.rows + row) * (size_t)d;
 #pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const int f = e * G + gl;
-            if (f < d) atomic_add_f32(acc + f, g[e]);
+            for (int e = 0; e < E; ++e) {
+              const int f = e * G + gl;
+              if (f < d) atomic_add_f32(acc + f, g[e]);
+            }
+            if (T.b != nullptr && gl == 0) atomic_add_f32(T.Gb + (size_t)ns * (size_t)T.rows + row, gb);
           }
-          if (T.b != nullptr && gl == 0) atomic_add_f32(T.Gb + (size_t)ns * (size_t)T.rows + row, gb);
           // publish: every store above has left this CU before the header says so
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (gl == 0) st_hdr(T.H + row, vhdr_pack(new_last, t, ns, 0));
+          if (gl == 0) st_hdr(T.H + row, vhdr_pack(cur, te, ns, 0));
           done = true;
         }
       }
@@ -530,6 +571,7 @@ struct VStreamArgs {
   const int32_t* users;
   const int32_t* pos;
   int32_t* neg;
+  const uint8_t* alone;  // [n] 1 = the triple's user occurs once in its virtual batch (k_valone); DIRECT launches
   float* partials;  // NULL = no statistics
   uint64_t seed, offset;
   int64_t t_base;   // virtual step of the chunk's first batch
@@ -549,7 +591,11 @@ struct VStreamArgs {
 #ifndef VS_BLOCKS_E4
 #define VS_BLOCKS_E4 4  // blocks of 256 per CU at E <= 4 (= waves per SIMD)
 #endif
-template <int G, int E, int SAMPLER, int SEEN, int KIND>
+// DIRECT: user rows are OWNED (vs_contribute) and take the steps of batches they are alone in at once.
+// BIAS = false: a model without item_bias — the scalar copies of the optimizer math that serve the
+// riding scalar are compiled out (a fifth of the Adam kernel's code, and code size is what this
+// kernel is sensitive to: profiles/r04_vstream_direct.md).
+template <int G, int E, int SAMPLER, int SEEN, int KIND, bool DIRECT, bool BIAS>
 __global__ __launch_bounds__(256, (E <= 4 ? VS_BLOCKS_E4 : (E <= 8 ? 2 : 1))) void k_vstream(const VStreamArgs a) {
   constexpr int DP = G * E;
   const int lane = threadIdx.x & 63;
@@ -572,10 +618,10 @@ __global__ __launch_bounds__(256, (E <= 4 ? VS_BLOCKS_E4 : (E <= 8 ? 2 : 1))) vo
     T.Gacc = r == 0 ? a.P.Gacc : a.Q.Gacc;
     T.H = r == 0 ? a.P.H : a.Q.H;
     T.rows = r == 0 ? a.P.rows : a.Q.rows;
-    T.b = r == 0 ? nullptr : a.Q.b;
-    T.mb = r == 0 ? nullptr : a.Q.mb;
-    T.vb = r == 0 ? nullptr : a.Q.vb;
-    T.Gb = r == 0 ? nullptr : a.Q.Gb;
+    T.b = (!BIAS || r == 0) ? nullptr : a.Q.b;
+    T.mb = (!BIAS || r == 0) ? nullptr : a.Q.mb;
+    T.vb = (!BIAS || r == 0) ? nullptr : a.Q.vb;
+    T.Gb = (!BIAS || r == 0) ? nullptr : a.Q.Gb;
     return T;
   };
 
@@ -586,6 +632,8 @@ __global__ __launch_bounds__(256, (E <= 4 ? VS_BLOCKS_E4 : (E <= 8 ? 2 : 1))) vo
     const uint32_t u = (uint32_t)a.users[kk];
     const uint32_t i = (uint32_t)a.pos[kk];
     const int64_t t = a.t_base + (int64_t)(kk / a.B);
+    bool alone = false;
+    if constexpr (DIRECT) alone = a.alone[kk] != 0;
     int32_t j = 0;
     float bi = 0.f, bj = 0.f;
     uint64_t hu = 0, hi_ = 0, hj = 0;  // headers the three views were taken under
@@ -657,7 +705,7 @@ __global__ __launch_bounds__(256, (E <= 4 ? VS_BLOCKS_E4 : (E <= 8 ? 2 : 1))) vo
     // padding_idx drops the gradient of the pad EMBEDDING row (torch's embedding backward); the
     // pad item's bias is an ordinary parameter and keeps its gradient.
     const float w = 1.0f / (1.0f + expf(x));
-    const bool has_bias = a.Q.b != nullptr;
+    const bool has_bias = BIAS && a.Q.b != nullptr;
 #pragma unroll 1
     for (int r = 0; r < 3; ++r) {
       const uint32_t row = r == 0 ? u : (r == 1 ? i : (uint32_t)j);
@@ -672,7 +720,8 @@ __global__ __launch_bounds__(256, (E <= 4 ? VS_BLOCKS_E4 : (E <= 8 ? 2 : 1))) vo
       const float gb = r == 0 ? 0.f : (r == 1 ? -w : w);
       vs_contribute<G, E, KIND>(table(r), row, d, gl, lane, t, g, gb,
                                 act && (!pad || (r != 0 && has_bias)), a.o,
-                                r == 0 ? hu : (r == 1 ? hi_ : hj));
+                                r == 0 ? hu : (r == 1 ? hi_ : hj), DIRECT && r == 0,
+                                DIRECT && r == 0 && alone);
     }
   }
   if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);
@@ -777,6 +826,44 @@ __global__ __launch_bounds__(256) void k_vfill_hdr(uint64_t* __restrict__ H, int
 }
 
 // final sum of the per-block loss statistics (added to the caller's four floats)
+// alone[k] = 1 when users[k] occurs exactly once among the users of its virtual batch
+// [b * B, (b + 1) * B) — one block per batch, an open-addressing set in LDS (S >= 2 B slots, a power
+// of two: keys[S] then dup[S]).  B <= VALONE_MAX_B; the launch leaves the direct path off above that.
+constexpr int VALONE_MAX_B = 2048;
+__global__ __launch_bounds__(256) void k_valone(const int32_t* __restrict__ users, int32_t n, int32_t B,
+                                                int32_t S, uint8_t* __restrict__ alone) {
+  extern __shared__ uint32_t valone_lds[];
+  uint32_t* keys = valone_lds;
+  uint32_t* dup = valone_lds + S;
+  const int64_t lo = (int64_t)blockIdx.x * B;
+  const int32_t cnt = (int32_t)((lo + B <= n ? lo + B : (int64_t)n) - lo);
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    keys[s] = 0xFFFFFFFFu;
+    dup[s] = 0u;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
+    const uint32_t u = (uint32_t)users[lo + k];
+    uint32_t s = ((u * 0x9E3779B1u) >> 7) & (uint32_t)(S - 1);
+    while (true) {
+      const uint32_t prev = atomicCAS(&keys[s], 0xFFFFFFFFu, u);
+      if (prev == 0xFFFFFFFFu) break;
+      if (prev == u) {
+        dup[s] = 1u;
+        break;
+      }
+      s = (s + 1) & (uint32_t)(S - 1);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
+    const uint32_t u = (uint32_t)users[lo + k];
+    uint32_t s = ((u * 0x9E3779B1u) >> 7) & (uint32_t)(S - 1);
+    while (keys[s] != u) s = (s + 1) & (uint32_t)(S - 1);
+    alone[lo + k] = dup[s] ? 0 : 1;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_vsum_partials(const float* __restrict__ partials,
                                                        int n_blocks, float* __restrict__ out) {
   __shared__ double red[256][4];

@@ -77,6 +77,9 @@ static VOpt vopt(const bpr_ctx* c) {
 
 void vs_free(bpr_ctx* c) {
   hipFree(c->vGP); hipFree(c->vGQ); hipFree(c->vGb); hipFree(c->vHP); hipFree(c->vHQ);
+  hipFree(c->v_alone);
+  c->v_alone = nullptr;
+  c->v_alone_cap = 0;
   c->vGP = c->vGQ = c->vGb = nullptr;
   c->vHP = c->vHQ = nullptr;
   c->vs_active = false;
@@ -198,8 +201,17 @@ static int launch_vstream(bpr_ctx* c, VStreamArgs a, int sampler, int64_t cap_gr
       auto go = [&](auto smp, auto knd) {
         constexpr int SMP = decltype(smp)::value, KND = decltype(knd)::value;
         constexpr int SN = SMP == NEG_GIVEN ? SEEN_CSR : SEEN_LIST;
-        hipLaunchKernelGGL((k_vstream<G, E, SMP, SN, KND>), dim3(grid), dim3(block), shmem,
-                           c->stream, a);
+        auto with_bias = [&](auto dir) {
+          constexpr bool DIR = decltype(dir)::value;
+          if (a.Q.b != nullptr)
+            hipLaunchKernelGGL((k_vstream<G, E, SMP, SN, KND, DIR, true>), dim3(grid), dim3(block), shmem,
+                               c->stream, a);
+          else
+            hipLaunchKernelGGL((k_vstream<G, E, SMP, SN, KND, DIR, false>), dim3(grid), dim3(block), shmem,
+                               c->stream, a);
+        };
+        if (a.alone != nullptr) with_bias(std::integral_constant<bool, true>{});
+        else with_bias(std::integral_constant<bool, false>{});
       };
       using std::integral_constant;
       auto with_kind = [&](auto smp) {
@@ -262,6 +274,29 @@ int bpr_train_stream_batched(bpr_ctx* c, const int32_t* users, const int32_t* po
   a.inv_log1mp = sampler == BPR_NEG_ADAPTIVE ? inv_log1mp(adaptive_p) : 0.f;
   a.iw = ItemWeights{c->w_accept, c->w_alias};
   a.o = vopt(c);
+  // DIRECT launches: user rows are owned, and alone in their virtual batch they take their step at
+  // once (bpr_vstream.h, vs_contribute): +20 / +5 / +6 % for SGD / momentum / RMSprop on the Yelp
+  // shape, +2 % for Adam without item_bias.  Off for Adam WITH item_bias, whose kernel is at the
+  // edge of its registers and loses 3 % to the extra branches (profiles/r04_vstream_direct.md).
+  // BPR_VS_DIRECT=0 / 1 forces it (tests run both).
+  const char* direct_env = getenv("BPR_VS_DIRECT");
+  const bool direct = direct_env != nullptr && (direct_env[0] == '0' || direct_env[0] == '1')
+                          ? direct_env[0] == '1'
+                          : !(c->opt_kind == BPR_OPT_ADAM && a.Q.b != nullptr);
+  if (B <= VALONE_MAX_B && direct) {
+    if (c->v_alone_cap < n) {
+      hipFree(c->v_alone);
+      c->v_alone = nullptr;
+      c->v_alone_cap = 0;
+      BPR_HIP_CHECK(hipMalloc(&c->v_alone, (size_t)n));
+      c->v_alone_cap = n;
+    }
+    int S = 64;
+    while (S < 2 * B) S <<= 1;
+    hipLaunchKernelGGL(k_valone, dim3((unsigned)steps), dim3(256), 2 * (size_t)S * sizeof(uint32_t), c->stream,
+                       users, (int32_t)n, (int32_t)B, (int32_t)S, c->v_alone);
+    a.alone = c->v_alone;
+  }
   if (int rc = launch_vstream(c, a, sampler, max_inflight, out_scalars)) return rc;
   c->step += steps;
   return BPR_OK;

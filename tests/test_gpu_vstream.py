@@ -234,6 +234,84 @@ def test_full_concurrency_closes_lose_and_double_nothing(opt_name, d):
             assert scale > 0 and np.abs(got - want).max() <= 1e-4 * scale, (k, np.abs(got - want).max(), scale)
 
 
+@pytest.mark.parametrize("opt_name", ["sgd", "nesterov", "adam_01", "rmsprop"])
+def test_direct_steps_for_rows_alone_in_their_batch_are_the_deferred_steps(opt_name, monkeypatch):
+    """r4: a user row that is alone in its virtual batch takes its step at once, under the lock its
+    opener holds (k_valone + vs_contribute's direct path), instead of parking the gradient for the
+    next visitor.  In the sequential limit that is the same arithmetic on the same operands: the
+    tables after two launches equal BIT FOR BIT those of BPR_VS_DIRECT=0 (every row deferred) — with
+    users that repeat inside a batch (not alone: deferred), users alone in one batch and repeated in
+    the next, a pad user, and a launch boundary in between."""
+    cfg = OPTS[opt_name]
+    U, I, B, d = 5000, 300, 32, 128
+    P, Q, _, _, _, _, _ = rand_problem(U, I, d, 10, seed=9, B=8)
+    P *= 4
+    Q *= 4
+    b = np.linspace(-0.1, 0.1, I).astype(np.float32)
+    rng = np.random.default_rng(3)
+    n = 40 * B - 5
+    users = rng.integers(1, U, n).astype(np.int32)  # 32 of 5,000: nearly all alone
+    pos = rng.integers(1, I, n).astype(np.int32)
+    neg = distinct_neg(pos, rng.integers(1, I, n).astype(np.int32), I)
+    users[3] = users[9] = users[20]  # three of one user inside batch 0
+    users[B + 1] = users[20]  # the same user alone in batch 1 (its batch-0 step is pending)
+    users[2 * B + 4] = users[2 * B + 5]  # a pair in batch 2 ...
+    users[5 * B + 7] = users[2 * B + 4]  # ... alone again in batch 5
+    users[40] = 0
+    out = {}
+    for direct in ("1", "0"):
+        monkeypatch.setenv("BPR_VS_DIRECT", direct)
+        e = make_engine(P, Q, b, REG)
+        e.set_optimizer(**cfg)
+        e.alloc_opt_state()
+        cut = 17 * B
+        e.train_stream_batched(dev(users[:cut]), dev(pos[:cut]), B, sampler=0, neg=dev(neg[:cut]), max_inflight=1)
+        e.train_stream_batched(dev(users[cut:]), dev(pos[cut:]), B, sampler=0, neg=dev(neg[cut:]), max_inflight=1)
+        e.flush_lazy()
+        out[direct] = (e.P.cpu().numpy().copy(), e.Q.cpu().numpy().copy(), e.item_bias.cpu().numpy().copy())
+    for got, want in zip(out["1"], out["0"]):
+        assert np.array_equal(got, want), maxerr(got, want)
+    Po, Qo, bo = P.copy(), Q.copy(), b.copy()
+    oracle_batches(Po, Qo, bo, users, pos, neg, B, cfg)
+    assert np.abs(Po - P).max() > 1e-3
+    assert agree(out["1"][0], Po, cfg), maxerr(out["1"][0], Po)
+    assert agree(out["1"][1], Qo, cfg), maxerr(out["1"][1], Qo)
+
+
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_full_concurrency_many_batches_conserve_the_gradients(direct, monkeypatch):
+    """The protocol at full concurrency over MANY virtual batches per launch (the shape of a real
+    launch: most user rows alone in their batch, a few items under heavy contention).  With lr = 0
+    the tables never move, so every gradient is a function of the inputs alone; with momentum
+    0.99999 the momentum buffer is — to 1e-5 per step of misattribution, and 128 virtual steps are
+    in flight here — the SUM of the row's gradients, whichever step a straggler's gradient was
+    counted in.  So buffer == oracle's to 5e-3 of the row's scale says: nothing lost, nothing
+    applied twice, by either path (a user row holds about five gradients: one lost is 20 %)."""
+    monkeypatch.setenv("BPR_VS_DIRECT", direct)
+    cfg = dict(kind=1, lr=0.0, momentum=0.99999)
+    U, I, B, d, n, launches = 20000, 40, 64, 128, 32768, 3
+    P, Q, _, _, _, _, _ = rand_problem(U, I, d, 5, seed=4, B=8)
+    rng = np.random.default_rng(8)
+    e = make_engine(P, Q, None, REG)
+    e.set_optimizer(**cfg)
+    state = e.alloc_opt_state()
+    Po, Qo = P.copy(), Q.copy()
+    st = oracle_state(Po, Qo, None)
+    for t in range(launches):
+        users = rng.integers(1, U, n).astype(np.int32)
+        pos = rng.integers(1, I, n).astype(np.int32)
+        neg = distinct_neg(pos, rng.integers(1, I, n).astype(np.int32), I)
+        e.train_stream_batched(dev(users), dev(pos), B, sampler=0, neg=dev(neg))
+        oracle_batches(Po, Qo, None, users, pos, neg, B, cfg, t0=t * (n // B), st=st)
+    e.flush_lazy()
+    assert np.array_equal(e.P.cpu().numpy(), P) and np.array_equal(e.Q.cpu().numpy(), Q)
+    for k in ("mP", "mQ"):
+        got, want = state[k].cpu().numpy(), st[k]
+        row_scale = np.abs(want).max(axis=1, keepdims=True)
+        bad = np.abs(got - want) > 5e-3 * row_scale + 1e-7
+        assert row_scale.max() > 0 and bad.sum() == 0, (k, int(bad.any(axis=1).sum()), "rows off")
+
+
 @pytest.mark.parametrize("opt_name", ["adam_09", "nesterov", "sgd"])
 def test_mode_switches_keep_one_trajectory(opt_name):
     """STRICT steps, then the batched stream, then STRICT again, with rows left pending / stale at
