@@ -513,12 +513,6 @@ void k_stream(const StreamArgs a) {
     float x_mine = 0.f;  // statistics: logit of step gl of this run
     bool x_have = false;
     for (int step = 0; step < L; ++step) {
-#if defined(KS_PAD_CODE)  // measurement probe (profiles/r04_vstream_direct.md): 512 executed s_nop, 2 KB of code
-      asm volatile(".rept 512\n s_nop 0\n .endr" ::: "memory");
-#elif defined(KS_PAD_LOOP)  // the same 512 issue slots from 32 bytes of code
-#pragma unroll 1
-      for (int q = 0; q < 64; ++q) asm volatile(".rept 8\n s_nop 0\n .endr" ::: "memory");
-#endif
       const int t = t0 + step;
       const bool act = run_act && t < t1;
       const int tt = act ? t : (a.n - 1);
