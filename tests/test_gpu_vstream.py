@@ -285,8 +285,9 @@ def test_full_concurrency_many_batches_conserve_the_gradients(direct, monkeypatc
     the tables never move, so every gradient is a function of the inputs alone; with momentum
     0.99999 the momentum buffer is — to 1e-5 per step of misattribution, and 128 virtual steps are
     in flight here — the SUM of the row's gradients, whichever step a straggler's gradient was
-    counted in.  So buffer == oracle's to 5e-3 of the row's scale says: nothing lost, nothing
-    applied twice, by either path (a user row holds about five gradients: one lost is 20 %)."""
+    counted in — a late add that stays in an accumulator until the flush, 1,500 steps later, is off
+    by 1.5 % of one gradient.  So buffer == oracle's to 2e-2 of the row's scale says: nothing lost,
+    nothing applied twice, by either path (a user row holds about five gradients: one lost is 20 %)."""
     monkeypatch.setenv("BPR_VS_DIRECT", direct)
     cfg = dict(kind=1, lr=0.0, momentum=0.99999)
     U, I, B, d, n, launches = 20000, 40, 64, 128, 32768, 3
@@ -308,7 +309,7 @@ def test_full_concurrency_many_batches_conserve_the_gradients(direct, monkeypatc
     for k in ("mP", "mQ"):
         got, want = state[k].cpu().numpy(), st[k]
         row_scale = np.abs(want).max(axis=1, keepdims=True)
-        bad = np.abs(got - want) > 5e-3 * row_scale + 1e-7
+        bad = np.abs(got - want) > 2e-2 * row_scale + 1e-7
         assert row_scale.max() > 0 and bad.sum() == 0, (k, int(bad.any(axis=1).sum()), "rows off")
 
 
