@@ -311,7 +311,12 @@ int bpr_hot_fold(bpr_ctx* ctx);
  * and see rows that may be a few steps stale.  Advances the step counter by
  * ceil(n / B); bpr_flush_lazy / bpr_adaptive_refresh bring rows to "now" (call bpr_flush_lazy
  * before reading the tables: eval, checkpoint, item all-reduce).  sampler / seed / offset / neg /
- * out_scalars as bpr_train_stream. */
+ * out_scalars as bpr_train_stream.
+ * r4: for 16 <= B <= 2048 the launch first marks the triples whose user occurs once in its virtual
+ * batch; such a user row takes its optimizer step at once, under the row's lock, instead of parking
+ * the gradient for the row's next visitor (same arithmetic, bit-identical in the max_inflight = 1
+ * limit).  On by default except for Adam on a model with item_bias; the environment
+ * variable BPR_VS_DIRECT=0 / 1 forces it off / on (a measurement and test aid, read per launch). */
 int bpr_train_stream_batched(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
                              int64_t n, int64_t B, int32_t sampler, float adaptive_p,
                              uint64_t seed, uint64_t offset, int64_t max_inflight,

@@ -283,7 +283,7 @@ int bpr_train_stream_batched(bpr_ctx* c, const int32_t* users, const int32_t* po
   const bool direct = direct_env != nullptr && (direct_env[0] == '0' || direct_env[0] == '1')
                           ? direct_env[0] == '1'
                           : !(c->opt_kind == BPR_OPT_ADAM && a.Q.b != nullptr);
-  if (B <= VALONE_MAX_B && direct) {
+  if (B >= 16 && B <= VALONE_MAX_B && direct) {  // (tiny batches: one block per batch would not pay)
     if (c->v_alone_cap < n) {
       hipFree(c->v_alone);
       c->v_alone = nullptr;
