@@ -1,5 +1,4 @@
 #!/bin/bash
 cd "$(dirname "$0")/../.."
-R=$PWD; O=$R/gpurun_out/r04_r; mkdir -p $O
-for i in 1 2 3 4 5 6 7 8 9 10; do timeout 300 python -m pytest tests/test_gpu_vstream.py -x -q -m gpu -k "conserve" 2>&1 | tail -1; done | sort | uniq -c
-timeout 600 python -m pytest tests/test_gpu_vstream.py -x -q -m gpu 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_vstream.py tests/test_gpu_baseline_configs.py tests/test_gpu_config_run.py -x -q -m gpu 2>&1 | tail -2
+python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" 2>&1 | tail -1
