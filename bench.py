@@ -169,6 +169,10 @@ def parse_args():
     ap.add_argument("--async-cut", type=int, default=0,
                     help="1: the cut of the next snapshot runs on the side stream beside the next launch "
                          "(bpr_train_stream_acut) instead of between two launches")
+    ap.add_argument("--item-bias", type=int, default=0,
+                    help="1: the model carries the reference's optional item_bias (models/bpr/model.py:101-110; "
+                         "its RQ configs switch it on).  Single GPU only here (a measurement aid: "
+                         "profiles/shapes_r04.txt); the default 0 is the model every earlier round timed")
     ap.add_argument("--sustained-epochs", type=int, default=3,
                     help="after the timed region: this many WHOLE epochs (plan + every step) timed by wall "
                          "clock, reported as `sustained` (0 = skip)")
@@ -349,7 +353,10 @@ def main():
     P[0] = 0
     Q[0] = 0
     P, Q = P.to(dev), Q.to(dev)
-    e = eng.Engine(P, Q)
+    if args.item_bias and (world > 1 or args.emulate_ranks > 1):
+        raise SystemExit("--item-bias 1 is a single-GPU measurement")
+    item_bias = torch.zeros(I, device=dev) if args.item_bias else None
+    e = eng.Engine(P, Q, item_bias)
     reg = (0.0016, 0.0001, 0.00375)  # configs/RQ2/neg-sampling/ada-sampling-ml-20m.yaml.j2:144-147
     e.set_reg(*reg)
     batched = args.batched or args.optimizer != "sgd"
@@ -637,6 +644,7 @@ def main():
                                else ", STREAM mode") + f", step = snapshot refresh + {chunk} triples"
                             + ("" if lag == 0.0 else f" (snapshot sorted beside the launch: lag {lag:g}, "
                                f"{split} launch(es) per refresh period, sort masked to {cus} CUs)"),
+                "item_bias": bool(args.item_bias),
                 "triples_per_step_per_gpu": chunk,
                 "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus,
                                      "sharded_over_ranks": bool(shard_refresh and not batched)},
