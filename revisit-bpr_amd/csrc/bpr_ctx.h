@@ -141,6 +141,8 @@ struct bpr_ctx {
   const int64_t* heavy_for = nullptr;  // the indptr the table was built from (NULL = not built)
   void* comm = nullptr;  // bpr_comm.hip: the RCCL communicator and the reconciliation buffers (NULL: one GPU)
   // scalar slots
+  float* bias_w = nullptr;  // [I * BIAS_LINE] the item_bias k_stream works on, one item per 128-B line (bpr_kernels.h)
+  int64_t bias_w_rows = 0;
   float* dev_scalars = nullptr;
   // timing of the dominant kernel
   bool timing = false;

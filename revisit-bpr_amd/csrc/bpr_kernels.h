@@ -362,10 +362,17 @@ __global__ __launch_bounds__(256) void k_sync_cut(const SyncCutArgs a) {
 extern __shared__ __attribute__((aligned(16))) uint32_t bpr_smem[];
 
 // kernel arguments of k_stream only (kept small: every field costs SGPRs for the whole kernel)
+// The item_bias k_stream works on is a table of our own with ONE ITEM PER 128-B LINE (element
+// i * BIAS_LINE): in the caller's dense vector 32 items share a line, every line takes the adds of
+// all of them, memory-side atomics drop the line from L2, and each bias LOAD — in the dependent
+// chain of the logit — then queues behind those adds at the memory side (46 us of a 264-us launch,
+// profiles/shapes_r04.txt).  launch_stream fills it from the caller's vector before the launch
+// (k_bias_widen) and writes it back after (k_bias_narrow): same arithmetic, another address.
+constexpr int BIAS_LINE = 32;
 struct StreamArgs {
   float* P;
   float* Q;
-  float* bias;
+  float* bias;  // the WIDE table (BIAS_LINE floats per item), or NULL
   const int64_t* indptr;
   const int32_t* indices;
   const int32_t* order;
@@ -629,8 +636,8 @@ void k_stream(const StreamArgs a) {
       }
       float bi = 0.f, bj = 0.f;
       if (a.bias != nullptr) {
-        bi = a.bias[i];
-        bj = a.bias[j];
+        bi = a.bias[(uint32_t)i * (uint32_t)BIAS_LINE];
+        bj = a.bias[(uint32_t)j * (uint32_t)BIAS_LINE];
       }
 
       // x_uij = <p_u, q_i - q_j> (+ bias difference): one group sum
@@ -669,8 +676,8 @@ void k_stream(const StreamArgs a) {
           }
         }
         if (a.bias != nullptr && gl == 0) {
-          atomic_add_f32(a.bias + i, lr * w);
-          atomic_add_f32(a.bias + j, -lr * w);
+          atomic_add_f32(a.bias + (uint32_t)i * (uint32_t)BIAS_LINE, lr * w);
+          atomic_add_f32(a.bias + (uint32_t)j * (uint32_t)BIAS_LINE, -lr * w);
         }
       }
     }
@@ -691,6 +698,19 @@ void k_stream(const StreamArgs a) {
     }
   }
   if (stats) reduce_scalars(a.partials, s_loss, s_reg, s_abs, s_cnt, lane);
+}
+
+// dense item_bias -> one item per line, and back (launch_stream, around every k_stream launch of a
+// model with an item_bias)
+__global__ __launch_bounds__(256) void k_bias_widen(const float* __restrict__ b, float* __restrict__ w,
+                                                    int32_t I) {
+  const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < I) w[(size_t)i * BIAS_LINE] = b[i];
+}
+__global__ __launch_bounds__(256) void k_bias_narrow(const float* __restrict__ w, float* __restrict__ b,
+                                                     int32_t I) {
+  const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < I) b[i] = w[(size_t)i * BIAS_LINE];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -381,6 +381,18 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       if (a.partials != nullptr) a.partials = c->dev_scalars + (size_t)c->acut_parity * 4 * (STREAM_MAX_GRID + 1);
       c->acut_parity ^= 1;
     }
+    if (a.bias != nullptr) {  // the launch works on the bias with one item per line (bpr_kernels.h)
+      if (c->bias_w_rows != c->I) {
+        hipFree(c->bias_w);
+        c->bias_w = nullptr;
+        c->bias_w_rows = 0;
+        BPR_HIP_CHECK(hipMalloc(&c->bias_w, sizeof(float) * (size_t)c->I * BIAS_LINE));
+        c->bias_w_rows = c->I;
+      }
+      hipLaunchKernelGGL(k_bias_widen, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream, c->bias,
+                         c->bias_w, (int32_t)c->I);
+      a.bias = c->bias_w;
+    }
     {
       Timer tm(c, true);
       (void)tm;
@@ -396,6 +408,9 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       };
       pick(go);
     }
+    if (a.bias != nullptr)
+      hipLaunchKernelGGL(k_bias_narrow, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream,
+                         c->bias_w, c->bias, (int32_t)c->I);
     if (acut) {
       // the cut of the next snapshot on the SIDE stream, behind this launch and beside the next
       // one: read-only (keys = Q + hot deltas, nothing folded), it also sums the loss partials
@@ -542,6 +557,7 @@ int bpr_ctx_destroy(bpr_ctx* c) {
   refresh_free(c);
   side_free(c);
   vs_free(c);
+  hipFree(c->bias_w);
   hipFree(c->dev_scalars);
   if (c->ev_launch) hipEventDestroy(c->ev_launch);
   for (auto e : c->ev_start) hipEventDestroy(e);
