@@ -272,7 +272,11 @@ int bpr_train_strict(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int
 
 /* STREAM throughput entry (train_one_epoch's inner loop, example.py:172-180, over n triples in ONE
  * launch): users/pos are the (already shuffled) triple stream resident in HBM.  `max_inflight`
- * bounds how many triples are processed concurrently (0 = fill the chip); see DESIGN.md §staleness. */
+ * bounds how many triples are processed concurrently (0 = fill the chip); see DESIGN.md §staleness.
+ * A model's item_bias is read and updated, for the duration of the launch, in a table of the
+ * library's own (one item per 128-byte line: DESIGN.md §9.5), filled from the bound vector in stream
+ * order before the launch and written back after it: the bound vector is current once the launch
+ * has completed on the ctx stream, not while it runs. */
 int bpr_train_stream(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
                      int64_t n, int32_t sampler, float adaptive_p, uint64_t seed, uint64_t offset,
                      int64_t max_inflight, float* out_scalars);
