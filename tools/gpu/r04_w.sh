@@ -1,3 +1,5 @@
 #!/bin/bash
 cd "$(dirname "$0")/../.."
-timeout 1200 python -m pytest tests/test_gpu_vstream.py tests/test_gpu_bench.py tests/test_gpu_e2e_parity.py tests/test_gpu_fullsize.py tests/test_metrics_product.py -x -q -m gpu -k "not strict_optimizers and not strict_api and not cfg1" 2>&1 | grep -E "passed|failed|^E " | head -8
+python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_vstream.py -x -q -m gpu 2>&1 | grep -E "passed|failed|^E " | head -5
+python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/bench_r04_driverlike.json; cut -c1-330 gpurun_out/bench_r04_driverlike.json
