@@ -85,10 +85,23 @@ struct Comm {
   hipEvent_t ev_hot_cut = nullptr, ev_hot_done = nullptr, ev_gather = nullptr;
 };
 
+// Leave the hot tier with the item table whole: fold the exchange in flight, fold what the launches
+// since left in the block (this rank's own deltas: nobody is asked for theirs), switch the tier off.
+static int comm_hot_close(bpr_ctx* c, Comm* m) {
+  if (m->hb == nullptr || !c->hot_tier) return BPR_OK;
+  if (m->hot_pending) BPR_HIP_CHECK(hipStreamWaitEvent(c->stream, m->ev_hot_done, 0));
+  if (int rc = bpr_hot_exchange(c, m->hb, m->htot, m->hot_pending ? 1 : 0, 1, m->base)) return rc;
+  m->hot_pending = false;
+  return bpr_hot_tier_end(c);
+}
+
 void comm_free(bpr_ctx* c) {
   Comm* m = static_cast<Comm*>(c->comm);
   if (m == nullptr) return;
   if (m->stream) hipStreamSynchronize(m->stream);
+  // the launches must not go on leaving hot-row deltas in a block nobody folds
+  if (c->P != nullptr && c->Q != nullptr) (void)comm_hot_close(c, m);
+  hipStreamSynchronize(c->stream);
   Rccl* l = rccl();
   if (m->comm && l) l->CommDestroy(m->comm);
   hipFree(m->base); hipFree(m->own); hipFree(m->tot);
@@ -298,7 +311,14 @@ int bpr_comm_hot_tier(bpr_ctx* c, const int32_t* items_host, int32_t H, const ui
   Comm* m = static_cast<Comm*>(c->comm);
   if (m == nullptr) return fail(BPR_ERR_INVALID, "bpr_comm_hot_tier: no communicator (bpr_comm_init first)");
   BPR_HIP_CHECK(hipSetDevice(c->device));
-  if (m->hot_pending) BPR_HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (c->hot_tier && m->hb != nullptr) {
+    // re-tiering mid-run (every rank calls this): one last exchange of what the launches since left in
+    // the block, folded at once, so that the replicas leave the old tier agreeing on its rows
+    if (int rc = comm_hot_sync(c, true)) return rc;
+    if (int rc = comm_hot_sync(c, false)) return rc;
+    if (int rc = bpr_hot_tier_end(c)) return rc;
+    BPR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  }
   m->hot_pending = false;
   if (c->hot_tier) bpr_hot_tier_end(c);
   hipFree(m->hb); hipFree(m->htot);

@@ -87,6 +87,8 @@ struct bpr_ctx {
   // afterwards clears it.
   bool keys_cut = false;
   bool keys_event = false;  // ev_keys was recorded by the cut kernel itself (hipExtLaunchKernelGGL)
+  bool keys_on_side = false;  // ... and that cut ran on `side` (bpr_train_stream_acut): a sort on `stream` waits for it
+  bool acut_pending = false;  // an asynchronous cut may still be reading Q, the hot deltas and a launch's partials
   // private scratch — epoch planner
   uint64_t* plan_keys = nullptr;
   uint64_t* plan_keys_sorted = nullptr;
@@ -166,6 +168,7 @@ int heavy_build_impl(bpr_ctx* c);   // bpr_refresh.hip
 void heavy_free(bpr_ctx* c);        // bpr_refresh.hip
 int hot_build_impl(bpr_ctx* c, const int32_t* pos, int64_t n);  // bpr_refresh.hip
 int hot_set_items_impl(bpr_ctx* c, const int32_t* items, int H, const uint32_t* counts);  // bpr_refresh.hip
+int flush_deferred_stats(bpr_ctx* c);  // bprcore.hip: loss partials a hot-tier cut launch left behind
 int hot_fold_impl(bpr_ctx* c);  // bprcore.hip: fold deltas left by bpr_train_stream_acut (no-op otherwise)
 void hot_free(bpr_ctx* c);                                       // bpr_refresh.hip
 int plan_chunk_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, int64_t n, int64_t chunk,

@@ -1070,8 +1070,15 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
     hipLaunchKernelGGL(k_transpose, tgrid, dim3(256), 0, c->stream, c->Q, c->keysT, I, d,
                        c->sig_acc);
   }
+  if (c->keys_cut && c->keys_on_side && !split) {
+    // the keys were cut on the side stream (bpr_train_stream_acut) and this sort runs on the launch
+    // stream: order it behind that cut (the split sort below waits for ev_keys on the side stream anyway)
+    BPR_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_keys, 0));
+    c->acut_pending = false;
+  }
   c->keys_cut = false;
   c->keys_event = false;
+  c->keys_on_side = false;
   // the sort reads the buffers just cut; the next cut goes to the other pair
   const float* const keysT = c->keysT + foff;
   double* const sig_acc = c->sig_acc + 2 * f_lo;

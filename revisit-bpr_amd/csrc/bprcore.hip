@@ -66,6 +66,7 @@ int hot_fold_impl(bpr_ctx* c) {
   if (c->hot_H <= 0) return BPR_OK;
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->ev_keys != nullptr) BPR_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_keys, 0));
+  c->acut_pending = false;
   EpilogueArgs ea;
   memset(&ea, 0, sizeof(ea));
   ea.Q = c->Q; ea.delta = c->hot_delta; ea.hot_items = c->hot_items;
@@ -74,6 +75,21 @@ int hot_fold_impl(bpr_ctx* c) {
   hipLaunchKernelGGL(k_stream_epilogue, dim3(1 + ea.fold_blocks), dim3(256), 0, c->stream, ea);
   BPR_HIP_CHECK(hipGetLastError());
   return BPR_OK;  // (Q + delta is what it was: keys cut from it stay valid)
+}
+
+// bpr_train_stream_cut under the hot tier leaves its loss partials to the bpr_sync_cut that should
+// follow.  Whoever comes first instead — the next launch (it overwrites the partials), a hot exchange
+// of the three-call protocol (bpr_hot_exchange / bpr_hot_sync), the end of the tier — sums them now.
+int flush_deferred_stats(bpr_ctx* c) {
+  if (!c->defer_pending) return BPR_OK;
+  c->defer_pending = false;
+  float* out = c->defer_out;
+  c->defer_out = nullptr;
+  if (out == nullptr || c->defer_blocks <= 0) return BPR_OK;
+  BPR_HIP_CHECK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->dev_scalars, c->defer_blocks, out);
+  BPR_HIP_CHECK(hipGetLastError());
+  return BPR_OK;
 }
 
 static int ensure_strict_scratch(bpr_ctx* c) {
@@ -265,6 +281,14 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
   if (a.n <= 0) return BPR_OK;
   if (cut)
     if (int rc = refresh_alloc(c)) return rc;
+  if (int rc = flush_deferred_stats(c)) return rc;  // (this launch overwrites the partials)
+  if (c->acut_pending && !acut) {
+    // the asynchronous cut of the previous launch still reads that launch's partials (and Q + the hot
+    // deltas) on the side stream: a launch outside the acut pipeline reuses the first set of partials
+    // and folds / moves the rows, so it waits for that cut
+    BPR_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_keys, 0));
+    c->acut_pending = false;
+  }
   return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
     constexpr int G = T::G, E = T::E;
@@ -367,7 +391,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     // hot tier + cut: fold, reconciliation passes and snapshot cut are ONE pass, bpr_sync_cut, which the
     // caller issues next; the launch leaves it its loss partials too
     const bool defer = cut && hot && c->hot_tier;
-    if (cut && c->ev_keys == nullptr) {
+    if ((cut || acut) && c->ev_keys == nullptr) {
       BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
       BPR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
     }
@@ -427,6 +451,8 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       BPR_HIP_CHECK(hipGetLastError());
       c->keys_cut = true;
       c->keys_event = true;
+      c->keys_on_side = true;  // whoever sorts these keys on the launch stream waits for ev_keys
+      c->acut_pending = true;
       c->hot_unfolded = hot;
       return BPR_OK;
     }
@@ -1207,6 +1233,7 @@ int bpr_hot_tier_begin(bpr_ctx* c, float* hot_base) {
 
 int bpr_hot_tier_end(bpr_ctx* c) {
   if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_hot_tier_end: ctx is NULL");
+  if (int rc = flush_deferred_stats(c)) return rc;
   c->hot_tier = false;  // (the caller has folded everything: bpr_hot_exchange with cut = 1 last)
   return BPR_OK;
 }
@@ -1218,6 +1245,7 @@ int bpr_hot_exchange(bpr_ctx* c, float* hot_base, float* tot, int32_t fold_prev,
   if (hot_base == nullptr || tot == nullptr)
     return fail(BPR_ERR_INVALID, "bpr_hot_exchange: NULL buffer");
   BPR_HIP_CHECK(hipSetDevice(c->device));
+  if (int rc = flush_deferred_stats(c)) return rc;  // a cut launch that was not followed by bpr_sync_cut
   c->keys_cut = false;  // the item table moves
   HotStepArgs a;
   memset(&a, 0, sizeof(a));

@@ -174,6 +174,20 @@ def generate_latent(users: int, items: int, actions: int, factors: int = 8, stre
         eval_items=he_i.astype(np.int32))
 
 
+def latent_factors(users: int, items: int, factors: int = 8, seed: int = 13) -> tuple[np.ndarray, np.ndarray]:
+    """The latent factors behind `generate_latent(users, items, ..., factors=factors, seed=seed)`:
+    Z [users + 1, factors], Y [items + 1, factors] (row 0 = the pad row, zero) — the same draws, replayed
+    in the generator's order.  A model initialised from them starts above the untrained floor, which
+    makes a short training prefix informative (tests/golden/make_golden_fullscale.py)."""
+    rng = np.random.default_rng(seed)
+    rng.standard_normal(users)   # n_u
+    rng.permutation(items)       # popularity ranks
+    Z = rng.standard_normal((users, factors)) / np.sqrt(factors)
+    Y = rng.standard_normal((items, factors)) / np.sqrt(factors)
+    return (np.vstack([np.zeros((1, factors)), Z]).astype(np.float32),
+            np.vstack([np.zeros((1, factors)), Y]).astype(np.float32))
+
+
 def generate_named(name: str, eval_users: int = 0, seed: int = 13, scale: float = 1.0,
                    **kw) -> Interactions:
     users, items, actions, med, mn = SHAPES[name]

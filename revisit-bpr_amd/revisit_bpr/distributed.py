@@ -72,6 +72,7 @@ class _DistComm:
     def __init__(self, group=None, cuda: bool = False) -> None:
         self.group = group
         self._side = torch.cuda.Stream() if cuda else None
+        self._done: dict = {}  # tag -> event behind the last all-reduce launched under that tag
         self.timing = False
         self.events: list = []
 
@@ -91,6 +92,10 @@ class _DistComm:
             with torch.cuda.stream(self._side):
                 for t in tensors:
                     self._one(t, tag)
+                ev = self._done.get(tag)
+                if ev is None:
+                    ev = self._done[tag] = torch.cuda.Event()
+                ev.record(self._side)
         else:
             for t in tensors:
                 self._one(t, tag)
@@ -106,8 +111,14 @@ class _DistComm:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def complete(self, tensors, tag=None) -> None:
+        """The current stream waits for the exchange launched last under `tag` — not for the whole side
+        stream: a hot exchange is folded without waiting for a cold all-reduce launched after it."""
         if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            ev = self._done.get(tag)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            elif self.world > 1:
+                torch.cuda.current_stream().wait_stream(self._side)
 
     def all_reduce_now(self, t, op=dist.ReduceOp.SUM) -> None:
         if self.world > 1:
@@ -388,6 +399,27 @@ class ItemSync:
             self._hot_pending = True
         self.comm.launch(self._tot, "cold")
         self._pending = True
+
+    @torch.no_grad()
+    def rebase(self) -> None:
+        """The replicated tensors were overwritten IN PLACE (a checkpoint restored into the same
+        storage, restore-best, STRICT steps between STREAM epochs): take them as the new reconciled
+        state.  Exchanges in flight are completed and dropped, the cold bases are re-cut from the
+        tensors, the hot base is re-gathered from the item table (without this the next `hot_step`
+        would write Q[hot] = old base + deltas and silently revert those rows).  Every rank calls it,
+        with the same tensors' content, at a point where the hot block holds no uncut deltas (after
+        `hot_finish()` / a `hot_step()`: the end of an epoch)."""
+        if self._hot_pending:
+            self.comm.complete([self._htot], "hot")
+            self._hot_pending = False
+        if self._pending:
+            self.comm.complete(self._tot, "cold")
+            self._pending = False
+        for t, b in zip(self.tensors, self.base):
+            b.copy_(t)
+        if self.hot_tier:
+            self._htot.zero_()
+            self.engine.hot_tier_begin(self._hb)
 
     def close(self) -> None:
         """Leave the hot tier (launches fold their hot block themselves again)."""

@@ -257,6 +257,8 @@ class StreamTrainer:
         else:
             e.adaptive_refresh()         # first launch: nothing in flight yet
         cut = lo if lag >= 1.0 else min(hi, lo + max(1, int(round((1.0 - lag) * (hi - lo)))))
+        # (fractional lag: BOTH phases always run — a short last chunk whose cut collapses onto its end
+        # still owes the other ranks the hot-tier exchanges of an empty second phase)
         if cut > lo:
             yield from self._launch(lo, cut)
         base = 0
@@ -270,7 +272,7 @@ class StreamTrainer:
             nxt = (self.epoch, index + 1) if (index + 1) * self.chunk < self.n else (self.epoch + 1, 0)
             self._plan(nxt[0], nxt[1], self._gk + 1, True)
             self._planned = nxt
-        if cut < hi:
+        if cut < hi or lag < 1.0:
             yield from self._launch(cut, hi, cut=fused, base=base)
         if self.jit_plan:
             self._gk += 1
@@ -286,6 +288,24 @@ class StreamTrainer:
         with self.stream_scope():  # the whole epoch on the CU-masked stream
             for _ in self.epoch_iter():
                 pass
+        return self.epoch_end()
+
+    def train_chunks(self, n: int) -> dict:
+        """The next `n` chunks (refresh periods) of the epoch in progress — a new epoch is begun, i.e.
+        planned, when none is; an epoch that ends on the way is closed and the call returns.  For a
+        training PREFIX (tests/test_gpu_fullscale_reference.py: the reference's own loop is timed in
+        refresh periods there); the statistics are those of the epoch so far."""
+        self.epoch_begin()  # the launch stream waits for whatever read the tables since (an evaluation)
+        if getattr(self, "_it", None) is None:
+            self._it = self.epoch_iter()
+        done = 0
+        with self.stream_scope():
+            while done < n:
+                try:
+                    done += next(self._it) == "chunk"
+                except StopIteration:
+                    self._it = None
+                    break
         return self.epoch_end()
 
     def epoch_begin(self) -> None:
@@ -332,7 +352,7 @@ class StreamTrainer:
             if self.item_sync is not None and (k + 1) % self.sync_every == 0 and not self._synced:
                 self.item_sync.step()
             self._synced = False
-            yield
+            yield "chunk"
         if self.item_sync is not None:
             self.item_sync.hot_finish()
             self.item_sync.finish()

@@ -39,7 +39,7 @@ FILE_ORDER = ["test_abi", "test_oracle_golden", "test_native_io_cpu", "test_conf
               "test_gpu_fullsize", "test_gpu_config_run", "test_gpu_example", "test_gpu_bench",
               # statistical (seed means against the reference's curves) — last
               "test_gpu_sampler_stats", "test_gpu_e2e_parity", "test_gpu_multirank_parity",
-              "test_gpu_fullscale_parity"]
+              "test_gpu_fullscale_parity", "test_gpu_fullscale_reference"]
 
 
 def _file_rank(item) -> int:

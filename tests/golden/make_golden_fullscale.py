@@ -47,8 +47,9 @@ GEN = dict(users=136677, items=20108, actions=9_700_000, factors=16, strength=1.
 D, B, LR, P_GEO = 128, 256, 0.05, 0.01
 REG = {"user": 0.0016, "item": 0.0001, "neg": 0.00375}
 INIT_SEED, ORDER_SEED = 13, 13
-# checkpoints in refresh periods (I ln I / B = 778 batches): ~0.26 and ~0.51 epoch
-CHECKPOINT_PERIODS = (12, 24)
+# checkpoints in refresh periods (I ln I / B = 778 batches): ~0.26 and ~0.51 epoch; E2E_PERIODS=12,24,36,47
+# runs on to the end of the first epoch (47 whole periods = 0.996 epoch)
+CHECKPOINT_PERIODS = tuple(int(x) for x in os.environ.get("E2E_PERIODS", "12,24").split(","))
 
 
 def dataset():
@@ -108,7 +109,7 @@ def run(seed, threads):
     items_t = torch.from_numpy(data.items.astype(np.int64))
     perm = np.random.default_rng(ORDER_SEED).permutation(data.nnz)  # DataLoader(shuffle=True) stand-in
     out = {"seed": seed, "checkpoints": {}, "threads": threads}
-    path = OUT / f"e2e_ml20m_reference_prefix_{seed}.json"
+    path = OUT / f"e2e_ml20m_reference_prefix_{seed}{'' if len(CHECKPOINT_PERIODS) <= 2 else '_long'}.json"
     t0 = time.time()
     nd0, rc0 = evaluate(model, data)
     out["checkpoints"]["0"] = {"batches": 0, "triples": 0, "ndcg@100": nd0, "recall@20": rc0}
@@ -153,9 +154,13 @@ def merge():
         res["runs"] = json.loads(main_file.read_text())["runs"]
     for f in sorted(OUT.glob("e2e_ml20m_reference_prefix_*.json")):
         j = json.loads(f.read_text())
-        if str(CHECKPOINT_PERIODS[-1]) in j["checkpoints"]:
+        old = res["runs"].get(str(j["seed"]), {})
+        if len(j["checkpoints"]) >= len(old):  # a longer run of the same seed replaces a shorter one
+            for k, v in old.items():           # ... and must reproduce it (torch CPU, same thread count)
+                assert k not in j["checkpoints"] or abs(j["checkpoints"][k]["ndcg@100"] - v["ndcg@100"]) < 1e-6, (f, k)
             res["runs"][str(j["seed"])] = j["checkpoints"]
-            f.unlink()
+        f.unlink()
+    res["config"]["checkpoint_periods"] = sorted({int(k) for r in res["runs"].values() for k in r})
     main_file.write_text(json.dumps(res, indent=1))
     print(main_file.name, sorted(res["runs"]))
 

@@ -1266,6 +1266,46 @@ def test_async_cut_reads_the_table_whole_and_folds_on_demand():
     assert close(res[0][2], res[1][2], 1e-4)
 
 
+@pytest.mark.parametrize("hot_rows", [0, 256])
+def test_sync_refresh_right_behind_an_async_cut_sorts_finished_keys(hot_rows):
+    """after bpr_train_stream_acut the keys of the next snapshot are cut on the SIDE stream.
+    A synchronous refresh (bpr_adaptive_refresh: StrictTrainer, bpr_train_strict's refresh_every) sorts
+    them on the launch stream — it must wait for that cut, with or without a hot block to fold, and a
+    launch outside the acut pipeline must not reuse the partials the cut still sums.  No host
+    synchronisation between the calls here: only the library's own events order them."""
+    rng = np.random.default_rng(18)
+    U, I, d, n = 6000, 9000, 128, 200_000
+    P = rng.normal(0, 0.1, (U, d)).astype(np.float32)
+    Q = rng.normal(0, 0.1, (I, d)).astype(np.float32)
+    P[0] = 0
+    Q[0] = 0
+    users = rng.integers(1, U, n).astype(np.int32)
+    pos = (1 + (rng.zipf(1.3, n) % (I - 1))).astype(np.int32)
+    neg = rng.integers(1, I, n).astype(np.int32)
+    e = make_engine(P, Q, None, (0.01, 0.02, 0.03))
+    e.bind_seen_csr(dev(np.zeros(U + 1, np.int64)), dev(np.zeros(0, np.int32)))
+    e.set_optimizer(kind=0, lr=0.01)
+    e.set_stream_opts(True, 0)
+    e.set_hot_rows(hot_rows, 1)
+    pu, pi = e.plan_epoch(dev(users), dev(pos), n, seed=3)
+    sc = torch.zeros(4, device="cuda")
+    e.adaptive_refresh()
+    torch.cuda.synchronize()
+    for k in range(4):
+        e.train_stream(pu, pi, sampler=0, neg=dev(neg), scalars=sc, cut="async")
+        e.adaptive_refresh()  # synchronous, on the launch stream, right behind the asynchronous cut
+        order = e.adaptive_snapshot()[0].cpu().numpy()
+        e.hot_fold()
+        torch.cuda.synchronize()
+        QT, _ = oracle.adaptive_stats(e.Q.cpu().numpy())
+        assert np.array_equal(order, oracle.adaptive_order(QT)), k
+    # ... and a plain launch behind an asynchronous one: both sets of statistics arrive whole
+    e.train_stream(pu, pi, sampler=0, neg=dev(neg), scalars=sc, cut="async")
+    e.train_stream(pu, pi, sampler=0, neg=dev(neg), scalars=sc)
+    torch.cuda.synchronize()
+    assert int(sc[3]) == 6 * n
+
+
 # ---- heavy users: precomputed seen bitmaps in HBM -------------------------------------------------
 @pytest.mark.parametrize("seen,heavy_t", [("", None), ("list", None), ("", "-1"), ("", "40"), ("list", "600")])
 @pytest.mark.parametrize("d", [64, 256])

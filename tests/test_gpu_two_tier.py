@@ -220,3 +220,46 @@ def test_trainers_over_local_world_with_uneven_shards(golden_dir, cadence, hot_r
 
     one, many = job(1), job(world)
     assert one > 0.25 and abs(many - one) < 0.03, (one, many)
+
+
+def test_cut_launch_under_the_hot_tier_keeps_its_statistics_without_sync_cut():
+    """`train_stream(cut=True)` under the hot tier leaves its loss partials to the
+    `bpr_sync_cut` that normally follows.  On the other documented two-tier path — hot exchange + cold
+    step as separate calls — nobody calls it: the sums must arrive anyway (flushed by the exchange, or by
+    the next launch before it overwrites the partials), once, and nothing stays pending."""
+    from revisit_bpr import engine as eng
+    from revisit_bpr.distributed import ItemSync, LocalWorld
+
+    U, I, d, n = 240, 150, 64, 900
+    P0, Q0, indptr, indices, users, pos = _problem(U, I, d, 3 * n, seed=5)
+    dev = torch.device("cuda")
+    counts = torch.bincount(torch.from_numpy(pos).long(), minlength=I)
+    u_d, p_d = torch.from_numpy(users).to(dev), torch.from_numpy(pos).to(dev)
+    totals = []
+    for path in ("sync_cut", "hot_step", "next_launch"):
+        e = eng.Engine(torch.from_numpy(P0).to(dev), torch.from_numpy(Q0).to(dev))
+        e.set_reg(0.01, 0.02, 0.03)
+        e.set_optimizer(eng.OPT_SGD, lr=0.05)
+        e.bind_seen_csr(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev))
+        e.set_stream_opts(True, 0)
+        sync = ItemSync([e.Q], comm=LocalWorld(1).member(0), engine=e, hot_rows=16, item_counts=counts,
+                        force_tiers=True)
+        assert sync.hot_tier
+        sc = torch.zeros(4, device=dev)
+        for k in range(3):
+            e.train_stream(u_d[k * n:(k + 1) * n], p_d[k * n:(k + 1) * n], sampler=eng.NEG_UNIFORM, seed=7,
+                           offset=k * n, max_inflight=1, scalars=sc, cut=True)
+            if path == "sync_cut":
+                sync.step_cut()
+            elif path == "hot_step":
+                sync.hot_step()
+                sync.step()
+            # "next_launch": nothing in between — the next launch must not overwrite unsummed partials
+        sync.hot_finish()
+        sync.finish()
+        sync.close()
+        torch.cuda.synchronize()
+        assert int(sc[3]) == 3 * n, (path, sc)
+        totals.append(sc.cpu().numpy())
+    # the same triples with the same negatives (max_inflight = 1: sequential): the same sums
+    assert np.allclose(totals[0], totals[1], rtol=1e-5) and np.allclose(totals[0], totals[2], rtol=1e-4)
