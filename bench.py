@@ -92,15 +92,45 @@ def cut_user_pieces(users, L, grouped):
     return float(cut.sum().item() + torch.unique(users[b[cut]]).numel())
 
 
+# Hyper-parameters of the BASELINE configs (files under the reference's configs/):
+# a --workload brings its own model width, batch size (refresh period), optimizer, learning rate, L2 and
+# sampler; every one of them can still be overridden on the command line.
+WORKLOADS = {
+    # configs[2] — the config the metric is quoted on: configs/RQ2/neg-sampling/ada-sampling-ml-20m.yaml.j2
+    "ml-20m": dict(dim=128, batch_size=256, optimizer="sgd", lr=0.001, reg=(0.0016, 0.0001, 0.00375),
+                   sampler="adaptive", source="configs/RQ2/neg-sampling/ada-sampling-ml-20m.yaml.j2:144-153"),
+    # configs[3]: configs/RQ2/neg-sampling/ada-sampling-msd.yaml.j2 (reg_alphas all: 0.00043)
+    "msd": dict(dim=256, batch_size=256, optimizer="sgd", lr=0.001, reg=(0.00043, 0.00043, 0.00043),
+                sampler="adaptive", source="configs/RQ2/neg-sampling/ada-sampling-msd.yaml.j2"),
+    # configs[4]: configs/RQ3/time-split/ada-sampling-adam.yaml.j2:165-175
+    "yelp": dict(dim=128, batch_size=256, optimizer="adam", lr=0.001, reg=(0.0025, 0.0025, 0.00025),
+                 sampler="adaptive", source="configs/RQ3/time-split/ada-sampling-adam.yaml.j2:165-175"),
+    # configs[1]: configs/RQ1/ours.yaml.j2:108-120 (Netflix, B = 16, uniform negatives)
+    "netflix": dict(dim=64, batch_size=16, optimizer="sgd", lr=0.05, reg=(0.0025, 0.0025, 0.00025),
+                    sampler="uniform", source="configs/RQ1/ours.yaml.j2:108-120"),
+    # configs[0]: example.py:290-296 on the synthetic 10k x 5k set
+    "cfg1-synth": dict(dim=32, batch_size=256, optimizer="sgd", lr=0.00943667980759196,
+                       reg=(0.0016, 0.0001, 0.00375), sampler="uniform", source="example.py:290-296"),
+}
+# HBM-side bytes per k_stream launch measured by separate rocprofv3 --pmc passes (profiles/*_pmc_traffic.md)
+# of exactly these commands: (workload, d, sampler, optimizer) -> file under profiles/
+TRAFFIC_FILES = {
+    ("ml-20m", 128, "adaptive", "sgd"): "traffic_r04.json",
+    ("msd", 256, "adaptive", "sgd"): "traffic_r04_msd_d256.json",
+}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default="ml-20m")
-    ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--sampler", choices=["adaptive", "uniform", "given"], default="adaptive")
-    ap.add_argument("--optimizer", choices=["sgd", "adam", "momentum", "rmsprop"], default="sgd",
+    ap.add_argument("--workload", default="ml-20m", choices=sorted(WORKLOADS))
+    ap.add_argument("--dim", type=int, default=None, help="default: the workload's (WORKLOADS)")
+    ap.add_argument("--sampler", choices=["adaptive", "uniform", "given"], default=None)
+    ap.add_argument("--reg", type=float, nargs=3, default=None, metavar=("USER", "ITEM", "NEG"),
+                    help="L2 (reg_alphas); default: the workload's")
+    ap.add_argument("--optimizer", choices=["sgd", "adam", "momentum", "rmsprop"], default=None,
                     help="sgd: the fused SGD STREAM kernel (BASELINE configs[2], the default); the "
                          "others run the batched STREAM kernel (virtual mini-batches of "
                          "--batch-size, one dense torch.optim step each; BASELINE configs[4] is "
@@ -110,8 +140,8 @@ def parse_args():
     ap.add_argument("--betas", type=float, nargs=2, default=(0.1, 0.999),
                     help="Adam betas (configs/RQ3/time-split/ada-sampling-adam.yaml.j2:175)")
     ap.add_argument("--adaptive-p", type=float, default=0.01)
-    ap.add_argument("--lr", type=float, default=0.001)
-    ap.add_argument("--batch-size", type=int, default=256,
+    ap.add_argument("--lr", type=float, default=None)
+    ap.add_argument("--batch-size", type=int, default=None,
                     help="reference batch size; only sets the refresh period I·ln(I)/B batches")
     ap.add_argument("--sync-every", type=int, default=1, help="item all-reduce period in steps (N>1)")
     ap.add_argument("--cadence", choices=["auto", "job", "rank"], default="auto",
@@ -174,19 +204,42 @@ def parse_args():
                          "its RQ configs switch it on).  Single GPU only here (a measurement aid: "
                          "profiles/shapes_r04.txt); the default 0 is the model every earlier round timed")
     ap.add_argument("--sustained-epochs", type=int, default=3,
-                    help="after the timed region: this many WHOLE epochs (plan + every step) timed by wall "
-                         "clock, reported as `sustained` (0 = skip)")
+                    help="after the K-step region: this many WHOLE epochs (every plan and every step in place) timed "
+                         "by wall clock between barriers — the headline `value`, on tables a few epochs from their "
+                         "random init as every round's line was (-1: as many as make ~0.6 s of work; 0 = skip: "
+                         "`value` is then the K-step region's).  See --steady-epochs for the trained state")
+    ap.add_argument("--steady-epochs", type=int, default=30,
+                    help="after the sustained region the job trains on, untimed, until this many epochs are done, and "
+                         "ONE more epoch is timed by wall clock: `steady_state` (0 = skip).  The adaptive sampler's "
+                         "negatives concentrate on popular rows and its walks get deeper once the model has moved "
+                         "(DESIGN.md §4.1 r5; tools/trained_state_probe.py): a long job sees this number, the first "
+                         "epochs from random init see `value`")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="WORLD_SIZE = 1 under torch.distributed.run: run the N > 1 code path anyway — RCCL process "
+                         "group, two-tier ItemSync, fused sync-cut, sharded refresh — with one rank (de-risks the "
+                         "first node run; tests/test_gpu_bench.py)")
+    ap.add_argument("--split-cold-mb", type=float, default=0.0,
+                    help="N>1: all-reduces of at least this many MB run as reduce-scatter + all-gather (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=13)
-    return ap.parse_args()
+    args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+    for k in ("dim", "sampler", "optimizer", "lr", "batch_size"):
+        if getattr(args, k) is None:
+            setattr(args, k, w[k])
+    args.reg = tuple(args.reg) if args.reg is not None else tuple(w["reg"])
+    return args
 
 
-def cpu_baseline(data, d, reg, lr, p, seconds, seed, sampler="adaptive"):
-    """The oracle (CPU port of the same path: adaptive sample → strict B=256 SGD step, sparse apply)
-    timed on one host core over a bounded number of batches."""
+def cpu_baseline(data, d, reg, lr, p, seconds, seed, sampler="adaptive", B=256):
+    """SURVEY §8d baseline (a): the C restatement of the same path (the oracle: sample a mini-batch's
+    negatives -> B gradients at the pre-step parameters -> one sparse SGD step; adaptive snapshot retaken
+    every I ln I / B batches) with OpenMP over the triples of a batch, timed on this host's cores over a
+    bounded number of batches.  The thread count is the fastest of a short probe; both are stated."""
     import oracle
 
+    host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     rng = np.random.default_rng(seed)
     P = ((rng.random((data.num_users, d)) - 0.5) / d).astype(np.float32)
     Q = ((rng.random((data.num_items, d)) - 0.5) / d).astype(np.float32)
@@ -195,29 +248,49 @@ def cpu_baseline(data, d, reg, lr, p, seconds, seed, sampler="adaptive"):
     QT, sigma = oracle.adaptive_stats(Q)
     order = oracle.adaptive_order(QT)
     perm = rng.permutation(data.nnz)
-    B, done, b0 = 256, 0, 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds and b0 + B <= data.nnz:
-        idx = perm[b0:b0 + B]
-        u, i = np.ascontiguousarray(data.users[idx]), np.ascontiguousarray(data.items[idx])
-        if sampler == "adaptive":
-            neg, _, _ = oracle.sample_adaptive(P, sigma, order, data.indptr, data.indices, u, p,
-                                               seed, offset=b0)
-        else:
-            neg = oracle.sample_uniform(data.indptr, data.indices, data.num_items, u, seed, b0)
-        oracle.step_sgd_sparse(P, Q, None, u, i, neg, lr, reg)
-        done += B
-        b0 += B
-    dt = time.perf_counter() - t0
+    users = np.ascontiguousarray(data.users[perm])
+    items = np.ascontiguousarray(data.items[perm])
+    every = max(1, int(data.num_items * math.log(data.num_items) / B))
+    smp = oracle.NEG_ADAPTIVE if sampler == "adaptive" else oracle.NEG_UNIFORM
+
+    def run(lo, secs, threads):
+        t0 = time.perf_counter()
+        done, _ = oracle.train_batches_omp(P, Q, users[lo:], items[lo:], B, smp, lr, reg, adaptive_p=p, QT=QT,
+                                           sigma=sigma, order=order, refresh_every=every, indptr=data.indptr,
+                                           indices=data.indices, seed=seed, offset=lo, seconds=secs, threads=threads)
+        return done, time.perf_counter() - t0
+
+    probe, lo = {}, 0
+    for th in sorted({1, min(host, 8), min(host, 32), min(host, 64), host}):
+        done, dt = run(lo, 0.5, th)
+        probe[th] = done / dt
+        lo += done
+    threads = max(probe, key=probe.get)
+    done, dt = run(lo, seconds, threads)
     return {
-        "value": done / dt, "unit": "triples/s", "cores": oracle.num_threads(), "kind": "port",
-        "sample": f"{done // B} batches of 256 triples ({done} triples, {dt:.1f} s) of the same "
-                  f"workload: oracle {sampler} sampler + strict SGD step, refresh "
-                  f"excluded; host has {os.cpu_count()} cores",
+        "value": done / dt, "unit": "triples/s", "cores": threads, "kind": "port",
+        "sample": f"{done // B} batches of {B} triples ({done} triples, {dt:.1f} s) of the same workload: the C "
+                  f"restatement (oracle/bpr_oracle.c orc_train_batches_omp: {sampler} sampler + strict SGD step, "
+                  f"snapshot refresh every {every} batches included) with OpenMP over the triples of a batch, "
+                  f"{threads} threads = the fastest of {sorted(probe)} on this {host}-core host "
+                  f"({', '.join(f'{k}: {v / 1e3:.0f} k/s' for k, v in sorted(probe.items()))})",
     }
 
 
-def cpu_reference_op_sequence(data, d, reg, lr, p, sampler, seed, warm=20, reps=3, steps=8):
+def torch_optimizer(params, name, lr, betas):
+    """the torch.optim object the reference's config would build for --optimizer (bench defaults:
+    momentum 0.9, RMSprop alpha 0.99 — what Engine.set_optimizer is given in main())"""
+    if name == "adam":
+        return torch.optim.Adam(params, lr=lr, betas=tuple(betas))
+    if name == "momentum":
+        return torch.optim.SGD(params, lr=lr, momentum=0.9)
+    if name == "rmsprop":
+        return torch.optim.RMSprop(params, lr=lr, alpha=0.99)
+    return torch.optim.SGD(params, lr=lr)
+
+
+def cpu_reference_op_sequence(data, d, reg, lr, p, sampler, seed, warm=20, reps=3, steps=8, optimizer="sgd",
+                              betas=(0.9, 0.999), B=256):
     """(b) of SURVEY §8d: the REFERENCE's op sequence restated on CPU tensors and timed with every
     host core — per batch of 256: `_sampling_weights` ([B, I] weights, seen + item 0 zeroed, row
     normalised: revisit_bpr/modules/neg_samplers.py:135-141) -> `torch.multinomial` (:31-37) or the
@@ -229,12 +302,12 @@ def cpu_reference_op_sequence(data, d, reg, lr, p, sampler, seed, warm=20, reps=
     from revisit_bpr.models.bpr import MF, set_backend
 
     host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    U, I, B = data.num_users, data.num_items, 256
+    U, I = data.num_users, data.num_items
     torch.manual_seed(seed)
     model = BPR(fuse_forward=True, reg_alphas=dict(zip(("user", "item", "neg"), reg)),
                 logits_model=MF(torch.nn.Embedding(U, d, padding_idx=0),
                                 torch.nn.Embedding(I, d, padding_idx=0)))
-    opt = torch.optim.SGD(model.parameters(), lr=lr)
+    opt = torch_optimizer(model.parameters(), optimizer, lr, betas)
     gen = torch.Generator().manual_seed(seed)
     lens = np.diff(data.indptr)
     S = int(min(lens.max(), 4096))
@@ -308,10 +381,11 @@ def cpu_reference_op_sequence(data, d, reg, lr, p, sampler, seed, warm=20, reps=
         "kind": "reference-op-sequence",
         "sample": f"the reference's op sequence restated on CPU tensors (torch {torch.__version__}, "
                   f"{threads} threads = the fastest of {sorted(probe)} on this {host}-core host): "
-                  f"[256, I] sampling weights + "
+                  f"[{B}, I] sampling weights + "
                   f"{'adaptive argsort' if sampler == 'adaptive' else 'multinomial'}, dense autograd, "
-                  f"dense torch.optim.SGD; {warm} warm steps, median of {reps} x {steps} timed steps "
-                  f"({ms:.1f} ms per step of 256 triples) of the same workload",
+                  f"dense {type(opt).__module__.split('.')[-1]}.{type(opt).__name__} step; {warm} warm steps, "
+                  f"median of {reps} x {steps} timed steps "
+                  f"({ms:.1f} ms per step of {B} triples) of the same workload",
     }
 
 
@@ -329,12 +403,21 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    forced = bool(args.force_dist) and world == 1  # the N > 1 code path with ONE rank, through RCCL
+    if forced and "MASTER_ADDR" not in os.environ:
+        raise SystemExit("--force-dist needs the rendezvous of torch.distributed.run (--nproc-per-node 1)")
+    rccl_ranks_seen = None
+    if world > 1 or forced:
         backend = os.environ.get("BPR_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        # ranks the communicator really spans: every rank contributes a one
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl_ranks_seen = int(ones.item())
+        assert rccl_ranks_seen == world, (rccl_ranks_seen, world)
 
     from revisit_bpr import engine as eng
     from revisit_bpr.datasets import synthetic
@@ -357,7 +440,7 @@ def main():
         raise SystemExit("--item-bias 1 is a single-GPU measurement")
     item_bias = torch.zeros(I, device=dev) if args.item_bias else None
     e = eng.Engine(P, Q, item_bias)
-    reg = (0.0016, 0.0001, 0.00375)  # configs/RQ2/neg-sampling/ada-sampling-ml-20m.yaml.j2:144-147
+    reg = args.reg  # the workload's reg_alphas (WORKLOADS) unless --reg
     e.set_reg(*reg)
     batched = args.batched or args.optimizer != "sgd"
     kind = {"sgd": eng.OPT_SGD, "momentum": eng.OPT_MOMENTUM, "adam": eng.OPT_ADAM,
@@ -368,11 +451,11 @@ def main():
     sampler = {"adaptive": eng.NEG_ADAPTIVE, "uniform": eng.NEG_UNIFORM, "given": eng.NEG_GIVEN}[args.sampler]
 
     # snapshot schedule of the adaptive sampler
-    sched = SCHEDULE if world == 1 or args.cadence != "job" else SCHEDULE_MULTI
+    sched = SCHEDULE if (world == 1 and not forced) or args.cadence != "job" else SCHEDULE_MULTI
     lag = sched["refresh_lag"] if args.refresh_lag is None else args.refresh_lag
     split = sched["refresh_split"] if args.refresh_split is None else args.refresh_split
     cus = sched["refresh_cus"] if args.refresh_cus is None else args.refresh_cus
-    shard_refresh = world > 1 and lag == 0.0 and not args.no_shard_refresh
+    shard_refresh = (world > 1 or forced) and lag == 0.0 and not args.no_shard_refresh
     if sampler != eng.NEG_ADAPTIVE or batched:
         lag, split, cus = 0.0, 1, 0
     # epoch order: bpr_plan_epoch = seeded pseudo-random partition of the triple list into chunks of
@@ -410,16 +493,21 @@ def main():
         total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         main_stream = eng.MaskedStream(dev, eng.cu_mask(total_cus - args.main_cus, args.main_cus, total_cus))
     sync = None
-    if world > 1 or emu:
+    if world > 1 or emu or forced:
         tier = args.tier_rows if (args.cadence != "job" and not batched) else 0
-        sync = ItemSync([Q], engine=e, hot_rows=tier, local_items=src_items, force_tiers=bool(emu))
+        comm = None
+        if forced or args.split_cold_mb > 0:
+            from revisit_bpr.distributed import _DistComm
+            comm = _DistComm(None, True, force=forced, split_bytes=int(args.split_cold_mb * 2**20))
+        sync = ItemSync([Q], engine=e, hot_rows=tier, local_items=src_items, force_tiers=bool(emu) or forced,
+                        comm=comm)
     pieces = args.hot_split if (sync is not None and sync.hot_tier) else 1
     scalars = torch.zeros(4, device=dev)
     seed = args.seed
     given_neg = (torch.randint(1, I, (chunk,), device=dev, dtype=torch.int32)
                  if sampler == eng.NEG_GIVEN else None)  # measurement aid only
 
-    fused = lag >= 1.0 and world == 1 and not emu  # the launch's epilogue cuts the next snapshot's keys
+    fused = lag >= 1.0 and world == 1 and not emu and not forced  # the launch's epilogue cuts the next snapshot's keys
     # several ranks: the reconciliation passes and the cut are ONE pass after the launch (--fuse-sync 0: r4's
     # first version, four kernels)
     fused_sync = (lag >= 1.0 and sync is not None and sync.hot_tier and sync.can_fuse and args.sync_every == 1
@@ -480,7 +568,7 @@ def main():
             launch(k, lo, lo + chunk, lo)
         elif lag == 0.0:
             if shard_refresh and not batched:
-                e.adaptive_refresh_sharded(rank, world)
+                e.adaptive_refresh_sharded(rank, world, force=forced)
             else:
                 e.adaptive_refresh()  # batched: brings the item rows to "now" first
             launch(k, lo, lo + chunk, lo)
@@ -507,7 +595,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -545,7 +633,13 @@ def main():
         # SUSTAINED: whole epochs in place — every epoch's bpr_plan_epoch where it belongs, nothing
         # modelled — wall clock over `sus_epochs` x n_chunks steps (the driver's 20-step
         # region is 5 ms and holds no plan)
-        sus_epochs = 0 if args.sustained_epochs <= 0 else args.sustained_epochs
+        sus_epochs = args.sustained_epochs
+        if sus_epochs < 0:  # ~0.6 s of work (the K-step region of the driver's --steps 20 is a few ms), >= 3 epochs
+            sus_epochs = int(min(max(math.ceil(0.6 / max(dt / args.steps * n_chunks, 1e-9)), 3), 400))
+            if world > 1:  # the same count on every rank
+                te = torch.tensor([sus_epochs], device=dev)
+                dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                sus_epochs = int(te.item())
         sus_dt = 0.0
         if sus_epochs > 0:
             k_s = ((first + args.steps) // n_chunks + 1) * n_chunks  # the next epoch boundary
@@ -560,6 +654,40 @@ def main():
             torch.cuda.synchronize()
             sus_dt = time.perf_counter() - ts
             barrier()
+        kernel_ms, launches = e.timing_read()
+        e.timing_enable(False)
+        # STEADY STATE: train on (untimed) to --steady-epochs epochs, then one whole epoch by wall clock
+        steady = None
+        steady_steps = 0
+        if args.steady_epochs > 0:
+            k_now = (k_s + sus_epochs * n_chunks) if sus_epochs > 0 else ((first + args.steps) // n_chunks + 1) * n_chunks
+            k_end = max(args.steady_epochs * n_chunks, k_now)
+            for k in range(k_now, k_end):
+                step(k)
+            barrier()
+            e.timing_enable(max(1, args.time_every))
+            tq = time.perf_counter()
+            for k in range(k_end, k_end + n_chunks):
+                step(k)
+            if sync is not None:
+                sync.hot_finish()
+                sync.finish()
+            if acut:
+                e.hot_fold()
+            torch.cuda.synchronize()
+            st_dt = time.perf_counter() - tq
+            barrier()
+            st_kernel_ms, st_launches = e.timing_read()
+            e.timing_enable(False)
+            steady_steps = k_end + n_chunks - k_now
+            if world > 1:
+                tt = torch.tensor([st_dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                st_dt = float(tt.item())
+            steady = {"epochs_trained_before": k_end // n_chunks, "steps": n_chunks, "ms_per_step": st_dt * 1e3 / n_chunks,
+                      "value": n_chunks * chunk * world / st_dt, "kernel_ms_avg": st_kernel_ms,
+                      "note": "one whole epoch by wall clock after that many epochs of the same job (lr as configured): "
+                              "the state a long training run is in"}
         # the epoch plan, timed on its own (3 calls; it does not touch the model)
         tp = time.perf_counter()
         for r in range(3):
@@ -574,8 +702,6 @@ def main():
     if jit:  # every chunk's plan ran inside the region (on the side stream): nothing to add
         plans_timed = args.steps / n_chunks
     dt += max(0.0, args.steps / n_chunks - plans_timed) * plan_ms * 1e-3
-    kernel_ms, launches = e.timing_read()
-    e.timing_enable(False)
     if world > 1:
         t = torch.tensor([dt, sus_dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -586,7 +712,7 @@ def main():
     q_after = Q.double().sum().item(), Q.abs().double().sum().item()
     # a kernel that did nothing cannot produce a number: every triple of the timed region was
     # counted by the kernel itself, the loss it accumulated is a real -log sigma, the tables moved
-    counted = (args.steps + sus_epochs * n_chunks) * chunk
+    counted = (args.steps + sus_epochs * n_chunks + steady_steps) * chunk
     assert int(round(float(sc[3]))) == counted, (sc[3], counted)
     assert 0.0 < float(sc[0] / sc[3]) < 5.0 and q_after != q_before and torch.isfinite(Q).all()
     # line-atomics per triple of the chunk planned last (what the L2 atomic units see): 2 item rows
@@ -603,7 +729,11 @@ def main():
                 "rmsprop": f"RMSprop lr={args.lr} alpha=0.99"}[args.optimizer]
     if rank == 0:
         triples = args.steps * chunk * world
-        value = triples / dt
+        region_value = args.steps * chunk * world / dt_measured  # the K-step region as measured (no plan inside unless an epoch began there)
+        region_value_with_plan = triples / dt
+        # headline: whole epochs by wall clock (every plan in place, nothing modelled) when they were run
+        value = (sus_epochs * n_chunks * chunk * world / sus_dt) if sus_epochs > 0 else region_value_with_plan
+        ms_per_step = (sus_dt * 1e3 / (sus_epochs * n_chunks)) if sus_epochs > 0 else dt * 1e3 / args.steps
         # SGD reads and writes 3 rows (+ 2 int32 ids); Adam reads and writes w, m, v of 3
         # rows (+ ids + 24 B of per-row step marks); momentum / RMSprop carry one state table
         bytes_per_triple = {"sgd": 24 * d + 8, "adam": 72 * d + 32, "momentum": 48 * d + 32,
@@ -612,12 +742,9 @@ def main():
         # summary of separate rocprofv3 --pmc passes of this same command (profiles/*_pmc_traffic.md:
         # FETCH_SIZE x2 correction + WRITE_SIZE); null when the run is not the profiled configuration
         traffic = None
-        # (one file per profiled shape: traffic_rNN.json = ml-20m d=128, traffic_rNN_msd_d256.json = BASELINE configs[3])
-        suffix = {("ml-20m", 128): "", ("msd", 256): "_msd_d256"}.get((args.workload, d))
-        tfiles = sorted(f for f in (ROOT / "profiles").glob("traffic_r*.json")
-                        if suffix is not None and f.stem.count("_") == (1 if suffix == "" else 3) and f.stem.endswith(suffix or f.stem[-3:]))
-        tfile = tfiles[-1] if tfiles else ROOT / "profiles" / "none"
-        if tfile.exists() and args.sampler == "adaptive" and args.scale == 1.0 and not batched:
+        tname = TRAFFIC_FILES.get((args.workload, d, args.sampler, args.optimizer))
+        tfile = ROOT / "profiles" / (tname or "none")
+        if tfile.exists() and args.scale == 1.0 and not batched and not args.item_bias:
             tj = json.loads(tfile.read_text())
             if tj.get("triples_per_launch") == chunk:
                 traffic = tj["traffic_bytes_per_launch"]
@@ -629,7 +756,13 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps,
+            "ms_per_step": ms_per_step,
+            "value_source": ("sustained: %d whole epochs = %d steps by wall clock between barriers, every bpr_plan_epoch "
+                             "in place, nothing modelled" % (sus_epochs, sus_epochs * n_chunks)) if sus_epochs > 0 else
+                            "the K-step region (+ the plan's amortised share when no epoch began inside it)",
+            "timed_region": {"steps": args.steps, "ms_per_step_measured": dt_measured * 1e3 / args.steps,
+                             "value_measured": region_value, "plans_inside": plans_timed,
+                             "value_with_amortised_plan": region_value_with_plan},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -690,6 +823,8 @@ def main():
                 "launches": launches,
             },
         }
+        if steady is not None:
+            out["steady_state"] = steady
         if sus_epochs > 0:
             out["sustained"] = {
                 "epochs": sus_epochs, "steps": sus_epochs * n_chunks,
@@ -714,16 +849,22 @@ def main():
             st["sync_every_steps"] = args.sync_every
             st["hidden_if_below_ms"] = dt * 1e3 / args.steps * args.sync_every
             out["item_sync"] = st
+        if rccl_ranks_seen is not None:
+            out["rccl_ranks_seen"] = rccl_ranks_seen
+            out["dist_backend"] = dist.get_backend()
+            out["forced_distributed"] = forced
         if not args.no_cpu_baseline:
             smp = "uniform" if args.sampler == "given" else args.sampler
             out["cpu_baseline"] = cpu_reference_op_sequence(data, d, reg, args.lr, args.adaptive_p,
-                                                            smp, args.seed)
-            # the 1-core C port of the same path (the oracle) beside it: sparse apply, no [B, I]
-            # weights — kinder to the CPU than the reference's own op sequence
+                                                            smp, args.seed, optimizer=args.optimizer,
+                                                            betas=tuple(args.betas), B=args.batch_size)
+            # the C restatement of the same path with OpenMP over triples beside it: sparse
+            # apply, no [B, I] weights — kinder to the CPU than the reference's own op sequence (plain SGD
+            # step whatever --optimizer: the C port has no sparse form of the stateful optimizers)
             out["cpu_baseline_c_port"] = cpu_baseline(data, d, reg, args.lr, args.adaptive_p,
-                                                      args.cpu_seconds, args.seed, smp)
+                                                      args.cpu_seconds, args.seed, smp, B=args.batch_size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

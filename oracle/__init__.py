@@ -266,7 +266,29 @@ def train_stream_seq(P, Q, bias, users, pos, neg, sampler, lr, alphas=(0.0, 0.0,
 
 
 def num_threads() -> int:
-    return 1  # scalar port
+    return 1  # the functions above are a scalar port
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+def train_batches_omp(P, Q, users, pos, B, sampler, lr, alphas=(0.0, 0.0, 0.0), adaptive_p=0.01, QT=None,
+                      sigma=None, order=None, refresh_every=0, indptr=None, indices=None, seed=0, offset=0,
+                      pad_user=0, pad_item=0, seconds=0.0, threads=0):
+    """Mini-batches of the path with OpenMP over the triples of a batch (SURVEY §8d baseline (a));
+    updates P / Q (and the snapshot buffers) in place, returns (triples trained, scalars)."""
+    U, d = P.shape
+    I = Q.shape[0]
+    sc = np.zeros(4, np.float64)
+    fn = lib().orc_train_batches_omp
+    fn.restype = ctypes.c_int64
+    done = fn(_f(P), _f(Q), c_i64(U), c_i64(I), c_i32(d), _i32(users), _i32(pos), c_i64(len(users)), c_i64(B),
+              c_i32(sampler), c_f(adaptive_p), _f(QT), _f(sigma), _i32(order), c_i64(refresh_every),
+              _i64(indptr), _i32(indices), c_u64(seed), c_u64(offset), c_f(alphas[0]), c_f(alphas[1]),
+              c_f(alphas[2]), c_i32(pad_user), c_i32(pad_item), c_f(lr), ctypes.c_double(seconds),
+              c_i32(threads), _p(sc, np.float64))
+    return int(done), sc
 
 
 __all__ = [n for n in dir() if not n.startswith("_")]

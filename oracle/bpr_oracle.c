@@ -545,3 +545,146 @@ void orc_train_stream_seq(float* P, float* Q, float* item_bias, int64_t U, int64
                   indptr, indices, seed, offset, a_user, a_item, a_neg, pad_user, pad_item, lr,
                   scalars);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * CPU baseline (a) of SURVEY §8d: the same path — sample a mini-batch's negatives, evaluate its B
+ * gradients at the parameters before the step, one sparse SGD step, the adaptive snapshot retaken
+ * every `refresh_every` batches — with OpenMP over the triples of a batch (and over the columns
+ * of a refresh).  bench.py times it; no test relies on it beyond equality with the serial route.
+ * ---------------------------------------------------------------------------------------- */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static void order_parallel(const float* QT, int64_t I, int32_t d, int32_t* order) {
+#pragma omp parallel
+  {
+    vid* tmp = (vid*)malloc(sizeof(vid) * (size_t)I);
+#pragma omp for schedule(dynamic, 1)
+    for (int32_t f = 0; f < d; ++f) {
+      for (int64_t i = 0; i < I; ++i) { tmp[i].v = QT[(int64_t)f * I + i]; tmp[i].id = (int32_t)i; }
+      qsort(tmp, (size_t)I, sizeof(vid), cmp_desc);
+      for (int64_t i = 0; i < I; ++i) order[(int64_t)f * I + i] = tmp[i].id;
+    }
+    free(tmp);
+  }
+}
+
+/* Trains mini-batches [0, n / B) of the stream; returns the number of triples trained, or -1.
+ * sampler: ORC_NEG_UNIFORM | ORC_NEG_ADAPTIVE.  QT / sigma / order: snapshot buffers of the caller
+ * ([d, I], [d], [d, I]), valid on entry for the adaptive sampler.  seconds > 0: stop after the batch
+ * that crosses that wall-clock budget.  threads <= 0: the OpenMP default. */
+int64_t orc_train_batches_omp(float* P, float* Q, int64_t U, int64_t I, int32_t d, const int32_t* users,
+                              const int32_t* pos, int64_t n, int64_t B, int32_t sampler, float adaptive_p,
+                              float* QT, float* sigma, int32_t* order, int64_t refresh_every,
+                              const int64_t* indptr, const int32_t* indices, uint64_t seed, uint64_t offset,
+                              float a_user, float a_item, float a_neg, int32_t pad_user, int32_t pad_item,
+                              float lr, double seconds, int32_t threads, double* scalars) {
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+  const double t_begin = omp_get_wtime();
+#else
+  (void)threads; (void)seconds;
+#endif
+  float* GP = (float*)calloc((size_t)U * (size_t)d, sizeof(float));
+  float* GQ = (float*)calloc((size_t)I * (size_t)d, sizeof(float));
+  int32_t* flagP = (int32_t*)calloc((size_t)U, sizeof(int32_t));
+  int32_t* flagQ = (int32_t*)calloc((size_t)I, sizeof(int32_t));
+  int64_t* touched = (int64_t*)malloc(sizeof(int64_t) * (size_t)(3 * B));
+  int32_t* neg = (int32_t*)malloc(sizeof(int32_t) * (size_t)B);
+  if (!GP || !GQ || !flagP || !flagQ || !touched || !neg) {
+    free(GP); free(GQ); free(flagP); free(flagQ); free(touched); free(neg);
+    return -1;
+  }
+  double loss = 0, reg = 0, sabs = 0;
+  int64_t done = 0, iter = 0;
+  for (int64_t lo = 0; lo + B <= n; lo += B) {
+    const int32_t* us = users + lo;
+    const int32_t* ps = pos + lo;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t b = 0; b < B; ++b) {
+      const int32_t u = us[b];
+      if (sampler == ORC_NEG_ADAPTIVE) {
+        int32_t f, rk;
+        adaptive_draw(P + (int64_t)u * d, d, sigma, I, indptr[u + 1] - indptr[u], adaptive_p, seed,
+                      offset + (uint64_t)(lo + b), &f, &rk);
+        neg[b] = orc_adaptive_pick(order, I, indptr, indices, u, f, rk);
+      } else {
+        neg[b] = sample_uniform_one(indptr, indices, I, u, seed, offset + (uint64_t)(lo + b));
+      }
+    }
+    ++iter;
+    if (sampler == ORC_NEG_ADAPTIVE && refresh_every > 0 && iter % refresh_every == 0) {
+      orc_adaptive_stats(Q, I, d, QT, sigma);  /* AdaptiveSampler.update_stats (neg_samplers.py:122-132) */
+      order_parallel(QT, I, d, order);
+    }
+    int64_t n_touched = 0;
+#pragma omp parallel for schedule(static) reduction(+ : loss, reg, sabs)
+    for (int64_t b = 0; b < B; ++b) {
+      const int32_t u = us[b], i = ps[b], j = neg[b];
+      const float* p = P + (int64_t)u * d;
+      const float* qi = Q + (int64_t)i * d;
+      const float* qj = Q + (int64_t)j * d;
+      const double x = (double)((float)ddot(p, qi, d) - (float)ddot(p, qj, d));
+      const float w = (float)(1.0 / (1.0 + exp(x)));
+      loss += neg_logsigmoid(x);
+      sabs += fabs(x);
+      reg += 0.5 * ((double)a_item * ddot(qi, qi, d) + (double)a_neg * ddot(qj, qj, d) +
+                    (double)a_user * ddot(p, p, d));
+      float* gu = GP + (int64_t)u * d;
+      float* gi = GQ + (int64_t)i * d;
+      float* gj = GQ + (int64_t)j * d;
+      for (int32_t k = 0; k < d; ++k) {
+        const float pk = p[k], qik = qi[k], qjk = qj[k];
+        const float du = -w * (qik - qjk) + a_user * pk, di = -w * pk + a_item * qik,
+                    dj = w * pk + a_neg * qjk;
+#pragma omp atomic
+        gu[k] += du;
+#pragma omp atomic
+        gi[k] += di;
+#pragma omp atomic
+        gj[k] += dj;
+      }
+      int64_t slot;
+      if (__atomic_exchange_n(&flagP[u], 1, __ATOMIC_RELAXED) == 0) {
+        slot = __atomic_fetch_add(&n_touched, 1, __ATOMIC_RELAXED);
+        touched[slot] = 2 * (int64_t)u;
+      }
+      if (__atomic_exchange_n(&flagQ[i], 1, __ATOMIC_RELAXED) == 0) {
+        slot = __atomic_fetch_add(&n_touched, 1, __ATOMIC_RELAXED);
+        touched[slot] = 2 * (int64_t)i + 1;
+      }
+      if (__atomic_exchange_n(&flagQ[j], 1, __ATOMIC_RELAXED) == 0) {
+        slot = __atomic_fetch_add(&n_touched, 1, __ATOMIC_RELAXED);
+        touched[slot] = 2 * (int64_t)j + 1;
+      }
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < n_touched; ++s) {
+      const int64_t key = touched[s], row = key >> 1;
+      float* w = (key & 1) ? Q + row * d : P + row * d;
+      float* g = (key & 1) ? GQ + row * d : GP + row * d;
+      const int pad = (key & 1) ? row == pad_item : row == pad_user;
+      for (int32_t k = 0; k < d; ++k) {
+        if (!pad) w[k] = w[k] - lr * g[k];
+        g[k] = 0.0f;
+      }
+      if (key & 1) flagQ[row] = 0; else flagP[row] = 0;
+    }
+    done += B;
+#ifdef _OPENMP
+    if (seconds > 0.0 && omp_get_wtime() - t_begin >= seconds) break;
+#endif
+  }
+  if (scalars) { scalars[0] = loss; scalars[1] = reg; scalars[2] = sabs; scalars[3] = (double)done; }
+  free(GP); free(GQ); free(flagP); free(flagQ); free(touched); free(neg);
+  return done;
+}

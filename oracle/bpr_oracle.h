@@ -121,6 +121,20 @@ void orc_train_stream_seq(float* P, float* Q, float* item_bias, int64_t U, int64
                           uint64_t seed, uint64_t offset, float a_user, float a_item, float a_neg,
                           int32_t pad_user, int32_t pad_item, float lr, double* scalars);
 
+/* CPU baseline (a) of SURVEY §8d: mini-batches of the same path with OpenMP over the triples of a
+ * batch (sampling, gradients at the pre-step parameters, one sparse SGD step per batch) and over the
+ * columns of the adaptive refresh (every `refresh_every` batches; QT [d,I] / sigma [d] / order [d,I]
+ * are the caller's snapshot buffers).  seconds > 0: wall-clock budget; threads <= 0: OpenMP's default.
+ * Returns the triples trained (-1: out of memory).  Timed by bench.py; equal to orc_step_sgd_sparse
+ * batch by batch up to fp32 association (tests/test_oracle_golden.py). */
+int orc_max_threads(void);
+int64_t orc_train_batches_omp(float* P, float* Q, int64_t U, int64_t I, int32_t d, const int32_t* users,
+                              const int32_t* pos, int64_t n, int64_t B, int32_t sampler, float adaptive_p,
+                              float* QT, float* sigma, int32_t* order, int64_t refresh_every,
+                              const int64_t* indptr, const int32_t* indices, uint64_t seed, uint64_t offset,
+                              float a_user, float a_item, float a_neg, int32_t pad_user, int32_t pad_item,
+                              float lr, double seconds, int32_t threads, double* scalars);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,8 +69,15 @@ class _DistComm:
     """torch.distributed: the all-reduce is enqueued on a side stream, `complete` makes the current
     stream wait for it."""
 
-    def __init__(self, group=None, cuda: bool = False) -> None:
+    def __init__(self, group=None, cuda: bool = False, force: bool = False, split_bytes: int = 0) -> None:
+        """force: enqueue the collectives even when the group has ONE rank (bench.py --force-dist: the
+        N > 1 code path through RCCL on one GPU).  split_bytes > 0: an all-reduce of at least that many
+        bytes runs as reduce-scatter + all-gather — on the 7-link xGMI ring each phase moves 1/N of
+        the message per link and the two can be scheduled around the hot tier's small exchanges
+        (NCCL / RCCL groups only, gloo keeps the plain all-reduce)."""
         self.group = group
+        self.force = bool(force)
+        self.split_bytes = int(split_bytes)
         self._side = torch.cuda.Stream() if cuda else None
         self._done: dict = {}  # tag -> event behind the last all-reduce launched under that tag
         self.timing = False
@@ -85,7 +92,7 @@ class _DistComm:
         return dist.get_rank(self.group) if dist.is_initialized() else 0
 
     def launch(self, tensors, tag=None) -> None:
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return
         if self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream())
@@ -100,15 +107,36 @@ class _DistComm:
             for t in tensors:
                 self._one(t, tag)
 
+    def _reduce(self, t) -> None:
+        nbytes = t.numel() * t.element_size()
+        w = self.world
+        if self.split_bytes > 0 and nbytes >= self.split_bytes and t.is_cuda and dist.get_backend(self.group) == "nccl":
+            # reduce-scatter + all-gather over a zero-padded flat view (numel need not divide by world)
+            flat = t.view(-1)
+            per = -(-flat.numel() // w)
+            if per * w != flat.numel():
+                buf = torch.zeros(per * w, dtype=t.dtype, device=t.device)
+                buf[:flat.numel()].copy_(flat)
+            else:
+                buf = flat
+            part = torch.empty(per, dtype=t.dtype, device=t.device)
+            dist.reduce_scatter_tensor(part, buf, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(buf, part, group=self.group)
+            if buf is not flat:
+                flat.copy_(buf[:flat.numel()])
+            self.split_used = getattr(self, "split_used", 0) + 1
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def _one(self, t, tag) -> None:
         if self.timing and self._side is not None:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._reduce(t)
             b.record()
             self.events.append((a, b, t.numel() * t.element_size(), tag))
         else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._reduce(t)
 
     def complete(self, tensors, tag=None) -> None:
         """The current stream waits for the exchange launched last under `tag` — not for the whole side
@@ -117,11 +145,11 @@ class _DistComm:
             ev = self._done.get(tag)
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
-            elif self.world > 1:
+            elif self.world > 1 or self.force:
                 torch.cuda.current_stream().wait_stream(self._side)
 
     def all_reduce_now(self, t, op=dist.ReduceOp.SUM) -> None:
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_reduce(t, op=op, group=self.group)
 
 

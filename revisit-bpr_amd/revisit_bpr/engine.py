@@ -256,14 +256,16 @@ class Engine:
         sigma = torch.as_tensor(_Dev(g.value, (self.d,), "<f4"), device=self.device)
         return order, sigma
 
-    def adaptive_refresh_sharded(self, rank: int, world: int, group=None) -> None:
+    def adaptive_refresh_sharded(self, rank: int, world: int, group=None, force: bool = False) -> None:
         """``adaptive_refresh`` with the sort shared by the ranks of a multi-GPU job: this rank
         sorts d / world factors of ITS replica of the item table, an all-gather hands every rank
         every factor's order (10 MB at ML-20M / d = 128) and the same snapshot is published
-        everywhere.  Falls back to the full refresh when d does not divide by world."""
+        everywhere.  Falls back to the full refresh when d does not divide by world.
+        force: take the sharded route with ONE rank too (part + all-gather + publish through the process
+        group: bench.py --force-dist)."""
         import torch.distributed as dist
 
-        if world <= 1 or self.d % world != 0:
+        if (world <= 1 and not force) or self.d % max(world, 1) != 0:
             return self.adaptive_refresh()
         self._sync_stream()
         per = self.d // world

@@ -35,9 +35,55 @@ def test_bench_single_gpu_line():
     sched = j["config"]["refresh_schedule"]
     assert sched["lag"] == 1.0 and sched["side_stream_cus"] >= 64  # the schedule the gates hold
     sus = j["sustained"]  # whole epochs, every plan in place
-    assert j["config"]["triples_counted_by_kernel"] == (6 + sus["steps"]) * j["config"]["triples_per_step_per_gpu"]
-    assert sus["epochs"] == 3 and sus["value"] > 1e6 and 0 < r["read_only_frac"] < r["frac"]
+    st = j["steady_state"]  # one epoch timed after 30 epochs of the same job: the trained state
+    spe = j["config"]["steps_per_epoch"]
+    assert st["epochs_trained_before"] >= 30 and st["steps"] == spe and st["value"] > 1e6
+    trained = st["epochs_trained_before"] * spe + spe - ((6 + 2 + 1) // spe + 1 + sus["epochs"]) * spe
+    assert j["config"]["triples_counted_by_kernel"] == (6 + sus["steps"] + trained) * j["config"]["triples_per_step_per_gpu"]
+    assert sus["epochs"] >= 3 and sus["value"] > 1e6 and 0 < r["read_only_frac"] < r["frac"]
+    # the headline is the whole-epoch wall-clock number; the K-step region rides along, nothing modelled in it
+    assert j["value"] == sus["value"] and j["value_source"].startswith("sustained")
+    assert j["timed_region"]["steps"] == 6 and j["timed_region"]["value_measured"] > 1e6
     assert j["config"]["parity"]["tolerance_north_star"] == 0.002
+    port = j["cpu_baseline_c_port"]  # the C restatement with OpenMP over triples
+    assert port["kind"] == "port" and port["cores"] >= 1 and port["value"] > 0 and "OpenMP" in port["sample"]
+    assert "optim.sgd.SGD" in j["cpu_baseline"]["sample"] or "SGD" in j["cpu_baseline"]["sample"]
+
+
+def test_bench_workload_brings_its_own_hyperparameters():
+    """--workload yelp = BASELINE configs[4]: Adam(0.1, 0.999), reg .0025/.0025/.00025, and a CPU baseline
+    with the SAME optimizer (the committed cfg5 line carried an SGD baseline)."""
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "yelp", "--scale", "0.1",
+                          "--steps", "4", "--warmup", "2", "--cpu-seconds", "1", "--sustained-epochs", "1",
+                          "--steady-epochs", "0"],
+                         capture_output=True, text=True, timeout=900)
+    j = _line(res)
+    w = j["config"]["workload"]
+    assert "Adam lr=0.001 betas=(0.1, 0.999)" in w and "(0.0025, 0.0025, 0.00025)" in w and "d=128" in w
+    assert "Adam" in j["cpu_baseline"]["sample"] and j["roofline"]["kernel"].startswith("k_vstream")
+
+
+@pytest.mark.parametrize("cadence", ["auto", "job"])
+def test_bench_forced_distributed_one_rank_through_rccl(cadence):
+    """WORLD_SIZE = 1 under torch.distributed.run with backend nccl drives the exact
+    N > 1 code path of bench.py through RCCL — process group on the device, two-tier ItemSync with both
+    all-reduces on the side stream (auto: fused bpr_sync_cut; job: the sharded refresh's all-gather), the
+    cold message as reduce-scatter + all-gather behind the size switch — before a node ever sees it."""
+    env = dict(os.environ)
+    env.pop("BPR_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29673", str(ROOT / "bench.py"), "--gpus", "1",
+           "--force-dist", "--scale", "0.05", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+           "--cadence", cadence, "--sustained-epochs", "1", "--steady-epochs", "0", "--split-cold-mb", "1"]
+    j = _line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900))
+    assert j["rccl_ranks_seen"] == 1 and j["dist_backend"] == "nccl" and j["forced_distributed"] is True
+    assert j["item_sync"]["all_reduces"] >= 6 and j["item_sync"]["all_reduce_ms_avg"] > 0
+    if cadence == "job":
+        assert j["config"]["refresh_schedule"]["sharded_over_ranks"] is True
+    else:
+        assert j["item_sync"]["hot"]["all_reduces"] >= 6 and j["config"]["refresh_schedule"]["lag"] == 1.0
+    steps = 6 + j["sustained"]["steps"]
+    assert j["config"]["triples_counted_by_kernel"] == steps * j["config"]["triples_per_step_per_gpu"]
 
 
 @pytest.mark.parametrize("cadence", ["auto", "job"])
@@ -46,7 +92,7 @@ def test_bench_two_ranks_over_gloo(cadence):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29671", str(ROOT / "bench.py"), "--gpus", "2",
            "--scale", "0.05", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--cadence", cadence,
-           "--sustained-epochs", "1"]
+           "--sustained-epochs", "1", "--steady-epochs", "0"]
     j = _line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900))
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 1e6
     assert j["config"]["cadence"].startswith(cadence)

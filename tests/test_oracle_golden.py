@@ -321,3 +321,46 @@ def test_weighted_static_sampler_follows_the_reference_formula():
     a1, l1 = oracle.alias_table(ones)
     assert np.array_equal(oracle.sample_weighted(indptr, indices, I, users, 9, 0, a1, l1),
                           oracle.sample_uniform(indptr, indices, I, users, 9, 0))
+
+
+def test_openmp_minibatch_route_equals_the_serial_oracle():
+    """bench.py's CPU baseline (a) (oracle.train_batches_omp: OpenMP over the triples of a batch) is the
+    serial route — sample_uniform / sample_adaptive + step_sgd_sparse, batch by batch, the snapshot
+    retaken every `refresh_every` batches after the draws — up to fp32 association of the row sums."""
+    rng = np.random.default_rng(5)
+    U, I, d, B, nb = 300, 200, 32, 64, 9
+    P = rng.normal(0, 0.1, (U, d)).astype(np.float32)
+    Q = rng.normal(0, 0.1, (I, d)).astype(np.float32)
+    P[0] = 0
+    Q[0] = 0
+    lens = rng.integers(0, 20, U)
+    lens[0] = 0
+    indptr = np.zeros(U + 1, np.int64)
+    indptr[1:] = np.cumsum(lens)
+    indices = np.concatenate([np.sort(rng.choice(np.arange(1, I), size=int(k), replace=False))
+                              for k in lens]).astype(np.int32)
+    users = rng.integers(1, U, nb * B).astype(np.int32)
+    pos = rng.integers(1, I, nb * B).astype(np.int32)
+    reg, lr = (0.01, 0.02, 0.03), 0.05
+    for sampler in (oracle.NEG_UNIFORM, oracle.NEG_ADAPTIVE):
+        Ps, Qs = P.copy(), Q.copy()
+        QT, sigma = oracle.adaptive_stats(Qs)
+        order = oracle.adaptive_order(QT)
+        for k in range(nb):
+            u, i = users[k * B:(k + 1) * B], pos[k * B:(k + 1) * B]
+            if sampler == oracle.NEG_UNIFORM:
+                neg = oracle.sample_uniform(indptr, indices, I, u, 7, k * B)
+            else:
+                neg, _, _ = oracle.sample_adaptive(Ps, sigma, order, indptr, indices, u, 0.05, 7, offset=k * B)
+            if sampler == oracle.NEG_ADAPTIVE and (k + 1) % 4 == 0:
+                QT, sigma = oracle.adaptive_stats(Qs)
+                order = oracle.adaptive_order(QT)
+            oracle.step_sgd_sparse(Ps, Qs, None, u, i, neg, lr, reg)
+        Po, Qo = P.copy(), Q.copy()
+        QT, sigma = oracle.adaptive_stats(Qo)
+        order = oracle.adaptive_order(QT)
+        done, sc = oracle.train_batches_omp(Po, Qo, users, pos, B, sampler, lr, reg, adaptive_p=0.05, QT=QT,
+                                            sigma=sigma, order=order, refresh_every=4, indptr=indptr,
+                                            indices=indices, seed=7, threads=3)
+        assert done == nb * B and sc[3] == nb * B
+        assert np.allclose(Po, Ps, rtol=0, atol=2e-6) and np.allclose(Qo, Qs, rtol=0, atol=2e-6)

@@ -14,7 +14,7 @@ for set in "TCC_REQ TCC_READ_REQ TCC_WRITE_REQ TCC_ATOMIC" \
            "TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TA_FLAT_ATOMIC_WAVEFRONTS" \
            "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /root/repo/gpurun_out/$out/p$i -o x -- python /root/repo/bench.py --no-cpu-baseline --steps 12 --warmup 2 "$@" > /root/repo/gpurun_out/$out.p$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /root/repo/gpurun_out/$out/p$i -o x -- python /root/repo/bench.py --no-cpu-baseline --sustained-epochs 0 --steps 12 --warmup 2 "$@" > /root/repo/gpurun_out/$out.p$i.log 2>&1
 done
 python - <<PY
 import csv,collections,glob

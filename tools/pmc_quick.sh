@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 for s in given uniform adaptive; do
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d /root/repo/gpurun_out/pmc_q/$s -o x -- python /root/repo/bench.py --no-cpu-baseline --steps 12 --warmup 2 --sampler $s > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d /root/repo/gpurun_out/pmc_q/$s -o x -- python /root/repo/bench.py --no-cpu-baseline --sustained-epochs 0 --steps 12 --warmup 2 --sampler $s > /dev/null 2>&1
 done
 python - <<PY
 import csv,collections,glob

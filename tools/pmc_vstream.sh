@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /root/repo/gpurun_out/pmc_vs/p$i -o x -- python /root/repo/bench.py --no-cpu-baseline --steps 6 --warmup 30 "$@" > /dev/null 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /root/repo/gpurun_out/pmc_vs/p$i -o x -- python /root/repo/bench.py --no-cpu-baseline --sustained-epochs 0 --steps 6 --warmup 30 "$@" > /dev/null 2>&1
 done
 python - <<PY
 import csv,collections,glob
