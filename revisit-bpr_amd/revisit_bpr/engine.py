@@ -268,6 +268,12 @@ class Engine:
         if (world <= 1 and not force) or self.d % max(world, 1) != 0:
             return self.adaptive_refresh()
         self._sync_stream()
+        if world <= 1:  # forced: one rank's share is every factor — a full refresh, then the same two
+            self.adaptive_refresh()  # all-gathers over the published snapshot (the collective path, one rank)
+            order, sigma = self._snapshot_views(back=False)
+            dist.all_gather_into_tensor(order.view(-1), order.view(-1).clone(), group=group)
+            dist.all_gather_into_tensor(sigma, sigma.clone(), group=group)
+            return
         per = self.d // world
         native.check(self._lib.bpr_adaptive_refresh_part(self._ctx, rank * per, (rank + 1) * per))
         order, sigma = self._snapshot_views(back=True)

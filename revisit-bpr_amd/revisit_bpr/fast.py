@@ -473,8 +473,15 @@ class BatchedStreamTrainer:
         if world is None:
             world = item_sync.world if item_sync is not None else 1
         self.chunk = max(batch_size, every // max(world, 1) * batch_size)
-        # staleness budget: at most ~U/4 triples against one parameter cut
-        self.max_inflight = max(64, U // 4) if max_inflight is None else max_inflight
+        # staleness budget: at most ~U/4 triples against one parameter cut — and at most
+        # I/3 (r5): every triple in flight holds two item rows, so beyond I/2 of them a row is, on average,
+        # in two virtual batches at once; gradients of neighbouring batches that reach a row before either
+        # step is closed merge into ONE optimizer step, which Adam normalises as one — on a 1,500-item table
+        # with 1,000 triples in flight that reads -0.0020 nDCG@100 / -0.0024 Recall@20 at epoch 12 against
+        # the reference over epoch orders, with 500 in flight -0.0014 / -0.0017, with one batch -0.0011 /
+        # -0.0013 (100 seeds each, profiles/r05_vstream_inflight.txt).  No BASELINE shape but ML-20M
+        # (6,702 against the chip's ~8,192 resident triples) is touched by the item bound.
+        self.max_inflight = max(64, min(U // 4, I // 3)) if max_inflight is None else max_inflight
         self.seed, self.rank = seed, rank
         self.epoch = 0
         self.drawn = 0
