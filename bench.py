@@ -473,6 +473,7 @@ def main():
     src_items = torch.from_numpy(data.items).to(dev)
     users_e, items_e = torch.empty_like(src_users), torch.empty_like(src_items)
     e.set_stream_opts(not args.ungrouped, args.run_len)
+    e.set_bias_tracking(True)  # this loop owns the item_bias between its launches (as fast.StreamTrainer's does)
     if args.hot_rows is not None:
         e.set_hot_rows(args.hot_rows, args.hot_replicas)
     main_stream = side_stream = None

@@ -368,6 +368,16 @@ int bpr_stream_run_len(bpr_ctx* ctx);
  * as updating Q directly, up to the association of fp32 sums.  hot_rows = 0 turns it off.  Takes
  * effect at the next bpr_plan_epoch. */
 int bpr_set_hot_rows(bpr_ctx* ctx, int32_t hot_rows, int32_t replicas);
+/* The item_bias during STREAM launches (models/bpr/model.py:101-110; the RQ configs switch it on).
+ * k_stream works on a table of its own with ONE item per 128-B line (in the dense vector 32 items share a
+ * line and every bias load queues behind their adds at the memory side); each launch fills it from the
+ * caller's vector and its epilogue writes it back.  bpr_set_bias_tracking(ctx, 1): the fill is skipped
+ * while the table is known to equal the vector — written back by the previous launch, no entry point of
+ * the library has written the vector since — which leaves writes the library cannot see: after any
+ * write of the caller's own to item_bias (optimizer step on the tensor, checkpoint load, zero_()) call
+ * bpr_bias_written before the next launch.  Off by default (every launch refills). */
+int bpr_set_bias_tracking(bpr_ctx* ctx, int32_t on);
+int bpr_bias_written(bpr_ctx* ctx);
 /* Heavy users (more seen items than `threshold`, default 256; -1 = none) get an I-bit seen bitmap in
  * HBM, built synchronously by the first sampling STREAM launch after the seen CSR was bound; the
  * bitmaps take at most `max_bytes` (default 1 GiB; 0 keeps the current cap) — the threshold is

@@ -179,6 +179,7 @@ int comm_item_sync(bpr_ctx* c, bool finish_only) {
     if (int rc = comm_rebase(c, m)) return rc;
   }
   c->keys_cut = false;  // the item table moves
+  c->bias_w_valid = false;  // ... and the item_bias with it
   const float scale = 1.0f;
   if (m->pending) {
     // fold the other ranks' contribution of the reconciliation in flight ...

@@ -145,6 +145,9 @@ struct bpr_ctx {
   // scalar slots
   float* bias_w = nullptr;  // [I * BIAS_LINE] the item_bias k_stream works on, one item per 128-B line (bpr_kernels.h)
   int64_t bias_w_rows = 0;
+  bool bias_track = false;    // bpr_set_bias_tracking: skip the refill while the wide table is known to be current
+  bool bias_w_valid = false;  // wide table == dense vector (written back by the last launch, untouched since)
+  const float* bias_w_of = nullptr;
   float* dev_scalars = nullptr;
   // timing of the dominant kernel
   bool timing = false;

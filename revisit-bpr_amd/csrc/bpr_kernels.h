@@ -114,6 +114,11 @@ struct EpilogueArgs {
   float* delta;
   const int32_t* hot_items;
   int32_t n_blocks, H, R, d, fold_blocks;
+  // the item_bias k_stream worked on (one item per 128-B line, StreamArgs::bias) back into the
+  // caller's dense vector: the blocks past the hot fold (NULL: nothing to write back)
+  const float* bias_w;
+  float* bias;
+  int32_t I, bias_blocks;
 };
 
 __global__ __launch_bounds__(256) void k_stream_epilogue(const EpilogueArgs a) {
@@ -137,6 +142,12 @@ __global__ __launch_bounds__(256) void k_stream_epilogue(const EpilogueArgs a) {
     return;
   }
   const int d = a.d;
+  if ((int)blockIdx.x > a.fold_blocks) {  // the bias blocks
+    for (int32_t i = (int32_t)(blockIdx.x - 1 - a.fold_blocks) * 256 + (int32_t)threadIdx.x; i < a.I;
+         i += a.bias_blocks * 256)
+      a.bias[i] = a.bias_w[(size_t)i * 32];
+    return;
+  }
   const int64_t n = (int64_t)a.H * d;
   for (int64_t k = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x; k < n;
        k += (int64_t)a.fold_blocks * 256) {
@@ -167,10 +178,17 @@ struct EpilogueCutArgs {
   // 0: read-only cut (bpr_train_stream_acut): the keys are Q + delta, nothing is folded — this pass
   // then runs on the side stream WHILE the next launch already updates the table
   int32_t fold;
+  // item_bias write-back (EpilogueArgs): the statistics row of the grid does it, 32 items per block
+  const float* bias_w;
+  float* bias;
 };
 
 __global__ __launch_bounds__(256) void k_stream_epilogue_cut(const EpilogueCutArgs a) {
   if (blockIdx.y == gridDim.y - 1) {  // the statistics row
+    if (a.bias != nullptr && threadIdx.x < 32) {
+      const int32_t i = (int32_t)blockIdx.x * 32 + (int32_t)threadIdx.x;
+      if (i < a.I) a.bias[i] = a.bias_w[(size_t)i * 32];
+    }
     if (blockIdx.x != 0) return;
     for (int k = threadIdx.x; k < 2 * a.d; k += 256) a.sig_acc[k] = 0.0;  // (as k_transpose does)
     if (a.out == nullptr) return;
@@ -368,7 +386,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t bpr_smem[];
 // chain of the logit — then queues behind those adds at the memory side (46 us of a 264-us launch,
 // profiles/shapes_r04.txt).  launch_stream fills it from the caller's vector before the launch
 // (k_bias_widen) and writes it back after (k_bias_narrow): same arithmetic, another address.
-constexpr int BIAS_LINE = 32;
+constexpr int BIAS_LINE = 32;  // (the epilogues above index the wide table with this stride)
 struct StreamArgs {
   float* P;
   float* Q;

@@ -113,6 +113,7 @@ static int vs_enter(bpr_ctx* c) {
 }
 
 int vs_flush(bpr_ctx* c, bool users, bool items) {
+  c->bias_w_valid = false;  // (the batched path writes the item_bias)
   if (!c->vs_active) return BPR_OK;
   const bool stateful = c->opt_kind != BPR_OPT_SGD;
   if (stateful)
@@ -153,6 +154,7 @@ int vs_flush(bpr_ctx* c, bool users, bool items) {
 
 // headers -> lastP / lastQ: everything applied, every row current as of c->step
 int vs_leave(bpr_ctx* c) {
+  if (c->vs_active) c->bias_w_valid = false;
   if (!c->vs_active) return BPR_OK;
   if (int rc = vs_flush(c, true, true)) return rc;
   if (c->lastP != nullptr) {

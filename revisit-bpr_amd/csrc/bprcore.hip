@@ -413,10 +413,18 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
         BPR_HIP_CHECK(hipMalloc(&c->bias_w, sizeof(float) * (size_t)c->I * BIAS_LINE));
         c->bias_w_rows = c->I;
       }
-      hipLaunchKernelGGL(k_bias_widen, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream, c->bias,
-                         c->bias_w, (int32_t)c->I);
+      // (re)fill the wide table — unless it is known to equal the dense vector still: the epilogue of
+      // the previous launch wrote it back, and nobody has touched the vector since (every entry point
+      // of the library that writes it says so; writes of the caller's own: bpr_bias_written)
+      if (!(c->bias_track && c->bias_w_valid && c->bias_w_of == c->bias))
+        hipLaunchKernelGGL(k_bias_widen, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream, c->bias,
+                           c->bias_w, (int32_t)c->I);
+      c->bias_w_valid = false;
+      c->bias_w_of = c->bias;
       a.bias = c->bias_w;
     }
+    // the write-back rides on the launch's own epilogue where there is one on this stream
+    const bool bias_in_epilogue = a.bias != nullptr && !acut && !(cut && hot && c->hot_tier);
     {
       Timer tm(c, true);
       (void)tm;
@@ -432,9 +440,10 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       };
       pick(go);
     }
-    if (a.bias != nullptr)
+    if (a.bias != nullptr && !bias_in_epilogue)
       hipLaunchKernelGGL(k_bias_narrow, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream,
                          c->bias_w, c->bias, (int32_t)c->I);
+    if (a.bias != nullptr) c->bias_w_valid = true;  // dense == wide again once the write-back has run
     if (acut) {
       // the cut of the next snapshot on the SIDE stream, behind this launch and beside the next
       // one: read-only (keys = Q + hot deltas, nothing folded), it also sums the loss partials
@@ -470,6 +479,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       ea.T = c->keysT; ea.sig_acc = c->sig_acc;
       ea.H = hot ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d; ea.I = (int32_t)c->I;
       ea.fold = 1;
+      if (bias_in_epilogue) { ea.bias_w = c->bias_w; ea.bias = c->bias; }
       dim3 eg((unsigned)((c->I + 31) / 32), (unsigned)((c->d + 31) / 32) + 1u);
       // the split refresh's side stream waits for this cut: the event rides on the kernel's own
       // completion signal (hipExtLaunchKernelGGL stop event) instead of a marker packet behind it
@@ -482,7 +492,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       }
       c->keys_cut = true;
       c->keys_event = ride;
-    } else if (out_scalars != nullptr || (hot && !c->hot_tier)) {
+    } else if (out_scalars != nullptr || (hot && !c->hot_tier) || bias_in_epilogue) {
       const bool fold = hot && !c->hot_tier;  // hot tier: the deltas stay for bpr_hot_exchange
       EpilogueArgs ea;
       memset(&ea, 0, sizeof(ea));
@@ -491,7 +501,11 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       ea.H = fold ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d;
       ea.fold_blocks =
           fold ? (int)std::min<int64_t>(((int64_t)c->hot_H * c->d + 255) / 256, 64) : 0;
-      hipLaunchKernelGGL(k_stream_epilogue, dim3(1 + ea.fold_blocks), dim3(256), 0, c->stream, ea);
+      if (bias_in_epilogue) {
+        ea.bias_w = c->bias_w; ea.bias = c->bias; ea.I = (int32_t)c->I;
+        ea.bias_blocks = (int)std::min<int64_t>((c->I + 255) / 256, 256);
+      }
+      hipLaunchKernelGGL(k_stream_epilogue, dim3(1 + ea.fold_blocks + ea.bias_blocks), dim3(256), 0, c->stream, ea);
     }
     BPR_HIP_CHECK(hipGetLastError());
     return BPR_OK;
@@ -530,6 +544,7 @@ int check_sampler(const bpr_ctx* c, const char* who, int32_t sampler, float adap
 // STRICT lazy replay: bring every row to step c->step (rows tracked by lastP / lastQ)
 int strict_flush_impl(bpr_ctx* c) {
   if (c->opt_kind == BPR_OPT_SGD || c->GP == nullptr || c->step == 0) return BPR_OK;
+  c->bias_w_valid = false;
   if (int rc = check_opt_state(c, "bpr_flush_lazy")) return rc;
   // (accumulated gradients of a batch in flight are left alone: the flush only advances w / m / v
   // and the rows' last-step marks, bpr_apply then finds nothing left to replay)
@@ -618,6 +633,7 @@ int bpr_bind_tables(bpr_ctx* c, float* P, int64_t U, float* Q, int64_t I, int32_
     if (int rc = vs_leave(c)) return rc;  // pending steps belong to the tables bound so far
   }
   c->P = P; c->Q = Q; c->bias = item_bias;
+  c->bias_w_valid = false;
   c->keys_cut = false;
   c->U = U; c->I = I; c->d = d;
   c->pad_user = pad_user; c->pad_item = pad_item;
@@ -926,6 +942,7 @@ int bpr_forward_grad(bpr_ctx* c, const int32_t* users, const int32_t* pos, const
 int bpr_apply(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_apply")) return rc;
   c->keys_cut = false;
+  c->bias_w_valid = false;  // writes the item_bias
   if (int rc = check_opt_state(c, "bpr_apply")) return rc;
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (int rc = ensure_strict_scratch(c)) return rc;
@@ -1303,6 +1320,19 @@ int bpr_sync_cut(bpr_ctx* c, float* hot_base, float* hot_tot, int32_t hot_fold_p
   return BPR_OK;
 }
 
+int bpr_set_bias_tracking(bpr_ctx* c, int32_t on) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_bias_tracking: ctx is NULL");
+  c->bias_track = on != 0;
+  c->bias_w_valid = false;
+  return BPR_OK;
+}
+
+int bpr_bias_written(bpr_ctx* c) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_bias_written: ctx is NULL");
+  c->bias_w_valid = false;
+  return BPR_OK;
+}
+
 int bpr_stream_run_len(bpr_ctx* c) {
   return c == nullptr ? 0 : c->last_run_len;
 }
@@ -1359,6 +1389,7 @@ int bpr_flush_lazy(bpr_ctx* c) {
 int bpr_flush_items(bpr_ctx* c) {
   if (int rc = check_bound(c, "bpr_flush_items")) return rc;
   c->keys_cut = false;
+  c->bias_w_valid = false;
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (c->vs_active) return vs_flush(c, false, true);
   if (c->opt_kind == BPR_OPT_SGD || c->GP == nullptr || c->step == 0) return BPR_OK;

@@ -455,6 +455,17 @@ class Engine:
         native.check(fn(self._ctx, users.data_ptr(), pos.data_ptr(), _ptr(neg), users.numel(),
                         sampler, adaptive_p, seed, offset, max_inflight, _ptr(scalars)))
 
+    def set_bias_tracking(self, on: bool) -> None:
+        """item_bias during STREAM launches (``bpr_set_bias_tracking``): on = a launch skips re-reading the
+        dense vector while the library knows its own one-item-per-line table is current.  Only for a
+        loop that owns the vector between its launches (fast.StreamTrainer switches it on for the
+        duration of one epoch call, bench.py for its run): a write through torch that the library
+        cannot see must be declared with `bias_written()`."""
+        native.check(self._lib.bpr_set_bias_tracking(self._ctx, int(bool(on))))
+
+    def bias_written(self) -> None:
+        native.check(self._lib.bpr_bias_written(self._ctx))
+
     def train_strict(self, users, pos, batch_size: int, sampler: int = NEG_UNIFORM,
                      neg: Optional[torch.Tensor] = None, adaptive_p: float = 0.01, seed: int = 0,
                      offset: int = 0, refresh_every: int = 0,

@@ -311,8 +311,12 @@ class StreamTrainer:
     def epoch_begin(self) -> None:
         if self._main is not None:
             self._main.torch.wait_stream(torch.cuda.current_stream(self.users.device))
+        # from here to epoch_end nobody but the launches writes the item_bias: they may keep their
+        # one-item-per-line copy of it instead of re-reading the vector every launch
+        self.engine.set_bias_tracking(True)
 
     def epoch_end(self) -> dict:
+        self.engine.set_bias_tracking(False)
         if self._main is not None:
             torch.cuda.current_stream(self.users.device).wait_stream(self._main.torch)
         if self.async_cut:  # the tables are read next: fold what the asynchronous cuts left, wait for their sums

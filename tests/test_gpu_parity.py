@@ -1306,6 +1306,54 @@ def test_sync_refresh_right_behind_an_async_cut_sorts_finished_keys(hot_rows):
     assert int(sc[3]) == 6 * n
 
 
+@pytest.mark.parametrize("cut", [False, True])
+def test_item_bias_write_back_rides_on_the_epilogue_and_tracking_skips_only_clean_refills(cut):
+    """r5: k_stream's one-item-per-line copy of the item_bias is written back by the launch's own
+    epilogue (k_stream_epilogue / _cut) instead of a kernel of its own, and with bias tracking on the
+    refill before a launch is skipped while the copy is current.  The sequence launch, launch, [torch
+    writes the vector + bias_written], launch must leave exactly what the same sequence leaves with a
+    refill before every launch (sequential mode: one wave walks the stream, so both are deterministic),
+    and both must follow the oracle's sequential SGD."""
+    rng = np.random.default_rng(31)
+    U, I, d, n = 300, 220, 64, 3000
+    P = rng.normal(0, 0.2, (U, d)).astype(np.float32)
+    Q = rng.normal(0, 0.2, (I, d)).astype(np.float32)
+    b = rng.normal(0, 0.1, I).astype(np.float32)
+    P[0] = 0
+    Q[0] = 0
+    users = np.sort(rng.integers(1, U, n)).astype(np.int32)
+    pos = rng.integers(1, I, n).astype(np.int32)
+    neg = rng.integers(1, I, n).astype(np.int32)
+    bump = rng.normal(0, 0.05, I).astype(np.float32)
+    reg, lr = (0.01, 0.02, 0.03), 0.05
+    out = []
+    for track in (False, True):
+        e = make_engine(P, Q, b, reg)
+        e.bind_seen_csr(dev(np.zeros(U + 1, np.int64)), dev(np.zeros(0, np.int32)))
+        e.set_optimizer(kind=0, lr=lr)
+        e.set_stream_opts(True, 0)
+        e.set_hot_rows(0, 1)
+        e.set_bias_tracking(track)
+        sc = torch.zeros(4, device="cuda")
+        if cut:
+            e.adaptive_refresh()
+        for k in range(3):
+            if k == 2:
+                e.item_bias.add_(dev(bump))  # a write the library cannot see ...
+                e.bias_written()             # ... declared
+            e.train_stream(dev(users), dev(pos), sampler=0, neg=dev(neg), scalars=sc, max_inflight=1, cut=cut)
+        torch.cuda.synchronize()
+        out.append((e.P.cpu().numpy(), e.Q.cpu().numpy(), e.item_bias.cpu().numpy(), sc.cpu().numpy()))
+    for a, c in zip(out[0], out[1]):
+        assert np.array_equal(a, c)
+    Po, Qo, bo = P.copy(), Q.copy(), b.copy()
+    for k in range(3):
+        if k == 2:
+            bo += bump
+        oracle.train_stream_seq(Po, Qo, bo, users, pos, neg, oracle.NEG_GIVEN, lr, reg)
+    assert close(out[1][0], Po, 2e-5) and close(out[1][1], Qo, 2e-5) and close(out[1][2], bo, 2e-5)
+
+
 # ---- heavy users: precomputed seen bitmaps in HBM -------------------------------------------------
 @pytest.mark.parametrize("seen,heavy_t", [("", None), ("list", None), ("", "-1"), ("", "40"), ("list", "600")])
 @pytest.mark.parametrize("d", [64, 256])
