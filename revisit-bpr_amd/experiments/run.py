@@ -19,14 +19,14 @@ from experiments.config import instantiate, parse_extra_vars, render
 @click.option("-d", "--dir", "exp_dir", type=click.Path(path_type=Path), default=None)
 @click.option("--seed", type=int, default=13, show_default=True)
 @click.option("--debug", is_flag=True)
-@click.option("--train-mode", type=click.Choice(["api", "strict", "stream"]), default="api",
+@click.option("--train-mode", type=click.Choice(["auto", "api", "strict", "stream"]), default="auto",
               show_default=True, help="api: the reference's per-batch loop; strict: the same "
               "mini-batches, whole epochs inside the library; stream: the fused SGD throughput path")
 def main(config_path: Path, extra_vars: str, exp_dir, seed: int, debug: bool, train_mode: str):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s | %(message)s")
     config = render(config_path, parse_extra_vars(extra_vars))
     exp_cfg = config.pop("experiment")
-    extra = {} if train_mode == "api" else {"train_mode": train_mode}
+    extra = {"train_mode": train_mode}
     experiment = instantiate(exp_cfg, exp_config=lambda: config, dir=exp_dir, seed=seed, debug=debug,
                              **extra)
     experiment.run()

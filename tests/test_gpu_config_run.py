@@ -14,7 +14,8 @@ CONFIG = Path(__file__).parent / "configs" / "bpr_small.yaml.j2"
                                           ("uniform-sgd-bias", "strict"), ("adaptive-adam", "strict"),
                                           ("uniform-sgd-bias", "stream"), ("adaptive-sgd", "stream"),
                                           ("adaptive-adam", "stream"), ("popularity-sgd", "api"),
-                                          ("popularity-sgd", "stream")])
+                                          ("popularity-sgd", "stream"), ("adaptive-adam", "auto"),
+                                          ("uniform-sgd-bias", "auto")])
 def test_config_run_learns(tmp_path, variant, mode):
     from click.testing import CliRunner
 
@@ -54,3 +55,5 @@ def test_config_run_learns(tmp_path, variant, mode):
     assert 0.5 < evals[-1]["auc"] <= 1.0
     assert trains[-1]["bpr_loss"] < trains[0]["bpr_loss"]
     assert (tmp_path / "exp" / "history.json").exists()
+    if mode == "auto":  # nothing observes single iterations here: the epochs ran inside the library
+        assert exp._train_mode == "strict"

@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Triples/s THROUGH experiments/trainer.py (events, eval engine and all) on a config in the reference's schema:
+the per-batch API loop (`--train-mode api`: DataLoader -> sampler -> model(batch) -> backward -> optimizer.step)
+against what an unchanged command line gets since r5 (`auto`: whole epochs inside the library when nothing observes
+single iterations).  Netflix-shaped synthetic set, d = 64, B = 256, SGD / Adam, 3 epochs each."""
+import sys, tempfile, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "revisit-bpr_amd")]
+import torch
+from click.testing import CliRunner
+from experiments import run as run_mod
+from revisit_bpr.datasets import interactions, synthetic
+
+CONFIG = ROOT / "tests" / "configs" / "bpr_small.yaml.j2"
+data = synthetic.generate_named("netflix", eval_users=20, seed=3)
+with tempfile.TemporaryDirectory() as tmp:
+    interactions.write_dataset(data, Path(tmp) / "data")
+    def run(variant, mode, epochs):
+        extra = (f"dataset={tmp}/data;num_users={data.num_users - 1};num_items={data.num_items - 1};"
+                 f"embedding_dim=64;train_batch_size=256;epochs={epochs};adaptive=1;item_bias=false")
+        if variant == "adam":
+            extra += ";optimizer=torch.optim.Adam;lr=0.001"
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = CliRunner().invoke(run_mod.main, [str(CONFIG), "--extra-vars", extra, "--train-mode", mode],
+                                 catch_exceptions=False, standalone_mode=False)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, res.return_value
+
+    for variant in ("sgd", "adam"):
+        for mode in ("api", "auto", "stream"):
+            run(variant, mode, 1)  # warm (library load, first-launch setup)
+            t1, _ = run(variant, mode, 1)
+            e_hi = 3 if mode == "api" else 9
+            t2, exp = run(variant, mode, e_hi)
+            per_epoch = (t2 - t1) / (e_hi - 1)  # one training epoch + one evaluation of 20 users
+            evals = [r for r in exp.history if r["engine"] == "eval"]
+            print(f"{variant:5s} --train-mode {mode:6s} ({exp._train_mode}): {per_epoch * 1e3:8.1f} ms per epoch (+ its eval) "
+                  f"= {data.nnz / per_epoch / 1e6:6.2f} M triples/s through Trainer.run; ndcg@100 {evals[0]['ndcg@100']:.3f} -> "
+                  f"{evals[-1]['ndcg@100']:.3f}", flush=True)
