@@ -319,8 +319,8 @@ int bpr_hot_fold(bpr_ctx* ctx);
  * r4: for 16 <= B <= 2048 the launch first marks the triples whose user occurs once in its virtual
  * batch; such a user row takes its optimizer step at once, under the row's lock, instead of parking
  * the gradient for the row's next visitor (same arithmetic, bit-identical in the max_inflight = 1
- * limit).  On by default except for Adam on a model with item_bias; the environment
- * variable BPR_VS_DIRECT=0 / 1 forces it off / on (a measurement and test aid, read per launch). */
+ * limit).  On by default except for Adam on a model with item_bias;
+ * bpr_set_tuning(ctx, "vs_direct", 0 / 1) forces it off / on (a measurement and test aid). */
 int bpr_train_stream_batched(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
                              int64_t n, int64_t B, int32_t sampler, float adaptive_p,
                              uint64_t seed, uint64_t offset, int64_t max_inflight,
@@ -368,6 +368,14 @@ int bpr_stream_run_len(bpr_ctx* ctx);
  * as updating Q directly, up to the association of fp32 sums.  hot_rows = 0 turns it off.  Takes
  * effect at the next bpr_plan_epoch. */
 int bpr_set_hot_rows(bpr_ctx* ctx, int32_t hot_rows, int32_t replicas);
+/* Test and measurement aids, per ctx (nothing in the library reads the environment per launch):
+ *   "seen"      0 = by shape (default), 1 = binary search in the CSR, 2 = LDS bitmap, 3 = staged list —
+ *               the structure the sampling kernels answer "has u seen c?" from;
+ *   "vs_direct" -1 = by optimizer (default), 0 / 1 = lonely user rows of the batched STREAM kernel step
+ *               through the gradient buffer / directly under the row's lock;
+ *   "adam_closed" 1 (default) / 0 = Adam's missed zero-gradient steps replayed in closed form / by the loop;
+ *   "refresh_sub" 0 = by shape (default), 1 | 2 | 4 = workgroups per column of the in-LDS snapshot sort. */
+int bpr_set_tuning(bpr_ctx* ctx, const char* key, int32_t value);
 /* The item_bias during STREAM launches (models/bpr/model.py:101-110; the RQ configs switch it on).
  * k_stream works on a table of its own with ONE item per 128-B line (in the dense vector 32 items share a
  * line and every bias load queues behind their adds at the memory side); each launch fills it from the

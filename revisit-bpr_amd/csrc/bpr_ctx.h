@@ -141,6 +141,12 @@ struct bpr_ctx {
   int64_t heavy_max_bytes = (int64_t)1 << 30;  // ... and the most HBM the bitmaps may take
   int64_t heavy_n = 0;
   const int64_t* heavy_for = nullptr;  // the indptr the table was built from (NULL = not built)
+  // test / measurement aids (bpr_set_tuning): which "seen?" structure the sampling kernels use
+  // (0 = by shape, 1 = CSR search, 2 = LDS bitmap, 3 = staged list) and whether the batched STREAM
+  // kernel steps lonely user rows directly (-1 = by optimizer, 0 / 1 = forced)
+  int tune_seen = 0, tune_vs_direct = -1;
+  int tune_adam_closed = 1;  // 0: Adam's missed steps are replayed by the step loop, never in closed form (tests compare both routes)
+  int tune_refresh_sub = 0;  // 1 | 2 | 4: workgroups per column of the in-LDS snapshot sort (0 = by shape; tests force the merge paths)
   void* comm = nullptr;  // bpr_comm.hip: the RCCL communicator and the reconciliation buffers (NULL: one GPU)
   // scalar slots
   float* bias_w = nullptr;  // [I * BIAS_LINE] the item_bias k_stream works on, one item per 128-B line (bpr_kernels.h)

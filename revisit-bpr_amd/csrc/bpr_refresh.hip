@@ -8,7 +8,7 @@
 // 64-bit keys (factor << 32 | descending-orderable float bits), restricted to the 32 + log2(d)
 // significant bits — measured 2.1x faster than DeviceSegmentedRadixSort / DeviceSegmentedSort for
 // d = 128 segments of 20 k keys (tools/ubench/sort_bench.hip: 0.23 ms vs 0.49 ms).
-#include <hipcub/hipcub.hpp>
+#include <string.h>  // (rocprim's texture iterator calls the host memset)
 #include <rocprim/rocprim.hpp>
 
 // bits per pass of the in-LDS block radix sort (0 = rocPRIM's default, 8)
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_sigma(const float* __restrict__ T, int6
 
 // ---------------------------------------------------------------------------------------------
 // Fast path (I <= 36,864 items): ONE 1024-thread workgroup per factor sorts the whole column in
-// registers + LDS (hipcub::BlockRadixSort — LSD radix, stable, so ties keep ascending item id) and
+// registers + LDS (rocprim::block_radix_sort — LSD radix, stable, so ties keep ascending item id) and
 // computes sigma_f on the way: d independent workgroups, no inter-block traffic, no memsets.
 // The column sits in 1024 x ITEMS registers; the ~100 KiB of LDS is the radix exchange buffer.
 // ---------------------------------------------------------------------------------------------
@@ -562,11 +562,11 @@ int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
     BPR_HIP_CHECK(hipMalloc(&c->plan_keys, sizeof(uint64_t) * n));
     BPR_HIP_CHECK(hipMalloc(&c->plan_keys_sorted, sizeof(uint64_t) * n));
     size_t bytes = 0;
-    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->plan_keys,
+    BPR_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, c->plan_keys,
                                                      c->plan_keys_sorted, pos_in, pos_out, (int)n,
                                                      0, 64, c->stream));
     size_t bytes32 = 0;
-    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(
+    BPR_HIP_CHECK(rocprim::radix_sort_pairs(
         nullptr, bytes32, reinterpret_cast<uint32_t*>(c->plan_keys),
         reinterpret_cast<uint32_t*>(c->plan_keys_sorted), pos_in, pos_out, (int)n, 0, 32, c->stream));
     bytes = std::max(bytes, bytes32);
@@ -581,14 +581,14 @@ int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
     uint32_t* k32s = reinterpret_cast<uint32_t*>(c->plan_keys_sorted);
     hipLaunchKernelGGL(k_plan_keys<uint32_t>, dim3(grid), dim3(256), 0, c->stream, users_in, n,
                        chunk, half_bits, ubits, seed, k32);
-    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->plan_tmp, bytes, k32, k32s, pos_in, pos_out,
+    BPR_HIP_CHECK(rocprim::radix_sort_pairs(c->plan_tmp, bytes, k32, k32s, pos_in, pos_out,
                                                      (int)n, 0, ubits + cbits, c->stream));
     hipLaunchKernelGGL(k_plan_users<uint32_t>, dim3(grid), dim3(256), 0, c->stream, k32s, n, ubits,
                        users_out);
   } else {
     hipLaunchKernelGGL(k_plan_keys<uint64_t>, dim3(grid), dim3(256), 0, c->stream, users_in, n,
                        chunk, half_bits, ubits, seed, c->plan_keys);
-    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->plan_tmp, bytes, c->plan_keys,
+    BPR_HIP_CHECK(rocprim::radix_sort_pairs(c->plan_tmp, bytes, c->plan_keys,
                                                      c->plan_keys_sorted, pos_in, pos_out, (int)n, 0,
                                                      ubits + cbits, c->stream));
     hipLaunchKernelGGL(k_plan_users<uint64_t>, dim3(grid), dim3(256), 0, c->stream,
@@ -627,7 +627,7 @@ int plan_chunk_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
     BPR_HIP_CHECK(hipMalloc(&c->pc_cnt, sizeof(uint32_t) * 3 * PC_MAX_BUCKETS));
     BPR_HIP_CHECK(hipMemsetAsync(c->pc_cnt, 0, sizeof(uint32_t) * 3 * PC_MAX_BUCKETS, st));
     size_t bytes = 0;
-    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->pc_keys,
+    BPR_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, c->pc_keys,
                                                      reinterpret_cast<uint32_t*>(users_out), c->pc_vals,
                                                      pos_out, (int)m, 0, 32, st));
     BPR_HIP_CHECK(hipMalloc(&c->pc_tmp, bytes > 0 ? bytes : 16));
@@ -654,7 +654,7 @@ int plan_chunk_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
   hipLaunchKernelGGL(k_plan_chunk, dim3(grid), dim3(256), 0, st, users_in, pos_in, n, j0, m, half_bits,
                      seed, c->pc_keys, c->pc_vals);
   size_t bytes = c->pc_tmp_bytes;
-  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->pc_tmp, bytes, c->pc_keys,
+  BPR_HIP_CHECK(rocprim::radix_sort_pairs(c->pc_tmp, bytes, c->pc_keys,
                                                    reinterpret_cast<uint32_t*>(users_out), c->pc_vals,
                                                    pos_out, (int)m, 0, ubits, st));
   BPR_HIP_CHECK(hipGetLastError());
@@ -889,8 +889,7 @@ int heavy_build_impl(bpr_ctx* c) {
   if (c->heavy_for == c->indptr) return BPR_OK;
   heavy_free(c);
   c->heavy_for = c->indptr;
-  const char* te = getenv("BPR_HEAVY_T");  // measurements: -1 = no heavy table
-  int T = te ? atoi(te) : c->heavy_T_opt;
+  int T = c->heavy_T_opt;  // bpr_set_heavy_users (-1 = no heavy table)
   if (T < 0 || c->indptr == nullptr) return BPR_OK;
   const uint32_t words = (uint32_t)(((c->I + 31) / 32 + 3) / 4 * 4);
   uint32_t* counter = nullptr;
@@ -1026,7 +1025,7 @@ int refresh_alloc(bpr_ctx* c) {
   hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, c->stream, c->ids_in, c->seg_offsets, I, d);
   size_t bytes = 0;
   uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
-  BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k64, k64 + n, c->ids_in,
+  BPR_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, k64, k64 + n, c->ids_in,
                                                    c->order, (int)n, 0, 64, c->stream));
   BPR_HIP_CHECK(hipMalloc(&c->sort_tmp, bytes > 0 ? bytes : 16));
   c->sort_tmp_bytes = bytes;
@@ -1100,9 +1099,8 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
     st = c->side;
   }
   // ---- sort
-  static const bool no_fast = getenv("BPR_NO_FAST_REFRESH") != nullptr;
-  const char* fs = getenv("BPR_REFRESH_SUB");  // tests force the split/merge paths on small tables
-  const int force_sub = fs ? atoi(fs) : 0;
+  static const bool no_fast = getenv("BPR_NO_FAST_REFRESH") != nullptr;  // (process-wide test aids, read once)
+  const int force_sub = c->tune_refresh_sub;  // bpr_set_tuning("refresh_sub", ...): tests force the split / merge paths on small tables
   // One 1024-thread workgroup sorts a (sub-)column of <= 36 keys per thread in LDS.  Columns are
   // split over 2 or 4 workgroups — sorted runs merged pairwise by k_merge_runs — when they do not
   // fit, or when d workgroups would leave CUs idle and the pieces stay >= 5,000 keys (measured on
@@ -1150,7 +1148,7 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
     int key_bits = 32;
     while ((1 << (key_bits - 32)) < d) ++key_bits;
     size_t bytes = c->sort_tmp_bytes;
-    BPR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp, bytes, k64, k64 + n, c->ids_in,
+    BPR_HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp, bytes, k64, k64 + n, c->ids_in,
                                                      order - foff, (int)n, 0, key_bits, st));
     BPR_HIP_CHECK(hipGetLastError());
   }

@@ -59,7 +59,7 @@ static VOpt vopt(const bpr_ctx* c) {
     if (b1 > 0.0) {
       const double ratio = b1 / sqrt(b2);
       o.kmax = ratio < 1.0 ? (int)ceil(log(1e-8) / log(ratio)) : 1 << 20;
-      const bool no_closed = getenv("BPR_NO_ADAM_CLOSED") != nullptr;  // tests compare both routes
+      const bool no_closed = c->tune_adam_closed == 0;  // bpr_set_tuning("adam_closed", 0)
       const double zmax = b1 / pow(b2, 0.5 * VADAM_SERIES);
       o.closed_min = o.kmax >= 64 ? 16 : 3;
       if (!no_closed && zmax < 0.999 && o.kmax >= 4 && o.kmax < (1 << 20)) {
@@ -179,9 +179,8 @@ static int launch_vstream(bpr_ctx* c, VStreamArgs a, int sampler, int64_t cap_gr
     }
     // "seen?" per triple (the stream is not grouped by user): the user's sorted seen list staged
     // in LDS (LIST_CAP entries, binary search in LDS; longer lists search the CSR in HBM).
-    // BPR_SEEN=csr stages nothing (every lookup searches the CSR: tests).
-    const char* force_env = getenv("BPR_SEEN");
-    const std::string force = force_env ? force_env : "";
+    // bpr_set_tuning("seen", 1) stages nothing (every lookup searches the CSR: tests).
+    const std::string force = c->tune_seen == 1 ? "csr" : "";  // bpr_set_tuning("seen", 1)
 #ifndef VS_LIST_CAP
 #define VS_LIST_CAP 512
 #endif
@@ -280,11 +279,9 @@ int bpr_train_stream_batched(bpr_ctx* c, const int32_t* users, const int32_t* po
   // once (bpr_vstream.h, vs_contribute): +20 / +5 / +6 % for SGD / momentum / RMSprop on the Yelp
   // shape, +2 % for Adam without item_bias.  Off for Adam WITH item_bias, whose kernel is at the
   // edge of its registers and loses 3 % to the extra branches (profiles/r04_vstream_direct.md).
-  // BPR_VS_DIRECT=0 / 1 forces it (tests run both).
-  const char* direct_env = getenv("BPR_VS_DIRECT");
-  const bool direct = direct_env != nullptr && (direct_env[0] == '0' || direct_env[0] == '1')
-                          ? direct_env[0] == '1'
-                          : !(c->opt_kind == BPR_OPT_ADAM && a.Q.b != nullptr);
+  // bpr_set_tuning("vs_direct", 0 / 1) forces it (tests run both).
+  const bool direct = c->tune_vs_direct >= 0 ? c->tune_vs_direct == 1
+                                             : !(c->opt_kind == BPR_OPT_ADAM && a.Q.b != nullptr);
   if (B >= 16 && B <= VALONE_MAX_B && direct) {  // (tiny batches: one block per batch would not pay)
     if (c->v_alone_cap < n) {
       hipFree(c->v_alone);

@@ -174,7 +174,7 @@ OptDev opt_dev(const bpr_ctx* c, int64_t t) {
     o.kmax = ratio < 1.0 ? (int)ceil(log(1e-8) / log(ratio)) : 1 << 20;
     // closed-form replay (bpr_kernels.h: opt_replay_row): needs 1 - b^t to round to 1.0f for every
     // replayed t (b^t < 2^-25) and all three series ratios b1 / b2^((j+1)/2) below 1
-    const bool no_closed = getenv("BPR_NO_ADAM_CLOSED") != nullptr;  // tests compare both routes
+    const bool no_closed = c->tune_adam_closed == 0;  // bpr_set_tuning("adam_closed", 0): tests compare both routes
     const double zmax = (double)o.b1 / pow((double)o.b2, 0.5 * ADAM_SERIES);
     if (!no_closed && zmax < 0.999 && o.b1 < 1.f && o.b2 > 0.f && o.b2 < 1.f) {
       const double lim = log(ldexp(1.0, -25));
@@ -301,12 +301,11 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     // "seen?" answers (bpr_device.h): the LDS bitmap (I bits per group) while a full 256-thread
     // block's bitmaps fit 64 KiB (>= 2 blocks per CU at full width: I <= 65,536 for d <= 128,
     // 131,072 above); larger item tables stage the user's sorted seen list in LDS instead
-    // (LIST_CAP entries per group, heavier users search the CSR in HBM).  BPR_SEEN=csr|bitmap|list
+    // (LIST_CAP entries per group, heavier users search the CSR in HBM).  bpr_set_tuning("seen", ...)
     // forces a structure (tests, measurements); a forced bitmap shrinks the block to fit.
     const int words = (int)(((c->I + 31) / 32 + 3) / 4 * 4);  // multiple of 4: 16-byte LDS wipes
-    const char* force_env = getenv("BPR_SEEN");
-    static const bool no_bm = getenv("BPR_NO_BITMAP") != nullptr;
-    const std::string force = force_env ? force_env : (no_bm ? "csr" : "");
+    static const char* const seen_names[] = {"", "csr", "bitmap", "list"};
+    const std::string force = seen_names[c->tune_seen];  // bpr_set_tuning (tests, measurements)
     constexpr int LIST_CAP = 512;
     int seen = SEEN_CSR;
     int lds_words = 0;
@@ -710,7 +709,7 @@ static int launch_sample(bpr_ctx* c, int what, SampleArgs a) {
     // bitmaps fit 64 KiB; the uniform sampler tests a handful and searches the CSR directly
     const int words = (int)(((c->I + 31) / 32 + 3) / 4 * 4);
     const size_t lds = (size_t)(256 / G) * words * sizeof(uint32_t);
-    static const bool no_bm = getenv("BPR_NO_BITMAP") != nullptr;
+    const bool no_bm = c->tune_seen == 1;
     // (one block per CU is plenty for a single batch, so the bitmaps may take most of the 160 KB)
     constexpr size_t SAMPLE_LDS_MAX = 144 * 1024;
     const bool bm = what != SAMPLE_UNIFORM && lds <= SAMPLE_LDS_MAX && !no_bm;
@@ -1317,6 +1316,18 @@ int bpr_sync_cut(bpr_ctx* c, float* hot_base, float* hot_tot, int32_t hot_fold_p
   c->defer_pending = false;
   c->keys_cut = true;   // the next bpr_adaptive_refresh_begin only queues the sort
   c->keys_event = true;
+  return BPR_OK;
+}
+
+int bpr_set_tuning(bpr_ctx* c, const char* key, int32_t value) {
+  if (c == nullptr || key == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_tuning: NULL argument");
+  const std::string k = key;
+  if (k == "seen" && value >= 0 && value <= 3) c->tune_seen = value;
+  else if (k == "vs_direct" && value >= -1 && value <= 1) c->tune_vs_direct = value;
+  else if (k == "adam_closed" && (value == 0 || value == 1)) c->tune_adam_closed = value;
+  else if (k == "refresh_sub" && (value == 0 || value == 1 || value == 2 || value == 4)) c->tune_refresh_sub = value;
+  else return fail(BPR_ERR_INVALID, "bpr_set_tuning: unknown key or value out of range");
+  c->stream_occ.clear();
   return BPR_OK;
 }
 

@@ -130,6 +130,24 @@ class Engine:
         self._keep: dict[str, object] = {}
         self._scalars = torch.zeros(native.SCALARS, dtype=torch.float32, device=self.device)
         self.opt_kind = OPT_SGD
+        # test / measurement aids: the environment is read HERE, once per engine, never by the library
+        import os
+
+        seen = os.environ.get("BPR_SEEN") or ("csr" if os.environ.get("BPR_NO_BITMAP") else "")
+        if seen:
+            self.set_tuning("seen", {"csr": 1, "bitmap": 2, "list": 3}[seen])
+        if os.environ.get("BPR_VS_DIRECT") in ("0", "1"):
+            self.set_tuning("vs_direct", int(os.environ["BPR_VS_DIRECT"]))
+        if os.environ.get("BPR_NO_ADAM_CLOSED"):
+            self.set_tuning("adam_closed", 0)
+        if os.environ.get("BPR_REFRESH_SUB") in ("1", "2", "4"):
+            self.set_tuning("refresh_sub", int(os.environ["BPR_REFRESH_SUB"]))
+        if os.environ.get("BPR_HEAVY_T"):
+            native.check(self._lib.bpr_set_heavy_users(self._ctx, int(os.environ["BPR_HEAVY_T"]), 0))
+
+    def set_tuning(self, key: str, value: int) -> None:
+        """``bpr_set_tuning``: "seen" 0 auto | 1 csr | 2 bitmap | 3 list; "vs_direct" -1 auto | 0 | 1."""
+        native.check(self._lib.bpr_set_tuning(self._ctx, key.encode(), int(value)))
 
     # ---- plumbing ---------------------------------------------------------------------------
     def _stream(self) -> int:

@@ -145,6 +145,71 @@ def _install_hook() -> None:
         _HOOK_INSTALLED = True
 
 
+class _SeenItemScorer(BaseLogitModel):
+    """Shared frame of the two item-to-item scorers (reference model.py:156-255; no reference config
+    instantiates them — they are kept for the import surface, as plain PyTorch modules: the HIP engine
+    is the MF path).  A candidate's logit is the sum, over the user's seen items, of an item-item
+    similarity; a seen item that is itself among the row's candidates contributes nothing."""
+
+    def __init__(self, num_items: int, width: int, padding_idx: int, bias: bool) -> None:
+        super().__init__()
+        self._padding_idx = padding_idx
+        self._weights = torch.nn.Parameter(torch.empty(num_items, width))
+        if bias:
+            self._bias = torch.nn.Parameter(torch.empty(num_items))
+        else:
+            self.register_parameter("_bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        with torch.no_grad():
+            self._weights.uniform_()
+            self._weights[self._padding_idx].zero_()
+            if self._bias is not None:
+                self._bias.zero_()
+
+    @staticmethod
+    def _kept(item: torch.Tensor, seen: torch.Tensor) -> torch.Tensor:
+        """[batch, seen] 1.0 where the seen item is NOT one of the row's candidates"""
+        hit = (seen.unsqueeze(1) == item.unsqueeze(2)).any(dim=1)
+        return (~hit).to(torch.float32)
+
+    def get_features(self) -> dict[str, torch.Tensor]:
+        return {"item": self._weights, "bias": self._bias}
+
+
+class ItemKNN(_SeenItemScorer):
+    """similarity(i, s) = <w_i, w_s> with w in R^hidden_dim (reference model.py:156-199)."""
+
+    def __init__(self, num_items: int, hidden_dim: int, padding_idx: int = 0, bias: bool = False) -> None:
+        super().__init__(num_items, hidden_dim, padding_idx, bias)
+
+    def forward(self, _user, item: torch.Tensor, other: dict) -> torch.Tensor:
+        seen = other["seen_items"]
+        profile = (self._weights[seen] * self._kept(item, seen).unsqueeze(-1)).sum(dim=1)  # [batch, hidden]
+        logits = torch.bmm(self._weights[item], profile.unsqueeze(-1)).squeeze(-1)
+        return logits if self._bias is None else logits + self._bias[item]
+
+
+class FreeItemKNN(_SeenItemScorer):
+    """similarity(i, s) = W[i, s], a free num_items x num_items matrix (reference model.py:201-255)."""
+
+    def __init__(self, num_items: int, padding_idx: int = 0, bias: bool = False) -> None:
+        super().__init__(num_items, num_items, padding_idx, bias)
+
+    def reset_parameters(self) -> None:
+        super().reset_parameters()
+
+    def forward(self, _user, item: torch.Tensor, other: Optional[dict]) -> torch.Tensor:
+        if not other or "seen_items" not in other:
+            raise ValueError("seen_items should be present")
+        seen = other["seen_items"]
+        rows = self._weights[item]                                         # [batch, items, num_items]
+        sims = rows.gather(-1, seen.unsqueeze(1).expand(-1, item.size(-1), -1))
+        logits = (sims * self._kept(item, seen).unsqueeze(1)).sum(dim=-1)
+        return logits if self._bias is None else logits + self._bias[item]
+
+
 class Model(torch.nn.Module):
     """The BPR model (reference: model.py:13-93).
 

@@ -270,10 +270,36 @@ def gen_metrics() -> None:
     print("wrote metrics")
 
 
+def gen_knn() -> None:
+    """The reference's two item-to-item scorers (models/bpr/model.py:156-255) on a small batch with
+    candidates that coincide with seen items -> tests/golden/knn.npz (weights, inputs, logits)."""
+    from revisit_bpr.models.bpr import FreeItemKNN, ItemKNN
+
+    rng = np.random.default_rng(3)
+    n_items, hidden, B, C, S = 40, 8, 5, 6, 7
+    item = rng.integers(1, n_items, (B, C))
+    seen = rng.integers(0, n_items, (B, S))
+    seen[:, :2] = item[:, :2]  # seen items among the candidates: masked
+    out = {"item": item, "seen": seen}
+    for name, mod in (("knn", ItemKNN(n_items, hidden, bias=True)), ("free", FreeItemKNN(n_items, bias=True))):
+        with torch.no_grad():
+            mod._weights.copy_(torch.from_numpy(rng.normal(0, 1, tuple(mod._weights.shape)).astype(np.float32)))
+            mod._bias.copy_(torch.from_numpy(rng.normal(0, 1, n_items).astype(np.float32)))
+            logits = mod(None, torch.from_numpy(item), {"seen_items": torch.from_numpy(seen)})
+        out[f"{name}_w"] = mod._weights.detach().numpy()
+        out[f"{name}_b"] = mod._bias.detach().numpy()
+        out[f"{name}_logits"] = logits.numpy()
+    np.savez_compressed(OUT / "knn.npz", **out)
+    print("wrote knn")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     if sys.argv[1:] == ["metrics"]:  # only metrics.npz
         gen_metrics()
+        sys.exit(0)
+    if sys.argv[1:] == ["knn"]:  # only knn.npz
+        gen_knn()
         sys.exit(0)
     for seed in (13, 42069):
         gen_math(seed, "uin", False)
@@ -283,3 +309,4 @@ if __name__ == "__main__":
     gen_math(42069, "none", False)
     gen_sampler()
     gen_metrics()
+    gen_knn()

@@ -121,3 +121,24 @@ def test_generate_latent_cache_round_trip(tmp_path):
     assert (a.num_users, a.num_items) == (c.num_users, c.num_items) and isinstance(c.num_users, int)
     synthetic.generate_latent(3000, 500, 60000, cache_dir=tmp_path, **dict(args, seed=4))
     assert len(list(tmp_path.iterdir())) == 2
+
+
+def test_item_knn_scorers_match_the_reference(golden_dir):
+    """revisit_bpr.models.bpr exports the reference's names (models/bpr/__init__.py:1-8); the two
+    item-to-item scorers are plain PyTorch modules held to logits of the reference's own
+    (tests/golden/knn.npz from make_golden.py knn), candidates that are seen items included."""
+    import numpy as np
+    import torch
+
+    from revisit_bpr.models.bpr import BaseLogitModel, FreeItemKNN, ItemKNN, Loss, MF, Model  # noqa: F401
+
+    g = np.load(golden_dir / "knn.npz")
+    item, seen = torch.from_numpy(g["item"]), torch.from_numpy(g["seen"])
+    for name, mod in (("knn", ItemKNN(40, 8, bias=True)), ("free", FreeItemKNN(40, bias=True))):
+        assert float(mod._weights[0].abs().sum()) == 0.0  # the pad row
+        with torch.no_grad():
+            mod._weights.copy_(torch.from_numpy(g[f"{name}_w"]))
+            mod._bias.copy_(torch.from_numpy(g[f"{name}_b"]))
+            out = mod(None, item, {"seen_items": seen})
+        assert np.allclose(out.numpy(), g[f"{name}_logits"], rtol=1e-5, atol=1e-5)
+        assert set(mod.get_features()) == {"item", "bias"}
