@@ -378,15 +378,25 @@ __device__ __forceinline__ uint64_t vs_view(float (&w)[E], float& wb, const VTab
   }
   int64_t a = h.last();
   const int64_t gs = h.gstep();
-  if (pend) {  // apply it in this view
-    vs_apply<KIND, E>(w, m, v, g, a, gs, o);
-    if (T.b != nullptr) vs_apply1<KIND>(wb, bm, bv, gb, a, gs, o);
-    a = gs;
-  }
-  if constexpr (STATEFUL) {
-    const int64_t k = (t - 1) - a;
-    vo_replay<KIND, E, false>(w, m, v, a, k, o);
-    if (T.b != nullptr) vo_replay1<KIND, false>(wb, bm, bv, a, k, o);
+  // Two stretches of zero-gradient steps, the pending step between them: [a+1, gs-1], step gs with the
+  // parked gradient, [gs+1, t-1].  ONE copy of the replay serves both (r5: the kernel waits for
+  // instruction fetch — profiles/r04_vstream_direct.md — and the replay is its largest block; the
+  // second stretch advances the view's private m, v as well, which nobody reads afterwards).
+#pragma unroll 1
+  for (int ph = pend ? 0 : 1; ph < 2; ++ph) {
+    const int64_t k = ph == 0 ? gs - 1 - a : (t - 1) - a;
+    if constexpr (STATEFUL) {
+      vo_replay<KIND, E, true>(w, m, v, a, k, o);
+      if (T.b != nullptr) vo_replay1<KIND, true>(wb, bm, bv, a, k, o);
+    }
+    if (ph == 0) {  // apply the pending step in this view
+      float stp, ibc2;
+      vo_step_consts<KIND>(o, gs, stp, ibc2);
+#pragma unroll
+      for (int e = 0; e < E; ++e) vo_update<KIND>(w[e], g[e], m[e], v[e], o, gs == 1, stp, ibc2);
+      if (T.b != nullptr) vo_update<KIND>(wb, gb, bm, bv, o, gs == 1, stp, ibc2);
+      a = gs;
+    }
   }
   return h.raw;  // the header this view was taken under (vs_contribute's first guess)
 }
