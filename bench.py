@@ -469,6 +469,10 @@ def main():
                         launches_per_period(args.lr, cad_world, period))
     chunk = max(1, period // (split * ranks_per_period))
     n_chunks = max(1, data.nnz // chunk)
+    if world > 1:  # every rank's own shard: the same number of steps per epoch everywhere, or the collectives of
+        tn = torch.tensor([n_chunks], device=dev)  # a sustained / steady epoch stop matching up
+        dist.all_reduce(tn, op=dist.ReduceOp.MIN)
+        n_chunks = int(tn.item())
     src_users = torch.from_numpy(data.users).to(dev)
     src_items = torch.from_numpy(data.items).to(dev)
     users_e, items_e = torch.empty_like(src_users), torch.empty_like(src_items)
