@@ -214,6 +214,10 @@ def parse_args():
                          "negatives concentrate on popular rows and its walks get deeper once the model has moved "
                          "(DESIGN.md §4.1 r5; tools/trained_state_probe.py): a long job sees this number, the first "
                          "epochs from random init see `value`")
+    ap.add_argument("--partial-snapshot", type=int, default=0,
+                    help="1: the split refresh sorts only the two ends of every snapshot column and buckets the middle "
+                         "(bpr_set_tuning partial_snapshot; DESIGN.md §4.3 r5)")
+    ap.add_argument("--partial-target", type=int, default=640)
     ap.add_argument("--force-dist", action="store_true",
                     help="WORLD_SIZE = 1 under torch.distributed.run: run the N > 1 code path anyway — RCCL process "
                          "group, two-tier ItemSync, fused sync-cut, sharded refresh — with one rank (de-risks the "
@@ -478,6 +482,9 @@ def main():
     users_e, items_e = torch.empty_like(src_users), torch.empty_like(src_items)
     e.set_stream_opts(not args.ungrouped, args.run_len)
     e.set_bias_tracking(True)  # this loop owns the item_bias between its launches (as fast.StreamTrainer's does)
+    if args.partial_snapshot:
+        e.set_tuning("partial_snapshot", 1)
+        e.set_tuning("partial_target", args.partial_target)
     if args.hot_rows is not None:
         e.set_hot_rows(args.hot_rows, args.hot_replicas)
     main_stream = side_stream = None

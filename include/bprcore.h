@@ -158,6 +158,20 @@ int bpr_adaptive_refresh_begin(bpr_ctx* ctx);
 int bpr_adaptive_refresh_commit(bpr_ctx* ctx);
 /* *pending_host (HOST pointer) = 1 while a split refresh awaits its commit. */
 int bpr_adaptive_refresh_pending(bpr_ctx* ctx, int32_t* pending_host);
+/* PARTIAL snapshots (r5, opt-in: bpr_set_tuning(ctx, "partial_snapshot", 1); "partial_target" = keys aimed at
+ * per exact end, 1..1024, default 640).  All the sampler ever reads of a column is rank Geometric(p) +
+ * seen-skips from either end (revisit_bpr/modules/neg_samplers.py:90-121), so the split refresh
+ * (bpr_adaptive_refresh_begin) sorts only the two ends of every column exactly and BUCKETS the middle
+ * (equi-depth bins cut along a coarse histogram of the column, bins in order): 39 us per 20 k-key column
+ * instead of 98.  STREAM launches (bpr_train_stream*) read such a snapshot directly — a walk that leaves an
+ * exact end finishes inside one bin by taking its <= 64 keys out in order, the same negative as from the
+ * fully sorted column, triple for triple — every other reader (bpr_sample_adaptive, bpr_adaptive_pick, the
+ * batched STREAM kernel, bpr_adaptive_get_snapshot / _snapshot_ptrs) first has it sorted whole, in place.
+ * Columns of 2,048 .. 24,576 items; others — and a column with more than 64 equal-ranked keys in a bin, or an
+ * end over 1,024 keys — are sorted whole as before.  Worth +1.6 % on the metric's configuration with the
+ * sorter on 32 CUs (the finish costs the launch a wave of occupancy); off by default.
+ * *partial_host = 1 while the snapshot the samplers read is a partial one. */
+int bpr_adaptive_snapshot_partial(bpr_ctx* ctx, int32_t* partial_host);
 /* The refresh SHARDED over the ranks of a multi-GPU job: every rank holds a replica of the item
  * table, so instead of every rank sorting all d columns (an Amdahl term: the sort does not shrink
  * with the number of ranks) rank r sorts columns [f_lo, f_hi) only — _part cuts the keys and
@@ -374,7 +388,8 @@ int bpr_set_hot_rows(bpr_ctx* ctx, int32_t hot_rows, int32_t replicas);
  *   "vs_direct" -1 = by optimizer (default), 0 / 1 = lonely user rows of the batched STREAM kernel step
  *               through the gradient buffer / directly under the row's lock;
  *   "adam_closed" 1 (default) / 0 = Adam's missed zero-gradient steps replayed in closed form / by the loop;
- *   "refresh_sub" 0 = by shape (default), 1 | 2 | 4 = workgroups per column of the in-LDS snapshot sort. */
+ *   "refresh_sub" 0 = by shape (default), 1 | 2 | 4 = workgroups per column of the in-LDS snapshot sort;
+ *   "partial_snapshot" 0 / 1, "partial_target" 1..1024: bpr_adaptive_snapshot_partial above. */
 int bpr_set_tuning(bpr_ctx* ctx, const char* key, int32_t value);
 /* The item_bias during STREAM launches (models/bpr/model.py:101-110; the RQ configs switch it on).
  * k_stream works on a table of its own with ONE item per 128-B line (in the dense vector 32 items share a

@@ -75,6 +75,17 @@ struct bpr_ctx {
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   bool have_snapshot = false;
+  // PARTIAL snapshots (bpr_set_tuning "partial_snapshot"; k_sort_partial): per snapshot buffer {kt, kb} of
+  // every column, whether that buffer holds a partial order, and the key buffer it was sorted from (the
+  // walk's in-bin finish reads it: it outlives the snapshot, see refresh_impl); *_front = the pair the
+  // samplers read (meta_front NULL = sorted whole)
+  int tune_partial = 0;       // 1: the split refresh sorts partially when the shape allows
+  int partial_target = 640;   // keys aimed at per exact end (at most 1,024 fit: k_sort_partial's PART_CAP)
+  int32_t* snap_meta[2] = {nullptr, nullptr};
+  bool snap_partial[2] = {false, false};
+  const float* snap_keys[2] = {nullptr, nullptr};
+  const int32_t* meta_front = nullptr;
+  const float* keys_front = nullptr;
   // split refresh (bpr_adaptive_refresh_begin / _commit): the keys are cut on `stream`, the sort
   // runs on `side` while the caller keeps launching on `stream`, commit orders the swap
   hipStream_t side = nullptr;
@@ -171,6 +182,7 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi);  // bpr_refresh.hi
 int refresh_publish_impl(bpr_ctx* c);       // bpr_refresh.hip
 int refresh_alloc(bpr_ctx* c);             // bpr_refresh.hip: the snapshot buffers (idempotent)
 int refresh_commit_impl(bpr_ctx* c);        // bpr_refresh.hip
+int snapshot_complete_impl(bpr_ctx* c);     // bpr_refresh.hip: a partial front snapshot is sorted whole, in place
 void refresh_free(bpr_ctx* c);      // bpr_refresh.hip
 void side_free(bpr_ctx* c);         // bpr_refresh.hip
 int heavy_build_impl(bpr_ctx* c);   // bpr_refresh.hip

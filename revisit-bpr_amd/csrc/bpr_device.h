@@ -283,6 +283,11 @@ struct AdaptiveDraw {
   int32_t factor;
   int32_t rank;  // 0-based from the top (neg_samplers.py:96-100)
   int32_t item;
+  // partial snapshots (PART): the candidate sits in the bucketed middle of its column at walk entry `kres`
+  // and the caller still has to finish inside its bin (adaptive_finish_in_bin) — the finish is the caller's
+  // so that it can get its own live registers out of the way first
+  int32_t kres;
+  bool mid, from_top;
 };
 
 // item number `skip` (0-based) among the items of order_f that are not in seen(u) ∪ {0}, counting
@@ -304,13 +309,133 @@ static_assert(WALK_UNROLL == 4, "the walk fetches one dwordx4 per lane and trip"
 // overhang; overhanging entries are masked to 0 (the pad item: never a candidate).
 constexpr int ORDER_PAD = WALK_UNROLL;  // == BPR_ORDER_PAD (bpr_ctx.h), checked in bprcore.hip
 
+// PARTIAL snapshots (bpr_refresh.hip k_sort_partial): only the two ends of a column are in exact order,
+// [0, kt) and [I - kb, I); the middle is bucketed — bins in order, any order inside a bin, the first
+// entry of a bin flagged in its top bit (item ids are < 2^30).  `keys_f` = the column of keys the
+// snapshot was sorted from (NULL: an ordinary, fully sorted snapshot — kt, kb unused).
+constexpr uint32_t ORDER_FLAG = 0x80000000u;
+struct PartialColumn {
+  const float* __restrict__ keys_f;  // NULL = the column is sorted whole
+  int32_t kt, kb;
+};
+
+// The walk found its candidate at walk entry `kres` inside the bucketed middle: counting unseen entries
+// is exact up to the candidate's BIN, the order inside the bin is not.  Fetch the 4*G entries around the
+// candidate (a bin holds at most 64: it lies inside), find the bin's unseen entries, and take them out
+// one by one in exact walk order — (key descending, id ascending) from the top, reversed from the bottom
+// — until as many are out as the position order had put before the candidate: the next one is the answer.
+// Kept lean on purpose (one bit mask per lane, one group-wide maximum per round): it is compiled into
+// the hot kernel, whose register allocation it must not disturb.  Wave-uniform call; `mine` = this group
+// needs it (the other group of the wave idles through).
 template <int G, typename Seen>
+__device__ __forceinline__ int32_t adaptive_finish_in_bin(const int32_t* __restrict__ order_f,
+                                                          const float* __restrict__ keys_f, int32_t I,
+                                                          const Seen& seen, bool from_top, int32_t kres,
+                                                          bool mine, int32_t zlo, int32_t zhi,
+                                                          int32_t fallback, int lane) {
+  const int gl = lane & (G - 1);
+  const bool second = G == 32 && (lane & 32) != 0;
+  const int32_t w0 = mine ? max(kres - 2 * G, 0) : 0;
+  const int32_t k0 = w0 + WALK_UNROLL * gl;
+  const int32_t kc = min(k0, I - 1);
+  const OrderVec vec = *reinterpret_cast<const OrderVec*>(order_f + (from_top ? kc : I - WALK_UNROLL - kc));
+  uint32_t raw[WALK_UNROLL];
+#pragma unroll
+  for (int c = 0; c < WALK_UNROLL; ++c)
+    raw[c] = (k0 + c < I) ? (uint32_t)(from_top ? vec.v[c] : vec.v[WALK_UNROLL - 1 - c]) : 0u;
+  // bin number of my entries = flags counted up to them (walking from the top a flagged entry OPENS its
+  // bin: inclusive count; from the bottom it CLOSES it: exclusive count)
+  int32_t run;
+  {
+    uint32_t below = 0u, cnt_lo = 0u;
+#pragma unroll
+    for (int c = 0; c < WALK_UNROLL; ++c) {
+      const Ballot b = wave_ballot((raw[c] & ORDER_FLAG) != 0u);
+      below = __builtin_amdgcn_mbcnt_hi(b.hi, __builtin_amdgcn_mbcnt_lo(b.lo, below));
+      cnt_lo += (uint32_t)__builtin_popcount(b.lo);
+    }
+    run = (int32_t)(below - (second ? cnt_lo : 0u));  // flags of the lower lanes of my group
+  }
+  const int32_t rel = kres - w0;  // the candidate's place in the window: lane rel / 4, slot rel % 4
+  int32_t b_cand = 0;             // its bin number (valid in its lane)
+  uint32_t in_bin = 0u;           // per lane: bit c = my entry c might be of the candidate's bin (by number)
+  int32_t bnum[WALK_UNROLL];
+#pragma unroll
+  for (int c = 0; c < WALK_UNROLL; ++c) {
+    const bool fl = (raw[c] & ORDER_FLAG) != 0u;
+    if (from_top) run += fl ? 1 : 0;
+    bnum[c] = run;
+    if (!from_top) run += fl ? 1 : 0;
+    b_cand = (rel & 3) == c ? bnum[c] : b_cand;
+  }
+  const int32_t bsel = group_bcast<G>(b_cand, mine ? (rel >> 2) : 0, lane);
+  // alive = unseen entries of that bin (inside the bucketed zone); key / id of each for the order
+  uint32_t alive = 0u;
+  int32_t before = 0;  // of them, those the position order puts before the candidate
+  float key[WALK_UNROLL];
+#pragma unroll
+  for (int c = 0; c < WALK_UNROLL; ++c) {
+    const int32_t it = (int32_t)(raw[c] & ~ORDER_FLAG);
+    const bool m = mine && bnum[c] == bsel && k0 + c >= zlo && k0 + c < zhi && it != 0;
+    key[c] = m ? keys_f[it] + 0.f : 0.f;  // (+0: a -0 key orders as +0, as in the full sort's comparisons)
+    const bool u = m && !seen(it);
+    alive |= u ? (1u << c) : 0u;
+    before += (u && k0 + c < kres) ? 1 : 0;
+  }
+  (void)in_bin;
+  // s = unseen entries of the bin before the candidate (sum over the group's lanes)
+  int32_t s = before;
+#pragma unroll
+  for (int off = 1; off < G; off <<= 1) s += __shfl_xor(s, off, G);
+  // take the bin's unseen entries out in walk order; the (s+1)-th is the answer
+  int32_t result = fallback;
+  const int32_t rounds = mine ? s : -1;
+  int32_t rmax = rounds;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) rmax = max(rmax, __shfl_xor(rmax, off, 64));  // both groups of the wave
+  for (int32_t round = 0; round <= rmax; ++round) {
+    // my best alive entry: composite (orderable key, id) — larger = earlier in walk order
+    uint32_t bh = 0u, bl = 0u;
+    int bc = -1;
+#pragma unroll
+    for (int c = 0; c < WALK_UNROLL; ++c) {
+      uint32_t kb = __float_as_uint(key[c]);
+      kb = (kb & 0x80000000u) ? ~kb : (kb | 0x80000000u);  // ascending uint = ascending float
+      const uint32_t id = raw[c] & ~ORDER_FLAG;
+      const uint32_t h = from_top ? kb : ~kb, l = from_top ? ~id : id;
+      const bool better = ((alive >> c) & 1u) && (bc < 0 || h > bh || (h == bh && l > bl));
+      bh = better ? h : bh;
+      bl = better ? l : bl;
+      bc = better ? c : bc;
+    }
+    if (bc < 0) bh = bl = 0u;
+    // the group's best (ids are unique: no ties between lanes)
+    uint32_t gh = bh, gl_ = bl;
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+      const uint32_t oh = __shfl_xor(gh, off, G), ol = __shfl_xor(gl_, off, G);
+      const bool take = oh > gh || (oh == gh && ol > gl_);
+      gh = take ? oh : gh;
+      gl_ = take ? ol : gl_;
+    }
+    const bool winner = bc >= 0 && bh == gh && bl == gl_ && round <= rounds;
+    if (winner) alive &= ~(1u << bc);
+    const uint32_t wid = from_top ? ~gl_ : gl_;  // the winner's item id, known to the whole group
+    if (round == rounds) result = (int32_t)wid;
+  }
+  return result;
+}
+
+// PART: the snapshot may be partial (its own instantiations of the kernels that sample: an ordinary
+// snapshot's walk carries none of this)
+template <int G, typename Seen, bool PART = false>
 __device__ __forceinline__ int32_t adaptive_walk(const int32_t* __restrict__ order_f, int64_t I64,
                                                  const Seen& seen, bool from_top, int32_t skip,
-                                                 int lane) {
+                                                 int lane, const PartialColumn pc = PartialColumn{nullptr, 0, 0},
+                                                 int32_t* kres_out = nullptr, bool* mid_out = nullptr) {
   const int gl = lane & (G - 1);
   const int32_t I = (int32_t)I64;  // d*I < 2^31 (bpr_adaptive_refresh)
-  int32_t result = 0;
+  int32_t result = 0, kres = 0;
   bool done = false;
   for (int32_t base = 0; base < I; base += G * WALK_UNROLL) {
     // entry k of the walk is order_f[from_top ? k : I-1-k]; k0 = my first entry
@@ -322,7 +447,7 @@ __device__ __forceinline__ int32_t adaptive_walk(const int32_t* __restrict__ ord
     bool is_seen[WALK_UNROLL], unseen[WALK_UNROLL];
 #pragma unroll
     for (int c = 0; c < WALK_UNROLL; ++c) {
-      const int32_t v = from_top ? vec.v[c] : vec.v[WALK_UNROLL - 1 - c];
+      const int32_t v = (int32_t)((uint32_t)(from_top ? vec.v[c] : vec.v[WALK_UNROLL - 1 - c]) & ~ORDER_FLAG);
       items[c] = (k0 + c < I) ? v : 0;
     }
 #pragma unroll
@@ -343,20 +468,32 @@ __device__ __forceinline__ int32_t adaptive_walk(const int32_t* __restrict__ ord
     const int32_t lanes_below = (int32_t)(wave_below - (second ? cnt_lo : 0u));
     // unseen entries before mine in walk order = those of lower lanes + my own earlier ones
     const bool here = !done && skip < run;
-    int32_t before = lanes_below, isel = 0;
+    int32_t before = lanes_below, isel = 0, ksel = 0;
     bool mine = false;
 #pragma unroll
     for (int c = 0; c < WALK_UNROLL; ++c) {
       const bool hit_c = unseen[c] && before == skip;
       isel = hit_c ? items[c] : isel;
+      ksel = hit_c ? k0 + c : ksel;
       mine |= hit_c;
       before += unseen[c] ? 1 : 0;
     }
-    const int32_t got = group_pick<G>(wave_ballot(here && mine), isel, lane);
+    const Ballot hb = wave_ballot(here && mine);
+    const int32_t got = group_pick<G>(hb, isel, lane);
     result = here ? got : result;
+    if constexpr (PART) {  // remember WHERE the candidate sits
+      const int32_t gotk = group_pick<G>(hb, ksel, lane);
+      kres = here ? gotk : kres;
+    }
     skip = (done | here) ? skip : skip - run;
     done |= here;
     if (__all(done)) break;
+  }
+  if constexpr (PART) {
+    // the bucketed middle in walk-entry coordinates
+    const int32_t zlo = from_top ? pc.kt : pc.kb, zhi = I - (from_top ? pc.kb : pc.kt);
+    *mid_out = done && kres >= zlo && kres < zhi;
+    *kres_out = kres;
   }
   return result;
 }
@@ -385,11 +522,14 @@ __device__ __forceinline__ AdaptiveRandoms adaptive_randoms(uint64_t seed, uint6
 
 // `sigma` is any indexable holder of the snapshot's per-factor std in the element layout of this
 // file (a register array, or an LDS view: k_stream keeps it in LDS to save registers).
-template <int G, int E, typename Seen, typename Sigma>
+// `meta` / `keysT`: a PARTIAL snapshot's per-column {kt, kb} and the key columns it was sorted from
+// (k_stream only; NULL = fully sorted).
+template <int G, int E, typename Seen, typename Sigma, bool PART = false>
 __device__ __forceinline__ AdaptiveDraw sample_adaptive(
     const float (&p)[E], int d, const Sigma& sigma,
     const int32_t* __restrict__ order, int64_t I, const Seen& seen, int64_t n_seen,
-    const AdaptiveRandoms& rnd, int lane) {
+    const AdaptiveRandoms& rnd, int lane, const int32_t* __restrict__ meta = nullptr,
+    const float* __restrict__ keysT = nullptr) {
   const int gl = lane & (G - 1);
   // ---- factor ~ Categorical(|p_uf|·σ_f)  (neg_samplers.py:84-88) by inverse CDF, lane by lane:
   // the factors are enumerated in the order (lane, chunk) = (f mod G, f div G) — any enumeration
@@ -441,8 +581,17 @@ __device__ __forceinline__ AdaptiveDraw sample_adaptive(
   AdaptiveDraw out;
   out.factor = fsel;
   out.rank = from_top ? r - 1 : n_unseen - r;
-  out.item = (n_unseen > 0) ? adaptive_walk<G>(order + (int64_t)fsel * I, I, seen, from_top, r - 1,
-                                               lane)
+  PartialColumn pc{nullptr, 0, 0};
+  if constexpr (PART) {
+    pc.kt = meta[2 * fsel];
+    pc.kb = meta[2 * fsel + 1];
+    pc.keys_f = keysT + (int64_t)fsel * I;
+  }
+  out.kres = 0;
+  out.mid = false;
+  out.from_top = from_top;
+  out.item = (n_unseen > 0) ? adaptive_walk<G, Seen, PART>(order + (int64_t)fsel * I, I, seen, from_top,
+                                                           r - 1, lane, pc, &out.kres, &out.mid)
                             : 0;
   return out;
 }

@@ -415,6 +415,10 @@ struct StreamArgs {
   const uint32_t* heavy_off;
   const uint32_t* heavy_bits;
   int32_t heavy_T;
+  // a PARTIAL adaptive snapshot (bpr_refresh.hip k_sort_partial): {kt, kb} per column and the key columns
+  // the snapshot was sorted from (NULL: `order` is sorted whole)
+  const int32_t* snap_meta;
+  const float* snap_keys;
 };
 
 // A hot row's value is its base row plus its replica delta rows; returns where this wave adds its
@@ -450,8 +454,11 @@ struct SigmaLds {
 // (occupancy: the adaptive sampler over the staged-list structure needs a few registers more than
 // 5 waves per SIMD leave; measured on MI355X, 4 and 5 waves run the kernel equally fast — it is not
 // bound by occupancy — so that variant asks for 4 instead of spilling)
-template <int G, int E, int SAMPLER, int SEEN, bool FULL>
-__global__ __launch_bounds__(256, (E <= 4 ? (SAMPLER == NEG_ADAPTIVE && SEEN == SEEN_LIST
+// PART: the adaptive snapshot may be partial (bpr_refresh.hip k_sort_partial) — its own instantiations
+// (its in-bin finish needs ~20 registers more than 5 waves per SIMD leave: it asks for 4 — the kernel is
+// not bound by occupancy, see above — instead of spilling)
+template <int G, int E, int SAMPLER, int SEEN, bool FULL, bool PART = false>
+__global__ __launch_bounds__(256, (E <= 4 ? ((SAMPLER == NEG_ADAPTIVE && SEEN == SEEN_LIST) || PART
                                                  ? BPR_STREAM_WAVES_PER_EU - 1
                                                  : BPR_STREAM_WAVES_PER_EU)
                                           : (E <= 8 ? 3 : 2)))
@@ -635,7 +642,18 @@ void k_stream(const StreamArgs a) {
         } else {
           const AdaptiveRandoms rnd = {group_bcast<G>(my_rnd.uf, step, lane),
                                        group_bcast<G>(my_rnd.r, step, lane)};
-          j = sample_adaptive<G, E>(pl, d, sg, a.order, a.I, seen, (int64_t)cur_n, rnd, lane).item;
+          const AdaptiveDraw dr = sample_adaptive<G, E, Seen, SigmaLds<G>, PART>(
+              pl, d, sg, a.order, a.I, seen, (int64_t)cur_n, rnd, lane, a.snap_meta, a.snap_keys);
+          j = dr.item;
+          if constexpr (PART) {
+            if (__builtin_expect(__any(dr.mid), 0)) {
+              // the walk ended in the bucketed middle of a partial snapshot: finish inside the bin
+              const int32_t kt = a.snap_meta[2 * dr.factor], kb = a.snap_meta[2 * dr.factor + 1];
+              const int32_t zlo = dr.from_top ? kt : kb, zhi = a.I - (dr.from_top ? kb : kt);
+              j = adaptive_finish_in_bin<G>(a.order + (int64_t)dr.factor * a.I, a.snap_keys + (int64_t)dr.factor * a.I,
+                                            a.I, seen, dr.from_top, dr.kres, dr.mid, zlo, zhi, j, lane);
+            }
+          }
         }
         if (a.neg != nullptr && act && gl == 0) a.neg[t] = j;
       }

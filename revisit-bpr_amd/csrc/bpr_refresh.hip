@@ -305,6 +305,338 @@ static void launch_sort_sub(bpr_ctx* c, hipStream_t st, int nf, const float* key
                      order, keysA, idsA, sigma, sig_acc);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// PARTIAL snapshot (r5): what the adaptive sampler reads of a column is its two ends
+// — rank Geometric(p) + seen-skips from the top or from the bottom (neg_samplers.py:90-121) — so only
+// the ends are sorted exactly and the middle is BUCKETED:
+//   order[0 .. Kt)        the Kt largest keys, exact descending order (ties by ascending id)
+//   order[Kt .. I - Kb)   the middle in MID_BINS value-linear bins, bins in descending key order,
+//                         any order inside a bin; the first entry of a bin carries MID_FLAG
+//   order[I - Kb .. I)    the Kb smallest keys, exact (the first of them carries MID_FLAG too)
+// Kt / Kb come from two cuts read off a coarse histogram of the column (any counts are legal;
+// meta[f] = {Kt, Kb}).  A walk that leaves an exact end keeps counting unseen entries — counting
+// does not care about the order inside a bin — and finishes INSIDE one bin by ranking its <= MID_BIN_MAX
+// keys on the fly (bpr_device.h adaptive_finish_in_bin).  A column the scheme does not fit (a threshold
+// that does not separate, an end that overflows its compaction buffer, a bin with more than
+// MID_BIN_MAX keys: many equal keys) reports meta[f] = {-1, -1} and is sorted whole by the kernel
+// launched behind this one (k_sort_sub over the flagged columns).
+// One 1024-thread workgroup per column, I <= 1024 * ITEMS.
+// ---------------------------------------------------------------------------------------------
+constexpr int MID_BINS = 4096;
+constexpr int MID_BIN_MAX = 64;
+constexpr int PART_CI = 2;                    // compacted keys per thread in the sort of the two ends
+constexpr int PART_CAP = 1024 * PART_CI / 2;  // ... i.e. at most 1,024 keys per end
+constexpr uint32_t MID_FLAG = 0x80000000u;    // == bpr::ORDER_FLAG (bpr_device.h)
+
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_sort_partial(const float* __restrict__ T, int64_t I,
+                                                       int32_t* __restrict__ order,
+                                                       float* __restrict__ sigma,
+                                                       int32_t* __restrict__ meta, int target) {
+  using EndSort = rocprim::block_radix_sort<float, 1024, PART_CI, uint16_t>;
+  __shared__ union {
+    typename EndSort::storage_type ends;
+    double red[2][16];
+  } sm;
+  __shared__ float s_ck[2 * PART_CAP];     // compacted keys: [0, CAP) the top end, [CAP, 2 CAP) the bottom end
+  __shared__ uint16_t s_ci[2 * PART_CAP];  // ... and their item ids
+  __shared__ uint32_t s_hist[MID_BINS];    // keys per middle bin, then the bins' first positions
+  __shared__ uint32_t s_coarse[1024];      // keys per coarse bin of the whole column
+  __shared__ uint32_t s_cum[1024];         // ... and before it, from the top
+  __shared__ uint32_t s_scan[1024];
+  __shared__ int32_t s_cnt[4];             // the cuts' coarse bins, largest middle bin
+  __shared__ int32_t s_mid[1024 * ITEMS];  // the middle, staged: written back in whole lines (a scattered 4-byte
+                                           // store is a 64-B write request at the memory side — the very
+                                           // resource k_stream, running beside this kernel, is bound by)
+  const int f = blockIdx.x;
+  const float* row = T + (int64_t)f * I;
+  const int t = threadIdx.x;
+  const int n = (int)I;
+  float keys[ITEMS];
+  double s1 = 0.0, s2 = 0.0;
+  const float first = row[1];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int l = t * ITEMS + k;  // blocked: a thread's ids ascend, and so do the threads'
+    const bool valid = l < n;
+    const float v = valid ? row[l] : 0.f;
+    keys[k] = v;
+    if (valid && l >= 1) {
+      const double c = (double)v - (double)first;
+      s1 += c;
+      s2 += c * c;
+    }
+  }
+  for (int k = t; k < MID_BINS; k += 1024) s_hist[k] = 0u;
+  s_coarse[t] = 0u;
+  if (t < 4) s_cnt[t] = t == 1 ? 1023 : 0;  // [0] / [1]: the cuts' coarse bins (defaults: nothing in the ends)
+  // sigma_f = unbiased std over rows 1..I-1 (neg_samplers.py:132), as k_sort_sub
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  if ((t & 63) == 0) {
+    sm.red[0][t >> 6] = s1;
+    sm.red[1][t >> 6] = s2;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      a += sm.red[0][w];
+      b += sm.red[1][w];
+    }
+    const double nn = (double)(I - 1);
+    sigma[f] = (float)sqrt(fmax(b - a * a / nn, 0.0) / (nn - 1.0));
+    sm.red[0][0] = a;  // the totals, for everybody (the coarse bins' range)
+    sm.red[1][0] = b;
+  }
+  __syncthreads();
+  // ---- a coarse histogram of the whole column: 1,024 value-linear bins over mean +- 5 sigma (out-of-range
+  // keys in the end bins).  Everything below is decided by a key's coarse bin and its place inside it — a
+  // monotone function of the key — so classes and bins agree with the order whatever the rounding, equal keys
+  // stay together, and any distribution works: a skewed column gets unequal ends, a column with a spike
+  // (the cold items of a trained model: thousands of keys within +-0.004 of zero) gets as many fine bins
+  // there as it has keys there (the fine bins are cut along the coarse CDF, not along the value axis).
+  float cmax, cscale;
+  {
+    const double nn = (double)(I - 1);
+    const double a = sm.red[0][0], b = sm.red[1][0];
+    const double mean = (double)first + a / nn;
+    const double sd = sqrt(fmax(b - a * a / nn, 0.0) / (nn - 1.0));
+    cmax = (float)(mean + 5.0 * sd);
+    cscale = sd > 0.0 ? (float)(1024.0 / (10.0 * sd)) : 0.f;
+  }
+  auto coarse = [&](float v) { return min(1023, max(0, (int)((cmax - v) * cscale))); };
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k)
+    if (t * ITEMS + k < n) atomicAdd(&s_coarse[coarse(keys[k])], 1u);
+  __syncthreads();
+  {
+    const int mine = (int)s_coarse[t];  // one coarse bin per thread
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if ((t & 63) >= off) incl += u;
+    }
+    if ((t & 63) == 63) s_scan[t >> 6] = (uint32_t)incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += (int)s_scan[w];
+    incl += base;                        // keys in coarse bins 0..t (from the top)
+    s_cum[t] = (uint32_t)(incl - mine);  // keys above coarse bin t
+  }
+  __syncthreads();
+  // ---- classify by a key's interpolated RANK r = (keys above its coarse bin) + (its place inside the bin) x
+  // (keys in the bin): top r < target, bottom r >= n - target, middle between; the middle's fine bin is r
+  // scaled to MID_BINS.  r is a monotone function of the key (equal keys: equal r), so classes and bins
+  // agree with the order; inside a coarse bin the density is taken as uniform, which is what makes the
+  // cuts and the bins equi-DEPTH rather than equi-width.
+  const float rt = (float)min(target, n / 4), rb = (float)n - rt;
+  const bool separates = cscale > 0.f;
+  const float fscale = (float)MID_BINS / fmaxf(rb - rt, 1.f);
+  int my_top = 0, my_bot = 0;
+  uint32_t packed[ITEMS];  // bit 31: not a middle key (bit 0: top); else bin << 8 | ordinal inside the bin
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int l = t * ITEMS + k;
+    packed[k] = 0x80000000u;
+    if (l >= n || !separates) continue;
+    const float x = (cmax - keys[k]) * cscale;
+    const int cb = min(1023, max(0, (int)x));
+    const float frac = fminf(fmaxf(x - (float)cb, 0.f), 0.999f);
+    const float r = (float)s_cum[cb] + frac * (float)s_coarse[cb];
+    if (r < rt) {
+      packed[k] = 0x80000001u;
+      ++my_top;
+    } else if (r >= rb) {
+      ++my_bot;
+    } else {
+      const int bin = min(MID_BINS - 1, max(0, (int)((r - rt) * fscale)));
+      const uint32_t ord = atomicAdd(&s_hist[bin], 1u);
+      packed[k] = ((uint32_t)bin << 8) | min(ord, 255u);
+    }
+  }
+  // ---- the ends' keys in the compaction buffers: block-wide exclusive scans of the threads' counts
+  auto block_excl = [&](int v, int* total) {
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if ((t & 63) >= off) incl += u;
+    }
+    __syncthreads();
+    if ((t & 63) == 63) s_scan[t >> 6] = (uint32_t)incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int c = (int)s_scan[w];
+      if (w < (t >> 6)) base += c;
+      tot += c;
+    }
+    *total = tot;
+    return base + incl - v;
+  };
+  int Kt = 0, Kb = 0, n_mid = 0;
+  const int top_at = block_excl(my_top, &Kt);
+  const int bot_at = block_excl(my_bot, &Kb);
+  n_mid = n - Kt - Kb;
+  // ---- the fine bins' sizes -> first positions (exclusive scan over MID_BINS = 4 per thread)
+  int biggest = 0;
+  {
+    uint32_t c4[MID_BINS / 1024];
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < MID_BINS / 1024; ++q) {
+      c4[q] = s_hist[t * (MID_BINS / 1024) + q];
+      mine += (int)c4[q];
+      biggest = max(biggest, (int)c4[q]);
+    }
+    int tot_mid = 0;
+    int at = block_excl(mine, &tot_mid);
+#pragma unroll
+    for (int q = 0; q < MID_BINS / 1024; ++q) {
+      s_hist[t * (MID_BINS / 1024) + q] = (uint32_t)at;
+      at += (int)c4[q];
+    }
+  }
+  if (biggest > MID_BIN_MAX) atomicMax(&s_cnt[2], biggest);
+  __syncthreads();
+  const bool ok = separates && Kt <= PART_CAP && Kb <= PART_CAP && Kt >= 1 && Kb >= 1 && n_mid >= 0 && s_cnt[2] == 0;
+  if (!ok) {  // (uniform over the block) the column is sorted whole by the kernel behind this one
+    if (t == 0) {
+      meta[2 * f] = -1;
+      meta[2 * f + 1] = -1;
+    }
+    return;
+  }
+  if (t == 0) {
+    meta[2 * f] = Kt;
+    meta[2 * f + 1] = Kb;
+  }
+  // ---- scatter (all in LDS): ends to the compaction buffers (ids ascending among equal keys: the sort is
+  // stable), middle keys to their place in the staged middle
+  // a key between the two ends for the pads: the smallest top key and the largest bottom key bracket it
+  // (block minimum / maximum through s_scan)
+  float tmin = __builtin_huge_valf(), bmax = -__builtin_huge_valf();
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    if (t * ITEMS + k >= n || (packed[k] & 0x80000000u) == 0u) continue;
+    if (packed[k] & 1u) tmin = fminf(tmin, keys[k]); else bmax = fmaxf(bmax, keys[k]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    tmin = fminf(tmin, __shfl_xor(tmin, off, 64));
+    bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64));
+  }
+  __syncthreads();
+  if ((t & 63) == 0) {
+    s_scan[t >> 6] = __float_as_uint(tmin);
+    s_scan[16 + (t >> 6)] = __float_as_uint(bmax);
+  }
+  __syncthreads();
+  for (int w = 0; w < 16; ++w) {
+    tmin = fminf(tmin, __uint_as_float(s_scan[w]));
+    bmax = fmaxf(bmax, __uint_as_float(s_scan[16 + w]));
+  }
+  const float pad_key = 0.5f * tmin + 0.5f * bmax;
+  __syncthreads();
+  for (int k = t; k < 2 * PART_CAP; k += 1024) {
+    // pads sort between the two ends: a key of the middle's range; should it tie with an end's key the pads
+    // still sit on the right side of the tie — top keys precede them in the buffer, bottom keys follow them
+    s_ck[k] = pad_key;
+    s_ci[k] = 0;
+  }
+  __syncthreads();
+  {
+    int ta = top_at, ba = bot_at;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int l = t * ITEMS + k;
+      if (l >= n) continue;
+      if ((packed[k] & 0x80000000u) == 0u) {
+        const int bin = (int)(packed[k] >> 8), ord = (int)(packed[k] & 255u);
+        s_mid[(int)s_hist[bin] + ord] = (int32_t)((uint32_t)l | (ord == 0 ? MID_FLAG : 0u));
+      } else if (packed[k] & 1u) {
+        s_ck[ta] = keys[k];
+        s_ci[ta] = (uint16_t)l;
+        ++ta;
+      } else {
+        // the bottom end sits at the END of its half: pads before it, so that pads win ties with it
+        const int at = 2 * PART_CAP - Kb + ba;
+        s_ck[at] = keys[k];
+        s_ci[at] = (uint16_t)l;
+        ++ba;
+      }
+    }
+  }
+  __syncthreads();
+  int32_t* col = order + (int64_t)f * I;
+  for (int k = t; k < n_mid; k += 1024) col[Kt + k] = s_mid[k];  // whole lines
+  // ---- the two ends in ONE stable descending sort of 2 x PART_CAP (key, id) pairs
+  float ek[PART_CI];
+  uint16_t ev[PART_CI];
+#pragma unroll
+  for (int k = 0; k < PART_CI; ++k) {
+    ek[k] = s_ck[t * PART_CI + k];
+    ev[k] = s_ci[t * PART_CI + k];
+  }
+  __syncthreads();
+  EndSort().sort_desc_to_striped(ek, ev, sm.ends);
+#pragma unroll
+  for (int k = 0; k < PART_CI; ++k) {
+    const int pos = k * 1024 + t;  // rank in the sorted sequence: top end, pads, bottom end
+    if (pos < Kt) col[pos] = (int32_t)ev[k];
+    else if (pos >= 2 * PART_CAP - Kb) {
+      const int b = pos - (2 * PART_CAP - Kb);  // 0 .. Kb-1
+      col[n - Kb + b] = (int32_t)((uint32_t)ev[k] | (b == 0 ? MID_FLAG : 0u));
+    }
+  }
+}
+
+// the columns k_sort_partial gave up on (meta[f] < 0), sorted whole: k_sort_sub's single-workgroup form
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_sort_flagged(const float* __restrict__ T, int64_t I,
+                                                       int32_t* __restrict__ order,
+                                                       int32_t* __restrict__ meta) {
+  using Sort = rocprim::block_radix_sort<float, 1024, ITEMS, uint16_t, 1, 1, BPR_SORT_RADIX_BITS>;
+  __shared__ typename Sort::storage_type sm;
+  const int f = blockIdx.x;
+  if (meta[2 * f] >= 0) return;
+  const float* row = T + (int64_t)f * I;
+  const int t = threadIdx.x;
+  float keys[ITEMS];
+  uint16_t vals[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int64_t l = (int64_t)t * ITEMS + k;
+    keys[k] = l < I ? row[l] : -__builtin_huge_valf();
+    vals[k] = (uint16_t)l;
+  }
+  Sort().sort_desc_to_striped(keys, vals, sm);
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int64_t pos = (int64_t)k * 1024 + t;
+    if (pos < I) order[(int64_t)f * I + pos] = (int32_t)vals[k];
+  }
+  __syncthreads();
+  if (t == 0) {
+    meta[2 * f] = (int32_t)I;  // every position exact
+    meta[2 * f + 1] = 0;
+  }
+}
+
+template <int ITEMS>
+static void launch_sort_partial(bpr_ctx* c, hipStream_t st, const float* keysT, int32_t* order, float* sigma,
+                                int32_t* meta, int target) {
+  hipLaunchKernelGGL((k_sort_partial<ITEMS>), dim3(c->d), dim3(1024), 0, st, keysT, c->I, order, sigma, meta,
+                     target);
+  hipLaunchKernelGGL((k_sort_flagged<ITEMS>), dim3(c->d), dim3(1024), 0, st, keysT, c->I, order, meta);
+}
+
 // composite sort key: (factor << 32) | ~orderable(value)  → ascending sort = per-factor descending
 __global__ void k_compose_keys(const float* __restrict__ T, uint64_t* __restrict__ keys, int64_t n,
                                int64_t I) {
@@ -954,9 +1286,15 @@ void refresh_free(bpr_ctx* c) {
   for (int k = 0; k < 2; ++k) {
     hipFree(c->keysT_buf[k]);
     hipFree(c->sig_acc_buf[k]);
+    hipFree(c->snap_meta[k]);
     c->keysT_buf[k] = nullptr;
     c->sig_acc_buf[k] = nullptr;
+    c->snap_meta[k] = nullptr;
+    c->snap_partial[k] = false;
+    c->snap_keys[k] = nullptr;
   }
+  c->meta_front = nullptr;
+  c->keys_front = nullptr;
   hipFree(c->keys_sorted);
   hipFree(c->ids_in);
   hipFree(c->seg_offsets);
@@ -1009,6 +1347,7 @@ int refresh_alloc(bpr_ctx* c) {
                                  c->stream));
     BPR_HIP_CHECK(hipMalloc(&c->sigma_buf[k], sizeof(float) * d));
   }
+  for (int k = 0; k < 2; ++k) BPR_HIP_CHECK(hipMalloc(&c->snap_meta[k], sizeof(int32_t) * 2 * d));
   c->snap_front = 0;
   c->order = c->order_alloc[0] + BPR_ORDER_PAD;
   c->sigma = c->sigma_buf[0];
@@ -1115,6 +1454,25 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
   if (force_sub == 1 || force_sub == 2 || force_sub == 4) sub = force_sub;
   int64_t len = (I + sub - 1) / sub;
   len = (len + 15) / 16 * 16;
+  // PARTIAL order (r5): the split refresh of a column that one workgroup holds — the exact ends + a
+  // bucketed middle, ~half the sort's work (k_sort_partial); everybody but k_stream gets the snapshot
+  // completed on demand (snapshot_complete_impl)
+  const bool partial = split && !part && c->tune_partial != 0 && sub == 1 && len <= 1024 * 24 && I <= 65535 &&
+                       I >= 2048 && !no_fast;
+  c->snap_partial[back] = partial;
+  c->snap_keys[back] = keysT;
+  if (partial) {
+    const int items = (int)((len + 1023) / 1024);
+    int32_t* meta = c->snap_meta[back];
+    const int target = c->partial_target;
+    if (items <= 6) launch_sort_partial<6>(c, st, keysT, order, sigma, meta, target);
+    else if (items <= 10) launch_sort_partial<10>(c, st, keysT, order, sigma, meta, target);
+    else if (items <= 12) launch_sort_partial<12>(c, st, keysT, order, sigma, meta, target);
+    else if (items <= 16) launch_sort_partial<16>(c, st, keysT, order, sigma, meta, target);
+    else if (items <= 20) launch_sort_partial<20>(c, st, keysT, order, sigma, meta, target);
+    else launch_sort_partial<24>(c, st, keysT, order, sigma, meta, target);
+    BPR_HIP_CHECK(hipGetLastError());
+  } else
   if (len <= 1024 * 36 && !no_fast) {
     float* keysA = reinterpret_cast<float*>(c->keys_sorted);
     int32_t* idsA = reinterpret_cast<int32_t*>(keysA + n);
@@ -1164,7 +1522,36 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
   c->snap_front = back;
   c->order = order;
   c->sigma = sigma;
+  c->meta_front = c->snap_partial[back] ? c->snap_meta[back] : nullptr;
+  c->keys_front = c->snap_keys[back];
   c->have_snapshot = true;
+  return BPR_OK;
+}
+
+// A partial front snapshot sorted whole, in place, from the keys it was cut from: for every reader but
+// k_stream (the sampler kernels behind the Python API, the batched STREAM kernel, bpr_adaptive_get_snapshot).
+int snapshot_complete_impl(bpr_ctx* c) {
+  if (c->meta_front == nullptr || !c->have_snapshot) return BPR_OK;
+  const int front = c->snap_front;
+  const int64_t I = c->I;
+  int64_t len = (I + 15) / 16 * 16;
+  const int items = (int)((len + 1023) / 1024);
+  int32_t* order = c->order_alloc[front] + BPR_ORDER_PAD;
+  float* sigma = c->sigma_buf[front];
+  double* acc = c->sig_acc;  // (unused by the single-workgroup form)
+  const float* keys = c->keys_front;
+  hipStream_t st = c->stream;
+  if (items <= 6) launch_sort_sub<6>(c, st, c->d, keys, acc, order, sigma, 1, len, nullptr, nullptr);
+  else if (items <= 10) launch_sort_sub<10>(c, st, c->d, keys, acc, order, sigma, 1, len, nullptr, nullptr);
+  else if (items <= 12) launch_sort_sub<12>(c, st, c->d, keys, acc, order, sigma, 1, len, nullptr, nullptr);
+  else if (items <= 16) launch_sort_sub<16>(c, st, c->d, keys, acc, order, sigma, 1, len, nullptr, nullptr);
+  else if (items <= 20) launch_sort_sub<20>(c, st, c->d, keys, acc, order, sigma, 1, len, nullptr, nullptr);
+  else if (items <= 24) launch_sort_sub<24>(c, st, c->d, keys, acc, order, sigma, 1, len, nullptr, nullptr);
+  else if (items <= 28) launch_sort_sub<28>(c, st, c->d, keys, acc, order, sigma, 1, len, nullptr, nullptr);
+  else launch_sort_sub<36>(c, st, c->d, keys, acc, order, sigma, 1, len, nullptr, nullptr);
+  BPR_HIP_CHECK(hipGetLastError());
+  c->snap_partial[front] = false;
+  c->meta_front = nullptr;
   return BPR_OK;
 }
 
@@ -1177,6 +1564,8 @@ int refresh_publish_impl(bpr_ctx* c) {
   c->snap_front = back;
   c->order = c->order_alloc[back] + BPR_ORDER_PAD;
   c->sigma = c->sigma_buf[back];
+  c->meta_front = nullptr;  // (a sharded refresh is always sorted whole)
+  c->keys_front = c->snap_keys[back];
   c->have_snapshot = true;
   c->part_pending = false;
   return BPR_OK;
@@ -1192,6 +1581,8 @@ int refresh_commit_impl(bpr_ctx* c) {
   c->snap_front = back;
   c->order = c->order_alloc[back] + BPR_ORDER_PAD;
   c->sigma = c->sigma_buf[back];
+  c->meta_front = c->snap_partial[back] ? c->snap_meta[back] : nullptr;
+  c->keys_front = c->snap_keys[back];
   c->have_snapshot = true;
   c->refresh_pending = false;
   return BPR_OK;

@@ -264,6 +264,7 @@ int bpr_train_stream_batched(bpr_ctx* c, const int32_t* users, const int32_t* po
   a.P = table_P(c);
   a.Q = table_Q(c);
   a.indptr = c->indptr; a.indices = c->indices;
+  if (int rc = snapshot_complete_impl(c)) return rc;  // (a partial snapshot left by the SGD path's split refresh)
   a.order = c->order; a.sigma = c->sigma;
   a.users = users; a.pos = pos; a.neg = neg;
   a.partials = out_scalars != nullptr ? c->dev_scalars : nullptr;

@@ -430,6 +430,17 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       hipEvent_t stop = acut ? c->ev_launch : nullptr;
       auto go = [&](auto smp, auto sn) {
         constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
+        if constexpr (SMP == NEG_ADAPTIVE) {
+          if (a.snap_meta != nullptr) {  // a partial snapshot: the instantiations whose walk can finish inside a bin
+            if (c->d == G * E)
+              hipExtLaunchKernelGGL((k_stream<G, E, SMP, SN, true, true>), dim3(grid), dim3(block), shmem,
+                                    c->stream, nullptr, stop, 0, a);
+            else
+              hipExtLaunchKernelGGL((k_stream<G, E, SMP, SN, false, true>), dim3(grid), dim3(block), shmem,
+                                    c->stream, nullptr, stop, 0, a);
+            return;
+          }
+        }
         if (c->d == G * E)
           hipExtLaunchKernelGGL((k_stream<G, E, SMP, SN, true>), dim3(grid), dim3(block), shmem,
                                 c->stream, nullptr, stop, 0, a);
@@ -749,6 +760,7 @@ static int launch_sample(bpr_ctx* c, int what, SampleArgs a) {
 static SampleArgs sample_args(const bpr_ctx* c) {
   SampleArgs a;
   memset(&a, 0, sizeof(a));
+  (void)snapshot_complete_impl(const_cast<bpr_ctx*>(c));  // the sampler kernels read a snapshot sorted whole
   a.P = c->P; a.I = c->I; a.d = c->d;
   a.indptr = c->indptr; a.indices = c->indices;
   a.order = c->order; a.sigma = c->sigma;
@@ -821,10 +833,19 @@ int bpr_adaptive_snapshot_ptrs(bpr_ctx* c, int32_t back, void** order_host, void
     return fail(BPR_ERR_INVALID, "bpr_adaptive_snapshot_ptrs: NULL argument");
   BPR_HIP_CHECK(hipSetDevice(c->device));
   if (int rc = refresh_alloc(c)) return rc;
+  if (!back)
+    if (int rc = snapshot_complete_impl(c)) return rc;
   const int front = c->snap_front;
   const int which = back ? (c->have_snapshot ? front ^ 1 : front) : front;
   *order_host = (void*)(c->order_alloc[which] + BPR_ORDER_PAD);
   *sigma_host = (void*)c->sigma_buf[which];
+  return BPR_OK;
+}
+
+int bpr_adaptive_snapshot_partial(bpr_ctx* c, int32_t* partial_host) {
+  if (c == nullptr || partial_host == nullptr)
+    return fail(BPR_ERR_INVALID, "bpr_adaptive_snapshot_partial: NULL argument");
+  *partial_host = (c->have_snapshot && c->meta_front != nullptr) ? 1 : 0;
   return BPR_OK;
 }
 
@@ -902,6 +923,7 @@ int bpr_adaptive_pick(bpr_ctx* c, const int32_t* users, const int32_t* factor, c
 int bpr_adaptive_get_snapshot(bpr_ctx* c, int32_t* order_out, float* sigma_out) {
   if (int rc = check_bound(c, "bpr_adaptive_get_snapshot")) return rc;
   if (!c->have_snapshot) return fail(BPR_ERR_INVALID, "bpr_adaptive_get_snapshot: no snapshot");
+  if (int rc = snapshot_complete_impl(c)) return rc;
   if (order_out)
     BPR_HIP_CHECK(hipMemcpyAsync(order_out, c->order, sizeof(int32_t) * (size_t)c->d * c->I,
                                  hipMemcpyDeviceToDevice, c->stream));
@@ -1023,6 +1045,8 @@ static int train_stream_impl(bpr_ctx* c, const int32_t* users, const int32_t* po
   a.P = c->P; a.Q = c->Q; a.bias = c->bias;
   a.indptr = c->indptr; a.indices = c->indices;
   a.order = c->order; a.sigma = c->sigma;
+  a.snap_meta = c->meta_front;
+  a.snap_keys = c->meta_front != nullptr ? c->keys_front : nullptr;
   a.users = users; a.pos = pos; a.neg = neg;
   a.partials = out_scalars != nullptr ? c->dev_scalars : nullptr;
   a.seed = seed; a.offset = offset;
@@ -1325,6 +1349,8 @@ int bpr_set_tuning(bpr_ctx* c, const char* key, int32_t value) {
   if (k == "seen" && value >= 0 && value <= 3) c->tune_seen = value;
   else if (k == "vs_direct" && value >= -1 && value <= 1) c->tune_vs_direct = value;
   else if (k == "adam_closed" && (value == 0 || value == 1)) c->tune_adam_closed = value;
+  else if (k == "partial_snapshot" && (value == 0 || value == 1)) c->tune_partial = value;
+  else if (k == "partial_target" && value >= 1 && value <= 1024) c->partial_target = value;
   else if (k == "refresh_sub" && (value == 0 || value == 1 || value == 2 || value == 4)) c->tune_refresh_sub = value;
   else return fail(BPR_ERR_INVALID, "bpr_set_tuning: unknown key or value out of range");
   c->stream_occ.clear();

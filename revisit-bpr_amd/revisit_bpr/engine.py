@@ -145,6 +145,12 @@ class Engine:
         if os.environ.get("BPR_HEAVY_T"):
             native.check(self._lib.bpr_set_heavy_users(self._ctx, int(os.environ["BPR_HEAVY_T"]), 0))
 
+    def snapshot_partial(self) -> bool:
+        """True while the snapshot the samplers read is a partial one (``bpr_adaptive_snapshot_partial``)."""
+        v = ctypes.c_int32()
+        native.check(self._lib.bpr_adaptive_snapshot_partial(self._ctx, ctypes.byref(v)))
+        return bool(v.value)
+
     def set_tuning(self, key: str, value: int) -> None:
         """``bpr_set_tuning``: "seen" 0 auto | 1 csr | 2 bitmap | 3 list; "vs_direct" -1 auto | 0 | 1."""
         native.check(self._lib.bpr_set_tuning(self._ctx, key.encode(), int(value)))

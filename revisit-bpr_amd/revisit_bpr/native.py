@@ -57,6 +57,7 @@ SIGNATURES = {
     "bpr_bind_item_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "bpr_set_reg": (c_int, [c_void_p, c_float, c_float, c_float]),
     "bpr_set_tuning": (c_int, [c_void_p, c_char_p, c_int32]),
+    "bpr_adaptive_snapshot_partial": (c_int, [c_void_p, POINTER(c_int32)]),
     "bpr_set_bias_tracking": (c_int, [c_void_p, c_int32]),
     "bpr_bias_written": (c_int, [c_void_p]),
     "bpr_set_optimizer": (c_int, [c_void_p, c_int32, POINTER(OptParams)]),

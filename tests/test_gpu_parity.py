@@ -1412,6 +1412,69 @@ def test_stream_heavy_users_pick_like_the_oracle(d, seen, heavy_t, monkeypatch):
                           oracle.sample_uniform(indptr, indices2, I, users, seed=5, offset=7))
 
 
+# ---- partial adaptive snapshots (r5): exact ends + bucketed middle, the walk finishes inside a bin ----
+@pytest.mark.parametrize("seen", ["", "list"])
+@pytest.mark.parametrize("I,d,target,ties", [(2500, 128, 4, False), (2500, 128, 64, False), (9000, 64, 16, False),
+                                             (20108, 128, 1024, False), (4000, 256, 8, False),
+                                             (3000, 128, 32, True)])
+def test_partial_snapshot_picks_exactly_what_the_full_snapshot_picks(I, d, target, ties, seen, monkeypatch):
+    """bpr_adaptive_refresh_begin with bpr_set_tuning("partial_snapshot", 1) sorts only the two ends of
+    every column and buckets the middle (k_sort_partial); k_stream's walk finishes inside a bin by
+    ranking its keys on the fly.  Whatever the size of the exact ends — `target` 4 sends nearly every walk
+    through the finish — the negatives must be, triple for triple, those drawn from the fully sorted
+    snapshot of the same table, i.e. the oracle's; heavy users (long walks, both ends) and light ones,
+    walks from the top and from the bottom; a column with many equal keys is given up by the partial
+    sort and sorted whole.  The snapshot the API hands out afterwards is complete (sorted on demand)."""
+    if seen:
+        monkeypatch.setenv("BPR_SEEN", seen)
+    rng = np.random.default_rng(I + target)
+    U, n = 400, 40_000
+    lens = np.where(rng.random(U) < 0.25, rng.integers(I // 3, (2 * I) // 3, U), rng.integers(0, 90, U))
+    lens[0] = 0
+    rows = [np.sort(rng.choice(np.arange(1, I), size=int(k), replace=False)).astype(np.int32) for k in lens]
+    indptr = np.zeros(U + 1, np.int64)
+    indptr[1:] = np.cumsum(lens)
+    indices = np.concatenate(rows)
+    P = rng.normal(0, 0.3, (U, d)).astype(np.float32)
+    Q = rng.normal(0, 0.3, (I, d)).astype(np.float32)
+    if ties:
+        Q[:, :7] = np.round(Q[:, :7] * 3) / 3   # a few dozen distinct values per column: bins overflow
+        Q[:, 7] = 0.25                           # an all-equal column
+    P[0] = 0
+    Q[0] = 0
+    users = np.sort(rng.integers(1, U, n)).astype(np.int32)
+    pos = rng.integers(1, I, n).astype(np.int32)
+    out = {}
+    for partial in (0, 1):
+        e = make_engine(P, Q, None, (0.01, 0.01, 0.01))
+        e.bind_seen_csr(dev(indptr), dev(indices))
+        e.set_optimizer(kind=0, lr=0.0)
+        e.set_stream_opts(True, 0)
+        e.set_tuning("partial_snapshot", partial)
+        e.set_tuning("partial_target", target)
+        e.adaptive_refresh()
+        e.adaptive_refresh_begin()
+        e.adaptive_refresh_commit()
+        assert e.snapshot_partial() == bool(partial)
+        negs = torch.zeros(n, dtype=torch.int32, device="cuda")
+        e.train_stream(dev(users), dev(pos), sampler=2, neg=negs, adaptive_p=0.02, seed=5, offset=7)
+        out[partial] = negs.cpu().numpy()
+        if partial:
+            assert e.snapshot_partial()  # the launch read it as it was
+            order = e.adaptive_snapshot()[0].cpu().numpy()  # completed on demand
+            assert not e.snapshot_partial()
+            QT, _ = oracle.adaptive_stats(Q)
+            assert np.array_equal(order, oracle.adaptive_order(QT))
+            # ... and the sampler kernel behind the Python API reads the completed snapshot
+            got2 = e.sample_adaptive(dev(users[:2048]), 0.02, seed=5, offset=7).cpu().numpy()
+            assert np.array_equal(got2, out[0][:2048])
+    assert np.array_equal(out[0], out[1]), (out[0] != out[1]).mean()
+    QT, sigma = oracle.adaptive_stats(Q)
+    want, _, _ = oracle.sample_adaptive(P, sigma, oracle.adaptive_order(QT), indptr, indices, users, 0.02, seed=5,
+                                        offset=7)
+    assert (out[1] == want).mean() > 0.995
+
+
 # ---- uniform sampler: exact pick when rejection cannot succeed ------------------------------------
 @pytest.mark.parametrize("seen", ["", "csr", "list"])
 @pytest.mark.parametrize("d", [32, 256])
