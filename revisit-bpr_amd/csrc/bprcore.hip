@@ -602,7 +602,13 @@ int bpr_ctx_create(bpr_ctx** out, int device_id, void* hip_stream) {
 int bpr_ctx_destroy(bpr_ctx* c) {
   if (c == nullptr) return BPR_OK;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  // The caller's streams may be GONE by now: a garbage collector destroys the objects of a finished
+  // trainer in any order, and hipStreamSynchronize on a destroyed (CU-masked) stream aborts inside the
+  // runtime ("std::system_error: Invalid argument") or hangs — the intermittent failure of the two-rank
+  // parity run (r5).  So: wait for the DEVICE, and do whatever cleanup work is left on the default stream.
+  hipDeviceSynchronize();
+  c->stream = nullptr;
+  if (!c->side_owned) c->side = nullptr;
   free_strict_scratch(c);
   comm_free(c);
   refresh_free(c);

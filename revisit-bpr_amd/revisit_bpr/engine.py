@@ -363,8 +363,10 @@ class Engine:
 
     def set_side_stream(self, stream: Optional["MaskedStream"]) -> None:
         """The stream the split refresh sorts on (None: a plain stream owned by the library)."""
-        self._keep["side_stream"] = stream
+        # (the library synchronises the stream it is about to let go of: the old one must still exist then —
+        # the reference kept here is replaced AFTER the call)
         native.check(self._lib.bpr_set_side_stream(self._ctx, None if stream is None else stream.ptr))
+        self._keep["side_stream"] = stream
 
     def sample_adaptive(self, users: torch.Tensor, p: float, seed: int, offset: int = 0,
                         return_draws: bool = False):
