@@ -494,7 +494,7 @@ def main():
             # by shape (fast.auto_schedule: 64 CUs for the ML-20M workload, 96 for MSD d=256); it may
             # also say that no split of the chip beats the reference's serial schedule
             from revisit_bpr.fast import auto_schedule
-            a_lag, cus = auto_schedule(I, d, chunk, total_cus)
+            a_lag, cus = auto_schedule(I, d, chunk, total_cus, lr=args.lr)  # (lr: the staleness budget of a lagged snapshot)
             if a_lag == 0.0 and args.refresh_lag is None:
                 lag, cus = 0.0, 0
         if cus > 0:

@@ -79,6 +79,7 @@ struct bpr_ctx {
   // every column, whether that buffer holds a partial order, and the key buffer it was sorted from (the
   // walk's in-bin finish reads it: it outlives the snapshot, see refresh_impl); *_front = the pair the
   // samplers read (meta_front NULL = sorted whole)
+  int tune_binned = 1;        // 1: columns of 2,048 .. 20,480 keys are ordered by k_sort_binned (0: the radix sort)
   int tune_partial = 0;       // 1: the split refresh sorts partially when the shape allows
   int partial_target = 640;   // keys aimed at per exact end (at most 1,024 fit: k_sort_partial's PART_CAP)
   int32_t* snap_meta[2] = {nullptr, nullptr};

@@ -637,6 +637,283 @@ static void launch_sort_partial(bpr_ctx* c, hipStream_t st, const float* keysT, 
   hipLaunchKernelGGL((k_sort_flagged<ITEMS>), dim3(c->d), dim3(1024), 0, st, keysT, c->I, order, meta);
 }
 
+// ---------------------------------------------------------------------------------------------
+// BINNED snapshot sort (r5): the WHOLE column in exact descending order (ties by
+// ascending item id, -0 == +0: the order of the stable radix sort above, bit for bit) without a radix sort.
+// An interpolated rank — a monotone function of the key read off a 1,024-bin histogram of the column's
+// [min, max] and a second 1,024-bin level over its crowded stretch — drops every key into one of BINS equi-DEPTH bins (n / BINS ~ 2.5 keys each);
+// a one-pass counting sort stages (orderable key, id) by bin in LDS; then, POSITION by position (a
+// wave takes 64 consecutive staged entries: its lanes read the same few words — broadcasts, no bank
+// conflicts — and find their bin's bounds from three ballots of first-of-bin flags), every key counts
+// the members of its bin that precede it; the ids move to their final places in LDS and leave in
+// whole lines.  Work per key: two LDS atomics, two LDS writes, ~bin-size LDS reads — against eight
+// (radix 4) or four (radix 8) ranked LDS exchanges of the 32-bit radix sort.  A column the scheme does
+// not fit (a bin over BIN_MAX keys: a spike narrower than a coarse bin, thousands of equal keys; no
+// spread at all) reports meta[2f] = -1 and is sorted whole by k_sort_flagged behind this kernel.
+// One 1024-thread workgroup per column, I <= 1024 * ITEMS <= 32,768 (the id shares 16 bits with the
+// first-of-bin flag); LDS = 6 B per key + 4 B per bin.
+// ---------------------------------------------------------------------------------------------
+constexpr int BIN_MAX = 64;  // (the ballots below look one 64-entry window back and one ahead)
+constexpr int BIN_CROWD = 32;
+constexpr uint32_t BIN_FIRST = 0x8000u;
+
+__device__ __forceinline__ uint32_t orderable_desc(float v) {  // larger float <=> larger uint; -0 == +0, as a
+  uint32_t b = __float_as_uint(v);                             // comparison and rocPRIM's radix digits have it
+  if (b == 0x80000000u) b = 0u;
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_sort_binned(const float* __restrict__ T, int64_t I,
+                                                      int32_t* __restrict__ order,
+                                                      float* __restrict__ sigma,
+                                                      int32_t* __restrict__ meta) {
+  static_assert(1024 * ITEMS <= 32768 && ITEMS >= 4, "ids share 16 bits with the first-of-bin flag");
+  constexpr int BINS = ITEMS <= 6 ? 2048 : ITEMS <= 10 ? 4096 : 8192;
+  constexpr int BPT = BINS / 1024;
+  __shared__ uint32_t s_key[1024 * ITEMS];  // orderable keys, staged by bin (before that: the coarse histogram)
+  __shared__ uint16_t s_id[1024 * ITEMS];   // their item ids | BIN_FIRST; then the ids in final order
+  __shared__ uint32_t s_hist[BINS + 1];     // keys per bin, then the bins' first positions ([BINS]: the pads' bin)
+  __shared__ uint32_t s_scan[16];
+  __shared__ double s_red[2][16];
+  __shared__ float s_mm[2][16];
+  __shared__ int32_t s_big;
+  uint32_t* const s_coarse = s_key;         // keys per coarse bin of the column
+  uint32_t* const s_cum = s_key + 1024;     // ... and before it, from the top
+  uint32_t* const s_fine = s_key + 2048;    // second level: keys per bin of the crowded stretch
+  uint32_t* const s_fcum = s_key + 3072;    // ... and before it, inside the stretch
+  __shared__ int32_t s_hull[2];             // the crowded stretch: first / last coarse bin over BIN_CROWD keys
+  const int f = blockIdx.x;
+  const float* row = T + (int64_t)f * I;
+  const int t = threadIdx.x;
+  const int n = (int)I;
+  // (array elements are assigned outside any branch: a conditional store into a register array makes the
+  // compiler carry the whole array through the branch as one vector value — 5,600 spilled VGPRs at ITEMS = 20)
+  float keys[ITEMS];
+  double s1 = 0.0, s2 = 0.0;
+  float vmin = __builtin_huge_valf(), vmax = -__builtin_huge_valf();
+  const float first = row[1];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int l = k * 1024 + t;  // striped: coalesced loads (the order below does not lean on the arrangement)
+    const bool valid = l < n;
+    const float v = valid ? row[l] : 0.f;
+    keys[k] = v;
+    const double c = (double)v - (double)first;
+    s1 += (valid && l >= 1) ? c : 0.0;
+    s2 += (valid && l >= 1) ? c * c : 0.0;
+    vmin = valid ? fminf(vmin, v) : vmin;
+    vmax = valid ? fmaxf(vmax, v) : vmax;
+  }
+  for (int k = t; k <= BINS; k += 1024) s_hist[k] = 0u;
+  s_coarse[t] = 0u;
+  s_fine[t] = 0u;
+  if (t == 0) {
+    s_big = 0;
+    s_hull[0] = 1024;
+    s_hull[1] = -1;
+  }
+  // sigma_f = unbiased std over rows 1..I-1 (neg_samplers.py:132), as k_sort_sub
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+    vmin = fminf(vmin, __shfl_xor(vmin, off, 64));
+    vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+  }
+  if ((t & 63) == 0) {
+    s_red[0][t >> 6] = s1;
+    s_red[1][t >> 6] = s2;
+    s_mm[0][t >> 6] = vmin;
+    s_mm[1][t >> 6] = vmax;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      a += s_red[0][w];
+      b += s_red[1][w];
+    }
+    const double nn = (double)(I - 1);
+    sigma[f] = (float)sqrt(fmax(b - a * a / nn, 0.0) / (nn - 1.0));
+  }
+  // ---- coarse histogram: 1,024 value-linear bins over the column's [min, max] — not mean +- 5 sigma: the
+  // columns of a trained table have tails out to 11 sigma, and everything past a clipped range lands in ONE bin
+  for (int w = 0; w < 16; ++w) {
+    vmin = fminf(vmin, s_mm[0][w]);
+    vmax = fmaxf(vmax, s_mm[1][w]);
+  }
+  const float cmax = vmax;
+  const float cscale = vmax > vmin ? 1024.0f / (vmax - vmin) : 0.f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k)
+    if (k * 1024 + t < n) atomicAdd(&s_coarse[min(1023, max(0, (int)((cmax - keys[k]) * cscale)))], 1u);
+  __syncthreads();
+  auto block_excl = [&](int v) {  // exclusive prefix of one value per thread over the block
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if ((t & 63) >= off) incl += u;
+    }
+    __syncthreads();
+    if ((t & 63) == 63) s_scan[t >> 6] = (uint32_t)incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += (int)s_scan[w];
+    return base + incl - v;
+  };
+  s_cum[t] = (uint32_t)block_excl((int)s_coarse[t]);  // keys above coarse bin t
+  // ---- second level.  A fine bin never holds more than the coarse bins it touches, so only CROWDED coarse bins
+  // (over BIN_CROWD keys) can overflow one — and they do when the column is a spike plus a few far outliers: the
+  // take-off of training, when popular items have grown a hundred times past the untouched rest and mean +- 5
+  // sigma puts ten thousand keys into a handful of coarse bins.  The stretch from the first to the last crowded
+  // coarse bin gets 1,024 value-linear bins of its own; a key inside it takes its rank from those.
+  {
+    const unsigned long long crowded = __ballot(s_coarse[t] > (uint32_t)BIN_CROWD);
+    if ((t & 63) == 0 && crowded != 0ull) {
+      atomicMin(&s_hull[0], (t & ~63) + __ffsll(crowded) - 1);
+      atomicMax(&s_hull[1], (t & ~63) + 63 - __clzll(crowded));
+    }
+  }
+  __syncthreads();
+  const int h_lo = s_hull[0], h_hi = s_hull[1];  // (h_lo > h_hi: no crowded bin)
+  const float ftop = cmax - (float)h_lo / cscale;  // the stretch's upper edge (any value near it does: membership
+  const float fscale = cscale * (1024.0f / (float)max(h_hi - h_lo + 1, 1));  // is decided by the COARSE bin)
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int cb = min(1023, max(0, (int)((cmax - keys[k]) * cscale)));
+    if (k * 1024 + t < n && cb >= h_lo && cb <= h_hi)
+      atomicAdd(&s_fine[min(1023, max(0, (int)((ftop - keys[k]) * fscale)))], 1u);
+  }
+  __syncthreads();
+  s_fcum[t] = (uint32_t)block_excl((int)s_fine[t]);
+  __syncthreads();
+  const float hull_above = h_lo <= h_hi ? (float)s_cum[h_lo] : 0.f;  // keys above the stretch
+  // ---- a key's bin from its interpolated rank r = (keys above its coarse bin) + (its place inside the bin) x
+  // (keys in the bin): monotone in the key, equal keys equal r — bins agree with the order whatever the rounding
+  const float bscale = (float)BINS / (float)n;
+  uint32_t packed[ITEMS];  // bin << 8 | ordinal inside the bin
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const float x = (cmax - keys[k]) * cscale;
+    const int cb = min(1023, max(0, (int)x));
+    const bool inside = cb >= h_lo && cb <= h_hi;
+    const float x2 = (ftop - keys[k]) * fscale;
+    const int fb = min(1023, max(0, (int)x2));
+    const float frac = fminf(fmaxf(inside ? x2 - (float)fb : x - (float)cb, 0.f), 0.999f);
+    const float r = inside ? hull_above + ((float)s_fcum[fb] + frac * (float)s_fine[fb])
+                           : (float)s_cum[cb] + frac * (float)s_coarse[cb];
+    const int bin = k * 1024 + t < n ? min(BINS - 1, max(0, (int)(r * bscale))) : BINS;
+    const uint32_t ord = atomicAdd(&s_hist[bin], 1u);
+    packed[k] = ((uint32_t)bin << 8) | min(ord, 255u);
+  }
+  __syncthreads();
+  // ---- the bins' sizes -> first positions
+  {
+    uint32_t c4[BPT];
+    int mine = 0, biggest = 0;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      c4[q] = s_hist[t * BPT + q];
+      mine += (int)c4[q];
+      biggest = max(biggest, (int)c4[q]);
+    }
+    if (biggest > BIN_MAX) atomicMax(&s_big, biggest);
+    int at = block_excl(mine);
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      s_hist[t * BPT + q] = (uint32_t)at;
+      at += (int)c4[q];
+    }
+  }
+  __syncthreads();  // (the coarse histogram is dead from here: the staged keys take its place)
+  if (s_big != 0 || cscale <= 0.f) {  // (uniform over the block) sorted whole by k_sort_flagged
+    if (t == 0) {
+      meta[2 * f] = -1;
+      meta[2 * f + 1] = -1;
+    }
+    return;
+  }
+  if (t == 0) {
+    meta[2 * f] = n;
+    meta[2 * f + 1] = 0;
+  }
+  // ---- counting sort into LDS; the first entry of a bin carries BIN_FIRST
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int l = k * 1024 + t;
+    const uint32_t ord = packed[k] & 255u;
+    const int at = (int)s_hist[packed[k] >> 8] + (int)ord;
+    if (l < n) {
+      s_key[at] = orderable_desc(keys[k]);
+      s_id[at] = (uint16_t)((uint32_t)l | (ord == 0u ? BIN_FIRST : 0u));
+    }
+  }
+  __syncthreads();
+  // ---- a key's place inside its bin, position by position: the members that precede it (larger key, or equal
+  // key and lower id).  A wave walks ITEMS consecutive 64-entry windows; the bin's bounds come from the
+  // first-of-bin flags of its window, the one before and the one after (a bin holds <= BIN_MAX = 64 entries;
+  // position n counts as flagged), each window's flags read once and handed on.
+  const int lane = t & 63;
+  uint32_t out[ITEMS];  // final position << 16 | id
+  {
+    int base = (t >> 6) * ITEMS * 64;
+    uint32_t me = base + lane < n ? (uint32_t)s_id[base + lane] : 0u;
+    const uint32_t before = base >= 64 && base + lane - 64 < n ? (uint32_t)s_id[base + lane - 64] : 0u;
+    unsigned long long bc = __ballot((me & BIN_FIRST) != 0u || base + lane == n);
+    unsigned long long bp = __ballot((before & BIN_FIRST) != 0u);
+    const unsigned long long upto = (2ull << lane) - 1ull;  // bits 0 .. lane
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int p = base + lane;
+      const bool valid = p < n;
+      const uint32_t next = p + 64 < n ? (uint32_t)s_id[p + 64] : 0u;
+      const unsigned long long bn = __ballot((next & BIN_FIRST) != 0u || p + 64 == n);
+      const unsigned long long at_or_before = bc & upto, after = bc & ~upto;
+      int lo = at_or_before ? base + 63 - __clzll(at_or_before) : base - 1 - __clzll(bp);
+      int hi = after ? base + __ffsll(after) - 1 : bn ? base + 63 + __ffsll(bn) : n;
+      if (!valid) lo = hi = 0;
+      const uint32_t u = valid ? s_key[p] : 0u;
+      const int id = (int)(me & (BIN_FIRST - 1u));
+      int rank = 0;
+      for (int j = lo; j < hi; j += 4) {  // four members in flight
+        const int j1 = min(j + 1, hi - 1), j2 = min(j + 2, hi - 1), j3 = min(j + 3, hi - 1);
+        const uint32_t o0 = s_key[j], o1 = s_key[j1], o2 = s_key[j2], o3 = s_key[j3];
+        const bool v1 = j + 1 < hi, v2 = j + 2 < hi, v3 = j + 3 < hi;
+        rank += (o0 > u ? 1 : 0) + (v1 && o1 > u ? 1 : 0) + (v2 && o2 > u ? 1 : 0) + (v3 && o3 > u ? 1 : 0);
+        const bool t0 = o0 == u && j != p, t1 = v1 && o1 == u && j1 != p, t2 = v2 && o2 == u && j2 != p,
+                   t3 = v3 && o3 == u && j3 != p;
+        if (t0 || t1 || t2 || t3) {  // equal keys (rare): the lower id goes first
+          rank += (t0 && (int)((uint32_t)s_id[j] & (BIN_FIRST - 1u)) < id ? 1 : 0) +
+                  (t1 && (int)((uint32_t)s_id[j1] & (BIN_FIRST - 1u)) < id ? 1 : 0) +
+                  (t2 && (int)((uint32_t)s_id[j2] & (BIN_FIRST - 1u)) < id ? 1 : 0) +
+                  (t3 && (int)((uint32_t)s_id[j3] & (BIN_FIRST - 1u)) < id ? 1 : 0);
+        }
+      }
+      out[k] = ((uint32_t)(lo + rank) << 16) | (uint32_t)id;
+      bp = bc;
+      bc = bn;
+      me = next;
+      base += 64;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k)
+    if (((t >> 6) * ITEMS + k) * 64 + lane < n) s_id[out[k] >> 16] = (uint16_t)(out[k] & 0xffffu);
+  __syncthreads();
+  int32_t* col = order + (int64_t)f * I;
+  for (int k = t; k < n; k += 1024) col[k] = (int32_t)s_id[k];  // whole lines
+}
+
+template <int ITEMS>
+static void launch_sort_binned(bpr_ctx* c, hipStream_t st, int nf, const float* keysT, int32_t* order, float* sigma,
+                               int32_t* meta) {
+  hipLaunchKernelGGL((k_sort_binned<ITEMS>), dim3(nf), dim3(1024), 0, st, keysT, c->I, order, sigma, meta);
+  hipLaunchKernelGGL((k_sort_flagged<ITEMS>), dim3(nf), dim3(1024), 0, st, keysT, c->I, order, meta);
+}
+
 // composite sort key: (factor << 32) | ~orderable(value)  → ascending sort = per-factor descending
 __global__ void k_compose_keys(const float* __restrict__ T, uint64_t* __restrict__ keys, int64_t n,
                                int64_t I) {
@@ -1452,6 +1729,11 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
   if (!split)
     while (sub < 4 && nf * sub < 256 && I / (2 * sub) >= 5000) sub *= 2;
   if (force_sub == 1 || force_sub == 2 || force_sub == 4) sub = force_sub;
+  // BINNED sort (r5): a column of <= 20,480 keys is ordered exactly by one workgroup in about a third of the radix
+  // sort's time (k_sort_binned) — whole columns then beat split-and-merge on the idle chip too
+  const bool binned = c->tune_binned != 0 && !no_fast && force_sub == 0 && I <= 1024 * 20 && I >= 2048 &&
+                      !(split && !part && c->tune_partial != 0);
+  if (binned) sub = 1;
   int64_t len = (I + sub - 1) / sub;
   len = (len + 15) / 16 * 16;
   // PARTIAL order (r5): the split refresh of a column that one workgroup holds — the exact ends + a
@@ -1471,6 +1753,14 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
     else if (items <= 16) launch_sort_partial<16>(c, st, keysT, order, sigma, meta, target);
     else if (items <= 20) launch_sort_partial<20>(c, st, keysT, order, sigma, meta, target);
     else launch_sort_partial<24>(c, st, keysT, order, sigma, meta, target);
+    BPR_HIP_CHECK(hipGetLastError());
+  } else if (binned) {
+    const int items = (int)((len + 1023) / 1024);
+    int32_t* meta = c->snap_meta[back] + 2 * f_lo;
+    if (items <= 6) launch_sort_binned<6>(c, st, nf, keysT, order, sigma, meta);
+    else if (items <= 10) launch_sort_binned<10>(c, st, nf, keysT, order, sigma, meta);
+    else if (items <= 16) launch_sort_binned<16>(c, st, nf, keysT, order, sigma, meta);
+    else launch_sort_binned<20>(c, st, nf, keysT, order, sigma, meta);
     BPR_HIP_CHECK(hipGetLastError());
   } else
   if (len <= 1024 * 36 && !no_fast) {

@@ -83,7 +83,8 @@ def strict_epoch(model, optimizer, sampler, users, items, seen_pad, batch_size, 
               default="sgd", show_default=True, help="batched / strict modes (stream is plain SGD)")
 @click.option("--refresh-lag", type=float, default=0.0, show_default=True,
               help="stream mode: 1 = the adaptive snapshot is sorted beside the previous launch "
-                   "(StreamTrainer refresh_lag); 0 = the reference's schedule")
+                   "(StreamTrainer refresh_lag); 0 = the reference's schedule; -1 = by shape and learning rate "
+                   "(fast.auto_schedule: lag 1 only inside the staleness budget lr x 2 x launch <= 4,000)")
 @click.option("--refresh-cus", type=int, default=64, show_default=True,
               help="stream mode with --refresh-lag > 0: CUs the snapshot sort is masked to")
 def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batch_size, epochs,
@@ -160,7 +161,8 @@ def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batc
         trainer = StreamTrainer(model, users_t, items_t, t["indptr"], t["indices"], lr=lr,
                                 sampler="adaptive", adaptive_p=sampling_prob,
                                 batch_size=batch_size, seed=seed, rank=rank, item_sync=sync,
-                                refresh_lag=refresh_lag, refresh_cus=refresh_cus if refresh_lag > 0 else 0)
+                                refresh_lag="auto" if refresh_lag < 0 else refresh_lag,
+                                refresh_cus=refresh_cus if refresh_lag > 0 else 0)
         run_epoch = trainer.train_epoch
     elif world > 1:  # reference mini-batches per user shard, item table reconciled by ItemSync
         from revisit_bpr.distributed import ItemSync, balanced_user_shards, owner_of

@@ -227,7 +227,7 @@ class BPRExperiment:
             if plain_sgd:  # the fused SGD kernel (immediate updates)
                 stream = StreamTrainer(model, users, items, indptr.to(dev), indices.to(dev),
                                        lr=group["lr"], sampler=kind, adaptive_p=p, batch_size=batch,
-                                       seed=self._seed)
+                                       seed=self._seed, refresh_lag="auto")  # lag 1 only inside the staleness budget
             else:  # Adam / momentum / RMSprop: the batched STREAM kernel (virtual mini-batches)
                 stream = BatchedStreamTrainer(model, opt, users, items, indptr.to(dev),
                                               indices.to(dev), sampler=kind, adaptive_p=p,

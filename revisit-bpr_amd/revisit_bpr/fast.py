@@ -34,13 +34,30 @@ def auto_refresh_cus(I: int, d: int, launch_triples: int, total_cus: int = 256) 
     return int(min(max(32 * round(want / 32), 64), total_cus // 2))
 
 
-def auto_schedule(I: int, d: int, launch_triples: int, total_cus: int = 256) -> tuple[float, int]:
-    """(refresh_lag, refresh_cus) for a shape, from a two-line cost model calibrated on MI355X
+def lag_within_budget(lr: float, launch_triples: int, budget: Optional[float] = None) -> bool:
+    """May the adaptive snapshot be one launch older (refresh_lag 1) at this learning rate?  A lagged launch
+    samples from a snapshot that misses up to TWO launches of updates — what a rank of a two-rank job at the
+    rank cadence sees — so it is held to the same staleness budget: lr x 2 x launch <= STALENESS_BUDGET.
+    Measured against the reference's OWN loop on the ML-20M-shaped set (tests/golden/
+    e2e_ml20m_reference_prefix.json, profiles/r05_fullepoch_reference.md): at lr 0.05 (2 x 199,168 x 0.05 =
+    19,917) the lagged schedule leads the reference by +0.003 nDCG@100 on the way up and trails it by 0.0065 at
+    the end of the first epoch — the steepest part of the curve — before both meet again (+0.002 from the
+    second epoch on); at lr 0.01 (3,983) and at the reference configs' 0.001 it stays with the exact
+    mini-batches throughout."""
+    return lr * 2.0 * launch_triples <= (STALENESS_BUDGET if budget is None else budget)
+
+
+def auto_schedule(I: int, d: int, launch_triples: int, total_cus: int = 256,
+                  lr: Optional[float] = None) -> tuple[float, int]:
+    """(refresh_lag, refresh_cus) for a shape (and, r5, a learning rate: `lag_within_budget` — outside
+    the staleness budget the answer is the reference's schedule), from a two-line cost model calibrated on MI355X
     (profiles/shapes_r03.txt, shapes_r04.txt): the reference's schedule costs launch + sort on the
     whole chip; the overlapped one max(launch on the CUs it keeps, sort on the CUs it gets) — a sort
     that is only partly hidden still pays, a side stream that is too small does not (MSD d=256 with
     the sort on 64 CUs: 387 M triples/s against 393 M at lag 0; on 96 CUs the sort fits).  Returns
     lag 0 when no CU split beats the serial schedule."""
+    if lr is not None and not lag_within_budget(lr, launch_triples):
+        return 0.0, 0
     per_triple = 0.72e-6 if d <= 32 else 0.8e-6 if d <= 64 else 1.1e-6 if d <= 128 else \
         1.8e-6 if d <= 256 else 3.5e-6 * d / 512
     launch_ms = max(launch_triples, 1) * per_triple
@@ -90,7 +107,7 @@ class StreamTrainer:
                  adaptive_p: float = 0.01, batch_size: int = 256, seed: int = 13,
                  max_inflight: Optional[int] = None, run_len: int = 0, rank: int = 0,
                  item_sync=None, sync_every: int = 1, world: Optional[int] = None,
-                 refresh_lag: float = 0.0, refresh_split: int = 1, refresh_cus: int = 0,
+                 refresh_lag: float | str = 0.0, refresh_split: int = 1, refresh_cus: int = 0,
                  shard_refresh: bool = False, cadence: str = "job", hot_split: int = 1,
                  rounds: Optional[int] = None, jit_plan: bool = False, async_cut: bool = False) -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
@@ -100,7 +117,10 @@ class StreamTrainer:
         Snapshot schedule of the adaptive sampler (extensions; the defaults are the reference's
         ``update_stats`` every period, neg_samplers.py:122-132):
           refresh_split k   the period is cut into k launches and the snapshot retaken before each;
-          refresh_lag       0: the snapshot is sorted between launches (the launch waits for it).
+          refresh_lag       "auto": 1 with the sort on masked CUs when the shape gains from it AND the learning
+                            rate keeps the older snapshot inside the staleness budget (`auto_schedule`,
+                            `lag_within_budget`), else 0.
+                            0: the snapshot is sorted between launches (the launch waits for it).
                             1: the snapshot a launch reads was cut BEFORE the previous launch and
                                sorted beside it (`adaptive_refresh_begin` / `_commit`): its age runs
                                from one to two launches instead of zero to one, nothing waits.
@@ -135,7 +155,10 @@ class StreamTrainer:
         launch stream runs launch after launch.  The hot rows are folded at the end of the epoch."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
             raise ValueError("users / items must be int32 device tensors")
-        if not 0.0 <= refresh_lag <= 1.0 or refresh_split < 1:
+        auto_lag = isinstance(refresh_lag, str)
+        if auto_lag and refresh_lag != "auto":
+            raise ValueError("refresh_lag must be in [0, 1] or 'auto'")
+        if not auto_lag and not 0.0 <= refresh_lag <= 1.0 or refresh_split < 1:
             raise ValueError("refresh_lag must be in [0, 1], refresh_split >= 1")
         self.model = model
         self.engine = model.engine()
@@ -164,6 +187,18 @@ class StreamTrainer:
         # staleness budget: at most ~U/4 triples in flight against one parameter cut
         self.max_inflight = max(64, U // 4) if max_inflight is None else max_inflight
         self.engine.set_stream_opts(True, run_len)
+        if auto_lag:  # by shape and learning rate; one GPU (several ranks keep their cadence's schedule)
+            refresh_lag, refresh_cus = (auto_schedule(I, self.engine.d, self.chunk, lr=lr)
+                                        if item_sync is None and self.sampler == eng.NEG_ADAPTIVE else (0.0, 0))
+        elif refresh_lag >= 1.0 and self.sampler == eng.NEG_ADAPTIVE and item_sync is None and \
+                not lag_within_budget(lr, self.chunk):
+            import warnings
+
+            warnings.warn(f"refresh_lag 1 at lr {lr} with launches of {self.chunk} triples is outside the staleness "
+                          f"budget (lr x 2 x launch = {lr * 2 * self.chunk:.0f} > {STALENESS_BUDGET:.0f}): the "
+                          "first epochs leave the reference's curve by more than 0.002 nDCG@100 "
+                          "(profiles/r05_fullepoch_reference.md); refresh_lag='auto' picks by learning rate",
+                          stacklevel=2)
         self.refresh_lag = float(refresh_lag) if self.sampler == eng.NEG_ADAPTIVE else 0.0
         self.shard_refresh = bool(shard_refresh) and item_sync is not None and item_sync.world > 1
         if self.shard_refresh and self.refresh_lag != 0.0:

@@ -227,3 +227,11 @@ def test_staleness_budget_and_schedule_rules():
     assert fast.auto_schedule(41141, 256, 436_992) == (1.0, 96)
     lag, cus = fast.auto_schedule(4800, 64, 40_704)
     assert lag == 1.0 and cus == 64
+    # r5: a lagged snapshot misses up to two launches of updates and is held to the same budget —
+    # lr x 2 x launch <= 4,000 (measured against the reference's own loop: profiles/r05_fullepoch_reference.md)
+    assert fast.lag_within_budget(0.001, period) and fast.lag_within_budget(0.01, period)
+    assert not fast.lag_within_budget(0.05, period)
+    assert fast.auto_schedule(20109, 128, period, lr=0.001) == (1.0, 64)
+    assert fast.auto_schedule(20109, 128, period, lr=0.05) == (0.0, 0)
+    assert fast.auto_schedule(4800, 64, 40_704, lr=0.05)[0] == 0.0   # Netflix at lr 0.05: 4,070 > 4,000
+    assert fast.auto_schedule(4800, 64, 40_704, lr=0.04)[0] == 1.0

@@ -862,6 +862,63 @@ def test_refresh_large_item_counts(I, d, force_sub, monkeypatch):
     assert close(sigma.cpu().numpy(), sigma_o, 2e-6)
 
 
+def _binned_tables(I, d, kind, rng):
+    Q = (rng.standard_normal((I, d)) * 0.05).astype(np.float32)
+    if kind == "ties":          # a few dozen distinct values per column: bins overflow -> the radix fallback
+        Q = (np.round(Q * 400) / 400).astype(np.float32)
+    elif kind == "few-ties":    # birthday collisions and planted equal rows, +0 / -0
+        Q[5] = Q[7]
+        Q[I // 2] = Q[I // 2 + 3]
+        Q[I - 1] = Q[1]
+        Q[11] = 0.0
+        Q[13] = -0.0
+        Q[17] = 0.0
+    elif kind == "spike":       # a trained model's cold items: most keys within a hair of zero, heavy tails
+        cold = rng.random(I) < 0.7
+        Q[cold] *= 1e-3
+        Q[rng.integers(1, I, 20)] *= 40.0
+    elif kind == "narrow-spike":  # a spike narrower than one coarse bin (10 sigma / 1,024)
+        Q[: I // 3] = (1e-7 * rng.standard_normal((I // 3, d))).astype(np.float32) + np.float32(0.0123)
+    elif kind == "skewed":      # one-sided, exponential
+        Q = (rng.exponential(0.05, (I, d))).astype(np.float32)
+    elif kind == "shifted":     # a large common offset: the value-linear bins must be taken about the mean
+        Q += np.float32(3.0)
+    elif kind == "equal":
+        Q[:] = np.float32(0.25)
+    Q[0] = 0
+    return Q
+
+
+@pytest.mark.parametrize("I,d", [(20108, 128), (20480, 8), (17771, 64), (4801, 64), (2048, 16), (9999, 24)])
+@pytest.mark.parametrize("kind", ["normal", "few-ties", "ties", "spike", "narrow-spike", "skewed", "shifted", "equal"])
+def test_binned_sort_is_the_stable_descending_order(I, d, kind):
+    """k_sort_binned (r5: equi-depth bins from an interpolated rank + ranking inside the bin, no radix sort) orders
+    a column exactly as the oracle's stable descending argsort does — ties by ascending item id, -0 == +0 —
+    on bell-shaped, spiky, one-sided, shifted and heavily tied columns; columns it gives up on (a bin over 64
+    keys) come out of the radix fallback behind it; the radix path (`binned_sort` 0) agrees bit for bit."""
+    rng = np.random.default_rng(I * 7 + d + len(kind))
+    Q = _binned_tables(I, d, kind, rng)
+    P = np.zeros((4, d), np.float32)
+    QT, sigma_o = oracle.adaptive_stats(Q)
+    order_o = oracle.adaptive_order(QT)
+    got = []
+    for binned in (1, 0):
+        e = make_engine(P, Q)
+        e.set_tuning("binned_sort", binned)
+        e.adaptive_refresh()
+        order, sigma = e.adaptive_snapshot()
+        got.append((order.cpu().numpy(), sigma.cpu().numpy()))
+        assert np.array_equal(got[-1][0], order_o), (binned, kind)
+        if np.all(sigma_o > 0):
+            assert close(got[-1][1], sigma_o, 2e-6)
+    assert np.array_equal(got[0][1], got[1][1])  # sigma: the same sums in the same order
+    # the overlapped schedule sorts on the side stream: same kernel, same order
+    e = make_engine(P, Q)
+    e.adaptive_refresh_begin()
+    e.adaptive_refresh_commit()
+    assert np.array_equal(e.adaptive_snapshot()[0].cpu().numpy(), order_o)
+
+
 def test_atomics_lose_nothing_under_chip_wide_contention():
     """100k triples hammering 50 item rows from every CU / XCD at once: the accumulated gradients
     must be the exact sums (device-scope fp32 atomics resolve below the per-XCD L2s)."""
