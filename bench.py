@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 ATOMIC_LINES_PEAK = 9.5e9
 # default snapshot schedule of the adaptive sampler: the one the parity gates hold
 # (tests/test_gpu_e2e_parity.py, tests/test_gpu_fullscale_parity.py)
-SCHEDULE = {"refresh_lag": 1.0, "refresh_split": 1, "refresh_cus": -1}  # -1: fast.auto_schedule (64 CUs here)
+SCHEDULE = {"refresh_lag": 1.0, "refresh_split": 1, "refresh_cus": -1}  # -1: fast.auto_schedule (32 CUs here since the binned sort)
 # N > 1 (cadence "job": every rank's launch is 1/N of a refresh period, far shorter than the sort):
 # the snapshot is sorted between launches, every rank sorting d/N of its factors
 SCHEDULE_MULTI = {"refresh_lag": 0.0, "refresh_split": 1, "refresh_cus": 0}
@@ -491,7 +491,7 @@ def main():
     if lag > 0.0 and cus != 0:
         total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         if cus < 0:
-            # by shape (fast.auto_schedule: 64 CUs for the ML-20M workload, 96 for MSD d=256); it may
+            # by shape (fast.auto_schedule: 32 CUs for the ML-20M workload, 96 for MSD d=256); it may
             # also say that no split of the chip beats the reference's serial schedule
             from revisit_bpr.fast import auto_schedule
             a_lag, cus = auto_schedule(I, d, chunk, total_cus, lr=args.lr)  # (lr: the staleness budget of a lagged snapshot)

@@ -671,7 +671,7 @@ __global__ __launch_bounds__(1024) void k_sort_binned(const float* __restrict__ 
   static_assert(1024 * ITEMS <= 32768 && ITEMS >= 4, "ids share 16 bits with the first-of-bin flag");
   constexpr int BINS = ITEMS <= 6 ? 2048 : ITEMS <= 10 ? 4096 : 8192;
   constexpr int BPT = BINS / 1024;
-  __shared__ uint32_t s_key[1024 * ITEMS];  // orderable keys, staged by bin (before that: the coarse histogram)
+  __shared__ uint32_t s_key[1024 * ITEMS + 4];  // orderable keys, staged by bin (before that: the histograms)
   __shared__ uint16_t s_id[1024 * ITEMS];   // their item ids | BIN_FIRST; then the ids in final order
   __shared__ uint32_t s_hist[BINS + 1];     // keys per bin, then the bins' first positions ([BINS]: the pads' bin)
   __shared__ uint32_t s_scan[16];
@@ -840,6 +840,7 @@ __global__ __launch_bounds__(1024) void k_sort_binned(const float* __restrict__ 
     meta[2 * f + 1] = 0;
   }
   // ---- counting sort into LDS; the first entry of a bin carries BIN_FIRST
+  if (t < 4) s_key[n + t] = 0u;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const int l = k * 1024 + t;
@@ -876,20 +877,20 @@ __global__ __launch_bounds__(1024) void k_sort_binned(const float* __restrict__ 
       if (!valid) lo = hi = 0;
       const uint32_t u = valid ? s_key[p] : 0u;
       const int id = (int)(me & (BIN_FIRST - 1u));
-      int rank = 0;
-      for (int j = lo; j < hi; j += 4) {  // four members in flight
-        const int j1 = min(j + 1, hi - 1), j2 = min(j + 2, hi - 1), j3 = min(j + 3, hi - 1);
-        const uint32_t o0 = s_key[j], o1 = s_key[j1], o2 = s_key[j2], o3 = s_key[j3];
-        const bool v1 = j + 1 < hi, v2 = j + 2 < hi, v3 = j + 3 < hi;
-        rank += (o0 > u ? 1 : 0) + (v1 && o1 > u ? 1 : 0) + (v2 && o2 > u ? 1 : 0) + (v3 && o3 > u ? 1 : 0);
-        const bool t0 = o0 == u && j != p, t1 = v1 && o1 == u && j1 != p, t2 = v2 && o2 == u && j2 != p,
-                   t3 = v3 && o3 == u && j3 != p;
-        if (t0 || t1 || t2 || t3) {  // equal keys (rare): the lower id goes first
-          rank += (t0 && (int)((uint32_t)s_id[j] & (BIN_FIRST - 1u)) < id ? 1 : 0) +
-                  (t1 && (int)((uint32_t)s_id[j1] & (BIN_FIRST - 1u)) < id ? 1 : 0) +
-                  (t2 && (int)((uint32_t)s_id[j2] & (BIN_FIRST - 1u)) < id ? 1 : 0) +
-                  (t3 && (int)((uint32_t)s_id[j3] & (BIN_FIRST - 1u)) < id ? 1 : 0);
-        }
+      // four members in flight, no bounds tests: an entry past the bin's end belongs to a LATER bin — its key is
+      // strictly smaller (equal keys share a bin), so it counts neither as larger nor as equal; the four words
+      // past position n hold 0, the smallest orderable key
+      int rank = 0, equal = 0;
+#pragma unroll 1  // (bins hold ~2.5 keys: one or two trips — unrolled further, the remainder tests cost more than the loop)
+      for (int j = lo; j < hi; j += 4) {
+        const uint32_t o0 = s_key[j], o1 = s_key[j + 1], o2 = s_key[j + 2], o3 = s_key[j + 3];
+        rank += (o0 > u ? 1 : 0) + (o1 > u ? 1 : 0) + (o2 > u ? 1 : 0) + (o3 > u ? 1 : 0);
+        equal += (o0 == u ? 1 : 0) + (o1 == u ? 1 : 0) + (o2 == u ? 1 : 0) + (o3 == u ? 1 : 0);
+      }
+      if (equal > 1) {  // equal keys (rare; `equal` counts the key itself once): the lower id goes first
+#pragma unroll 1
+        for (int j = lo; j < hi; ++j)
+          rank += s_key[j] == u && (int)((uint32_t)s_id[j] & (BIN_FIRST - 1u)) < id ? 1 : 0;
       }
       out[k] = ((uint32_t)(lo + rank) << 16) | (uint32_t)id;
       bp = bc;

@@ -16,22 +16,30 @@ import torch
 from revisit_bpr import engine as eng
 
 
+def sort_cu_ms(I: int, d: int) -> float:
+    """CU-milliseconds of one snapshot sort (one 1,024-thread workgroup per column, measured on MI355X): the
+    binned sort of r5 (columns of 2,048 .. 20,480 keys: ~2.0 ns per key + 3 us per column — 42 us for ML-20M's
+    20,108) or the in-LDS radix sort (~5.05 ns per key, 1.3x when columns are split and merged: I > 36,864)."""
+    if 2048 <= I <= 20480:
+        return d * (2.0e-6 * I + 0.003)
+    return 5.05e-6 * I * d * (1.3 if I > 36864 else 1.0)
+
+
 def auto_refresh_cus(I: int, d: int, launch_triples: int, total_cus: int = 256) -> int:
     """CUs for the side stream of the overlapped snapshot schedule: enough that the sort of I x d
     keys finishes inside one STREAM launch, as few as possible because the launch loses them.
-    Calibrated on MI355X (profiles/shapes_r03.txt): the in-LDS column sort costs ~5.05 ns x CU per
-    key (1.3x when columns are split and merged: I > 36,864), a launch ~0.72 / 0.8 / 1.1 / 1.8 / 3.5 ns
-    per triple at d <= 32 / 64 / 128 / 256 / 512; measured optima: 64 CUs for ML-20M d=128, Yelp and
-    Netflix, 96 for MSD d=256."""
+    Calibrated on MI355X (profiles/shapes_r03.txt, r05_binned_sort.md): `sort_cu_ms`, a launch ~0.72 / 0.8 / 1.1 /
+    1.8 / 3.5 ns per triple at d <= 32 / 64 / 128 / 256 / 512; measured optima: 32 CUs for ML-20M d=128 since
+    the binned sort (64 before it), 96 for MSD d=256."""
     per_triple = 0.72e-6 if d <= 32 else 0.8e-6 if d <= 64 else 1.1e-6 if d <= 128 else \
         1.8e-6 if d <= 256 else 3.5e-6 * d / 512
     launch_ms = max(launch_triples, 1) * per_triple
-    sort_ms_cu = 5.05e-6 * I * d * (1.3 if I > 36864 else 1.0)
-    want = sort_ms_cu / (0.95 * launch_ms)
+    want = sort_cu_ms(I, d) / (0.95 * launch_ms)
     # multiples of 32 only: the driver deals the mask bits over 8 XCDs x 4 shader engines, and a
     # count that leaves the engines uneven costs the launch more than the CUs it frees (Yelp: 72 CUs
     # 570 M triples/s, 64 CUs 632 M)
-    return int(min(max(32 * round(want / 32), 64), total_cus // 2))
+    floor = 32 if 2048 <= I <= 20480 else 64
+    return int(min(max(32 * math.ceil(want / 32 - 0.25), floor), total_cus // 2))
 
 
 def lag_within_budget(lr: float, launch_triples: int, budget: Optional[float] = None) -> bool:
@@ -61,16 +69,24 @@ def auto_schedule(I: int, d: int, launch_triples: int, total_cus: int = 256,
     per_triple = 0.72e-6 if d <= 32 else 0.8e-6 if d <= 64 else 1.1e-6 if d <= 128 else \
         1.8e-6 if d <= 256 else 3.5e-6 * d / 512
     launch_ms = max(launch_triples, 1) * per_triple
-    sort_ms_cu = 5.05e-6 * I * d * (1.3 if I > 36864 else 1.0)
-    serial = launch_ms + sort_ms_cu / total_cus + 0.040  # three kernels and their boundaries
+    sort_ms_cu = sort_cu_ms(I, d)
+    binned = 2048 <= I <= 20480
+    serial = launch_ms + sort_ms_cu / (min(total_cus, d) if binned else total_cus) + 0.040  # three kernels and their boundaries
     best = (serial, 0.0, 0)
-    for cus in (64, 96, 128):
-        if cus > total_cus // 2:
-            break
-        # the launch on the remaining CUs: +6 % per 64 CUs while the atomic units bound it
-        # (d <= 128), more once HBM does (d >= 256: measured +3 % .. +5 % at 64)
-        stretch = 1.0 + (0.06 if d <= 128 else 0.05) * cus / 64 * (1.0 if d <= 128 else 1.5)
-        step = max(launch_ms * stretch, 0.9 * sort_ms_cu / cus) + 0.026  # cut + the launch-to-launch gap
+    for cus in (32, 64, 96, 128):
+        if cus > total_cus // 2 or (cus == 32 and not binned):
+            continue
+        if binned:
+            # 224 CUs run the launch as fast as 256 (profiles/r05_sort_upper_bound.md), +6 % per 64 CUs below;
+            # one workgroup per column and CU: the sort takes whole rounds, 10 % slower beside a launch
+            stretch = 1.0 + 0.06 * (cus - 32) / 64
+            sort_ms = 1.1 * math.ceil(d / cus) * sort_ms_cu / d
+        else:
+            # the launch on the remaining CUs: +6 % per 64 CUs while the atomic units bound it
+            # (d <= 128), more once HBM does (d >= 256: measured +3 % .. +5 % at 64)
+            stretch = 1.0 + (0.06 if d <= 128 else 0.05) * cus / 64 * (1.0 if d <= 128 else 1.5)
+            sort_ms = 0.9 * sort_ms_cu / cus
+        step = max(launch_ms * stretch, sort_ms) + 0.026  # cut + the launch-to-launch gap
         if step < best[0]:
             best = (step, 1.0, cus)
     return best[1], best[2]

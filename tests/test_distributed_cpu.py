@@ -211,7 +211,7 @@ def test_staleness_budget_and_schedule_rules():
     """fast.launches_per_period: lr x world x chunk <= STALENESS_BUDGET — a full
     period per rank at the benchmark config's lr 0.001 for up to 8 ranks, 1 / 2 / 4 chunks at the
     reference's tuned lr 0.0094, period / 2.5 N at lr 0.05 (capped at 4 N); fast.auto_schedule: the
-    overlapped snapshot schedule on 64 CUs for the ML-20M shape, on 96 for MSD d = 256."""
+    overlapped snapshot schedule on 32 CUs for the ML-20M shape (binned sort), on 96 for MSD d = 256."""
     from revisit_bpr import fast
 
     period = 199_168
@@ -223,15 +223,15 @@ def test_staleness_budget_and_schedule_rules():
         for w in (2, 4, 8):
             k = fast.launches_per_period(lr, w, period)
             assert k == 4 * w or lr * w * (period / k) <= fast.STALENESS_BUDGET
-    assert fast.auto_schedule(20109, 128, period) == (1.0, 64)
+    assert fast.auto_schedule(20109, 128, period) == (1.0, 32)  # (64 until the binned sort of r5)
     assert fast.auto_schedule(41141, 256, 436_992) == (1.0, 96)
     lag, cus = fast.auto_schedule(4800, 64, 40_704)
-    assert lag == 1.0 and cus == 64
+    assert lag == 1.0 and cus == 32
     # r5: a lagged snapshot misses up to two launches of updates and is held to the same budget —
     # lr x 2 x launch <= 4,000 (measured against the reference's own loop: profiles/r05_fullepoch_reference.md)
     assert fast.lag_within_budget(0.001, period) and fast.lag_within_budget(0.01, period)
     assert not fast.lag_within_budget(0.05, period)
-    assert fast.auto_schedule(20109, 128, period, lr=0.001) == (1.0, 64)
+    assert fast.auto_schedule(20109, 128, period, lr=0.001) == (1.0, 32)
     assert fast.auto_schedule(20109, 128, period, lr=0.05) == (0.0, 0)
     assert fast.auto_schedule(4800, 64, 40_704, lr=0.05)[0] == 0.0   # Netflix at lr 0.05: 4,070 > 4,000
     assert fast.auto_schedule(4800, 64, 40_704, lr=0.04)[0] == 1.0

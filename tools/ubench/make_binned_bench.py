@@ -14,9 +14,10 @@ def variant(name, text):
     return "namespace " + name + " {\n" + text + "\n}\n"
 
 
-no_rank = body.replace("      for (int j = lo; j < hi; j += 4) {", "      for (int j = lo; j < lo; j += 4) {")
+no_rank = body.replace("      for (int j = lo; j < hi; j += 4) {", "      for (int j = lo; j < lo; j += 4) {", 1)
 no_scatter = no_rank.replace("    if (l < n) {\n      s_key[at] = orderable_desc(keys[k]);", "    if (l < n && at < 0) {\n      s_key[at] = orderable_desc(keys[k]);")
 assert no_rank != body and no_scatter != no_rank
+onetrip = body.replace("      for (int j = lo; j < hi; j += 4) {", "      for (int j = lo; j < min(hi, lo + 1); j += 4) {", 1)
 r1 = body.replace("  // ---- coarse histogram: 1,024 value-linear bins", "  return;\n  // ---- coarse histogram: 1,024 value-linear bins")
 r2 = body.replace("  // ---- a key's bin from its interpolated rank", "  return;\n  // ---- a key's bin from its interpolated rank")
 r3 = body.replace("  // ---- the bins' sizes -> first positions", "  return;\n  // ---- the bins' sizes -> first positions")
@@ -28,7 +29,7 @@ harness = r'''
 #include <cstdio>
 #include <vector>
 #include <random>
-''' + variant("full", body) + variant("norank", no_rank) + variant("noscatter", no_scatter) + variant("r1", r1) + variant("r2", r2) + variant("r3", r3) + variant("r4", r4) + r'''
+''' + variant("full", body) + variant("norank", no_rank) + variant("noscatter", no_scatter) + variant("onetrip", onetrip) + variant("r1", r1) + variant("r2", r2) + variant("r3", r3) + variant("r4", r4) + r'''
 template <typename K> float run(K k, const float* T, int64_t I, int d, int32_t* order, float* sigma, int32_t* meta) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(d), dim3(1024), 0, 0, T, I, order, sigma, meta);
@@ -48,6 +49,7 @@ int main() {
   printf("  full                       %.1f us\n", run(full::k_sort_binned<20>, T, I, d, order, sigma, meta));
   printf("  no rank loop               %.1f us\n", run(norank::k_sort_binned<20>, T, I, d, order, sigma, meta));
   printf("  ... and no scatter         %.1f us\n", run(noscatter::k_sort_binned<20>, T, I, d, order, sigma, meta));
+  printf("  rank loop capped at one trip %.1f us\n", run(onetrip::k_sort_binned<20>, T, I, d, order, sigma, meta));
   printf("  stops after sigma          %.1f us\n", run(r1::k_sort_binned<20>, T, I, d, order, sigma, meta));
   printf("  ... after the coarse histogram + scan %.1f us\n", run(r2::k_sort_binned<20>, T, I, d, order, sigma, meta));
   printf("  ... after the classification %.1f us\n", run(r3::k_sort_binned<20>, T, I, d, order, sigma, meta));
