@@ -152,7 +152,8 @@ class Engine:
         return bool(v.value)
 
     def set_tuning(self, key: str, value: int) -> None:
-        """``bpr_set_tuning``: "seen" 0 auto | 1 csr | 2 bitmap | 3 list; "vs_direct" -1 auto | 0 | 1."""
+        """``bpr_set_tuning``: "seen" 0 auto | 1 csr | 2 bitmap | 3 list; "vs_direct" -1 auto | 0 | 1;
+        "refresh_sub" 0 | 1 | 2 | 4; "partial_snapshot" 0 | 1; "partial_target" 1..1024; "binned_sort" 1 | 0."""
         native.check(self._lib.bpr_set_tuning(self._ctx, key.encode(), int(value)))
 
     # ---- plumbing ---------------------------------------------------------------------------

@@ -33,7 +33,7 @@ def test_bench_single_gpu_line():
     assert j["roofline_atomic"]["line_atomics_per_triple"] >= 8.0
     assert j["cpu_baseline"]["cores"] >= 1 and j["cpu_baseline"]["value"] > 0
     sched = j["config"]["refresh_schedule"]
-    assert sched["lag"] == 1.0 and sched["side_stream_cus"] >= 64  # the schedule the gates hold
+    assert sched["lag"] == 1.0 and sched["side_stream_cus"] >= 32  # the schedule the gates hold (32 CUs since the binned sort)
     sus = j["sustained"]  # whole epochs, every plan in place
     st = j["steady_state"]  # one epoch timed after 30 epochs of the same job: the trained state
     spe = j["config"]["steps_per_epoch"]
