@@ -2,7 +2,8 @@
 """Triples/s THROUGH experiments/trainer.py (events, eval engine and all) on a config in the reference's schema:
 the per-batch API loop (`--train-mode api`: DataLoader -> sampler -> model(batch) -> backward -> optimizer.step)
 against what an unchanged command line gets since r5 (`auto`: whole epochs inside the library when nothing observes
-single iterations).  Netflix-shaped synthetic set, d = 64, B = 256, SGD / Adam, 3 epochs each."""
+single iterations).  Netflix-shaped synthetic set, d = 64, B = 256, SGD / Adam, 3 epochs each.
+    python tools/bench_trainer_path.py [ml-20m 128]     another shape: the library modes only (auto, stream), SGD"""
 import sys, tempfile, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -13,12 +14,14 @@ from experiments import run as run_mod
 from revisit_bpr.datasets import interactions, synthetic
 
 CONFIG = ROOT / "tests" / "configs" / "bpr_small.yaml.j2"
-data = synthetic.generate_named("netflix", eval_users=20, seed=3)
+NAME = sys.argv[1] if len(sys.argv) > 1 else "netflix"
+DIM = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+data = synthetic.generate_named(NAME, eval_users=20, seed=3)
 with tempfile.TemporaryDirectory() as tmp:
     interactions.write_dataset(data, Path(tmp) / "data")
     def run(variant, mode, epochs):
         extra = (f"dataset={tmp}/data;num_users={data.num_users - 1};num_items={data.num_items - 1};"
-                 f"embedding_dim=64;train_batch_size=256;epochs={epochs};adaptive=1;item_bias=false")
+                 f"embedding_dim={DIM};train_batch_size=256;epochs={epochs};adaptive=1;item_bias=false")
         if variant == "adam":
             extra += ";optimizer=torch.optim.Adam;lr=0.001"
         torch.cuda.synchronize()
@@ -28,11 +31,11 @@ with tempfile.TemporaryDirectory() as tmp:
         torch.cuda.synchronize()
         return time.perf_counter() - t0, res.return_value
 
-    for variant in ("sgd", "adam"):
-        for mode in ("api", "auto", "stream"):
+    for variant in (("sgd", "adam") if NAME == "netflix" else ("sgd",)):
+        for mode in (("api", "auto", "stream") if NAME == "netflix" else ("auto", "stream")):
             run(variant, mode, 1)  # warm (library load, first-launch setup)
             t1, _ = run(variant, mode, 1)
-            e_hi = 3 if mode == "api" else 9
+            e_hi = 3 if mode == "api" or NAME != "netflix" else 9
             t2, exp = run(variant, mode, e_hi)
             per_epoch = (t2 - t1) / (e_hi - 1)  # one training epoch + one evaluation of 20 users
             evals = [r for r in exp.history if r["engine"] == "eval"]
