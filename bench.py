@@ -196,6 +196,12 @@ def parse_args():
                          "chunk is planned by bpr_plan_chunk on the side stream, one step ahead (measured SLOWER: "
                          "624 M vs 748 M triples/s, profiles/r04_jit_plan.md); 0 (default): bpr_plan_epoch at "
                          "every epoch boundary")
+    ap.add_argument("--plan-ahead", type=int, default=0,
+                    help="1: with the snapshot sort on masked CUs, the NEXT epoch's bpr_plan_epoch runs on a third stream "
+                         "masked to the sorter's CUs while this epoch trains (same plan, other buffers).  Measured and "
+                         "lost (profiles/r05b_plan_ahead.txt: 711 against 799 M triples/s — the plan's radix sort holds the "
+                         "sorter's CUs for milliseconds and the snapshot sort becomes the critical path); 0 (default): "
+                         "between the epochs on the launch stream")
     ap.add_argument("--async-cut", type=int, default=0,
                     help="1: the cut of the next snapshot runs on the side stream beside the next launch "
                          "(bpr_train_stream_acut) instead of between two launches")
@@ -536,13 +542,20 @@ def main():
     cbuf = [(torch.empty(chunk, dtype=torch.int32, device=dev), torch.empty(chunk, dtype=torch.int32, device=dev))
             for _ in range(2)] if jit else None
     planned = set()
+    # --plan-ahead: epoch e + 1 is planned beside epoch e, on the sorter's CUs (fast.StreamTrainer does the same)
+    plan_ahead = bool(args.plan_ahead) and side_stream is not None and not jit and not batched
+    ebuf = [(users_e, items_e)]
+    cur, pre, plan_stream = [0], {}, None
+    if plan_ahead:
+        ebuf.append((torch.empty_like(src_users), torch.empty_like(src_items)))
+        plan_stream = eng.MaskedStream(dev, eng.cu_mask(0, cus, total_cus))
 
     def plan_chunk(kk: int, on_side: bool):
         e.plan_chunk(src_users, src_items, chunk, seed + kk // n_chunks, kk % n_chunks, out=cbuf[kk & 1],
                      on_side=on_side)
 
     def launch(k: int, lo: int, hi: int, base: int, cut: bool = False):
-        users, items = (cbuf[k & 1][0], cbuf[k & 1][1]) if jit else (users_e, items_e)
+        users, items = (cbuf[k & 1][0], cbuf[k & 1][1]) if jit else ebuf[cur[0]]
         if jit:  # a chunk buffer: positions relative to the chunk
             lo, hi, base = lo - base, hi - base, 0
         if batched:
@@ -575,7 +588,24 @@ def main():
             if batched:
                 e.shuffle_epoch(src_users, src_items, seed + k // n_chunks, out=(users_e, items_e))
             else:
-                e.plan_epoch(src_users, src_items, chunk, seed + k // n_chunks, out=(users_e, items_e))
+                ep = k // n_chunks
+                if ep in pre:  # planned beside the previous epoch
+                    cur[0], ev = pre.pop(ep)
+                    torch.cuda.current_stream().wait_event(ev)
+                else:
+                    e.plan_epoch(src_users, src_items, chunk, seed + ep, out=ebuf[cur[0]])
+                if plan_ahead:
+                    nxt = cur[0] ^ 1
+                    ev0 = torch.cuda.Event()
+                    ev0.record()  # the launches that read that buffer last (the previous epoch's) are all queued
+                    with torch.cuda.stream(plan_stream.torch):
+                        plan_stream.torch.wait_event(ev0)
+                        e.plan_epoch(src_users, src_items, chunk, seed + ep + 1, out=ebuf[nxt])
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    e._sync_stream()  # the library back on this stream
+                    pre.clear()
+                    pre[ep + 1] = (nxt, ev)
         if sampler != eng.NEG_ADAPTIVE:
             launch(k, lo, lo + chunk, lo)
         elif lag == 0.0:
@@ -802,7 +832,9 @@ def main():
                             ) if (world > 1 or emu) else "single GPU",
                 "steps_per_epoch": n_chunks,
                 "plan_epoch": {"mode": ("per chunk, one step ahead, on the side stream behind the sort "
-                                        "(bpr_plan_chunk): inside every step") if jit else "bpr_plan_epoch per epoch",
+                                        "(bpr_plan_chunk): inside every step") if jit else
+                                       ("bpr_plan_epoch per epoch, the next epoch's beside this epoch's launches on a "
+                                        "third stream masked to the sorter's CUs") if plan_ahead else "bpr_plan_epoch per epoch",
                                "ms": plan_ms, "inside_timed_region": plans_timed,
                                "amortised_share_added_ms_per_step":
                                    max(0.0, args.steps / n_chunks - plans_timed) * plan_ms / args.steps,
