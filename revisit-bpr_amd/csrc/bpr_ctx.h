@@ -80,6 +80,7 @@ struct bpr_ctx {
   // walk's in-bin finish reads it: it outlives the snapshot, see refresh_impl); *_front = the pair the
   // samplers read (meta_front NULL = sorted whole)
   int tune_binned = 1;        // 1: columns of 2,048 .. 20,480 keys are ordered by k_sort_binned (0: the radix sort)
+  int tune_binned_split = 0;  // 0: workgroups per column of the binned sort by shape; 1..4: forced (tests)
   int tune_partial = 0;       // 1: the split refresh sorts partially when the shape allows
   int partial_target = 640;   // keys aimed at per exact end (at most 1,024 fit: k_sort_partial's PART_CAP)
   int32_t* snap_meta[2] = {nullptr, nullptr};

@@ -96,13 +96,15 @@ __global__ __launch_bounds__(1024) void k_sort_sub(const float* __restrict__ T, 
                                                    float* __restrict__ keys_out,
                                                    int32_t* __restrict__ ids_out,
                                                    float* __restrict__ sigma,
-                                                   double* __restrict__ sig_acc) {
+                                                   double* __restrict__ sig_acc,
+                                                   const int32_t* __restrict__ only_flagged = nullptr) {
   using Sort = rocprim::block_radix_sort<float, 1024, ITEMS, uint16_t, 1, 1, BPR_SORT_RADIX_BITS>;
   __shared__ union {
     typename Sort::storage_type sort;
     double red[2][16];
   } sm;
   const int f = blockIdx.y;
+  if (only_flagged != nullptr && only_flagged[2 * f] >= 0) return;  // (the fallback of k_sort_binned_split)
   const int64_t base = (int64_t)blockIdx.x * len;
   const int64_t cnt = min(len, I - base);
   const bool single = gridDim.x == 1;
@@ -199,12 +201,14 @@ __device__ __forceinline__ int64_t merge_split(int64_t k, int64_t lenA, int64_t 
 __global__ __launch_bounds__(MERGE_THREADS) void k_merge_runs(
     const float* __restrict__ keys_in, const int32_t* __restrict__ ids_in, int64_t I, int64_t run,
     int tiles_per_pair, float* __restrict__ keys_out, int32_t* __restrict__ ids_out, int last,
-    float* __restrict__ sigma, const double* __restrict__ sig_acc) {
+    float* __restrict__ sigma, const double* __restrict__ sig_acc,
+    const int32_t* __restrict__ only_flagged = nullptr) {
   __shared__ float lk[MERGE_TILE + MERGE_THREADS + 1];
   __shared__ int32_t lv[MERGE_TILE + MERGE_THREADS + 1];
   __shared__ int64_t cut[2];
   const int f = blockIdx.y;
   const int t = threadIdx.x;
+  if (only_flagged != nullptr && only_flagged[2 * f] >= 0) return;
   if (last && blockIdx.x == 0 && t == 0) {
     const double a = sig_acc[2 * f], b = sig_acc[2 * f + 1], n = (double)(I - 1);
     sigma[f] = (float)sqrt(fmax(b - a * a / n, 0.0) / (n - 1.0));
@@ -300,9 +304,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_runs(
 template <int ITEMS>
 static void launch_sort_sub(bpr_ctx* c, hipStream_t st, int nf, const float* keysT, double* sig_acc,
                             int32_t* order, float* sigma, int sub, int64_t len, float* keysA,
-                            int32_t* idsA) {
+                            int32_t* idsA, const int32_t* only_flagged = nullptr) {
   hipLaunchKernelGGL((k_sort_sub<ITEMS>), dim3(sub, nf), dim3(1024), 0, st, keysT, c->I, len,
-                     order, keysA, idsA, sigma, sig_acc);
+                     order, keysA, idsA, sigma, sig_acc, only_flagged);
 }
 
 
@@ -906,6 +910,264 @@ __global__ __launch_bounds__(1024) void k_sort_binned(const float* __restrict__ 
   __syncthreads();
   int32_t* col = order + (int64_t)f * I;
   for (int k = t; k < n; k += 1024) col[k] = (int32_t)s_id[k];  // whole lines
+}
+
+// ---------------------------------------------------------------------------------------------
+// The binned sort with G workgroups per column: workgroup g orders the g-th stretch of RANKS.  For columns
+// that do not fit one workgroup's LDS (20,480 < I <= 65,535: MSD's 41,141).  Every workgroup reads the whole column
+// (L2-resident) and builds the same two-level histogram; nothing is kept in registers between passes — a
+// count pass and a fill pass over the keys replace the remembered ordinals — and only the keys whose bin falls
+// into its stretch are staged: about I / G, at most 1,024 x SITEMS.  The first-of-bin flags live in a bit
+// array (past 32,767 items the ids need all 16 bits): a 64-entry window's flags are one 64-bit word.  Its part
+// of the order starts at (keys above its stretch).  A workgroup that cannot (a bin over BIN_MAX keys, a
+// stretch over its capacity, no spread) flags the column — meta[2f] = -1, cleared to 0 before the launch — and
+// the radix path behind it redoes exactly the flagged columns.
+// ---------------------------------------------------------------------------------------------
+constexpr int SPLIT_BINS = 4096;  // bins per workgroup
+
+template <int SITEMS>
+__global__ __launch_bounds__(1024) void k_sort_binned_split(const float* __restrict__ T, int64_t I,
+                                                            int32_t* __restrict__ order,
+                                                            float* __restrict__ sigma,
+                                                            int32_t* __restrict__ meta) {
+  constexpr int CAP = 1024 * SITEMS;
+  constexpr int BPT = SPLIT_BINS / 1024;
+  __shared__ uint32_t s_key[CAP + 4];
+  __shared__ uint16_t s_id[CAP];
+  __shared__ uint32_t s_flag[CAP / 32 + 4];  // first-of-bin bits
+  __shared__ uint32_t s_hist[SPLIT_BINS];
+  __shared__ uint32_t s_coarse[1024], s_cum[1024], s_fine[1024], s_fcum[1024];
+  __shared__ uint32_t s_scan[16];
+  __shared__ double s_red[2][16];
+  __shared__ float s_mm[2][16];
+  __shared__ int32_t s_big;
+  __shared__ int32_t s_hull[2];
+  __shared__ int32_t s_tot[2];
+  const int g = blockIdx.x, G = gridDim.x;
+  const int f = blockIdx.y;
+  const float* row = T + (int64_t)f * I;
+  const int t = threadIdx.x;
+  const int n = (int)I;
+  const int items = (n + 1023) / 1024;
+  // a pass over the column: eight loads in flight, then the work on them (a load per trip would leave every
+  // trip waiting for the L2: 5 passes x 41 trips x ~0.6 us on MSD)
+  auto for_keys = [&](auto&& fn) {
+    for (int k0 = 0; k0 < items; k0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int l = (k0 + q) * 1024 + t;
+        v[q] = l < n ? row[l] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int l = (k0 + q) * 1024 + t;
+        if (l < n) fn(l, v[q]);
+      }
+    }
+  };
+  // ---- pass 1: sigma, min, max (the sums in k_sort_binned's order)
+  double s1 = 0.0, s2 = 0.0;
+  float vmin = __builtin_huge_valf(), vmax = -__builtin_huge_valf();
+  const float first = row[1];
+  for_keys([&](int l, float v) {
+    if (l >= 1) {
+      const double c = (double)v - (double)first;
+      s1 += c;
+      s2 += c * c;
+    }
+    vmin = fminf(vmin, v);
+    vmax = fmaxf(vmax, v);
+  });
+  for (int k = t; k < SPLIT_BINS; k += 1024) s_hist[k] = 0u;
+  for (int k = t; k < CAP / 32 + 4; k += 1024) s_flag[k] = 0u;
+  s_coarse[t] = 0u;
+  s_fine[t] = 0u;
+  if (t == 0) {
+    s_big = 0;
+    s_hull[0] = 1024;
+    s_hull[1] = -1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+    vmin = fminf(vmin, __shfl_xor(vmin, off, 64));
+    vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+  }
+  if ((t & 63) == 0) {
+    s_red[0][t >> 6] = s1;
+    s_red[1][t >> 6] = s2;
+    s_mm[0][t >> 6] = vmin;
+    s_mm[1][t >> 6] = vmax;
+  }
+  __syncthreads();
+  if (t == 0 && g == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      a += s_red[0][w];
+      b += s_red[1][w];
+    }
+    const double nn = (double)(I - 1);
+    sigma[f] = (float)sqrt(fmax(b - a * a / nn, 0.0) / (nn - 1.0));
+  }
+  for (int w = 0; w < 16; ++w) {
+    vmin = fminf(vmin, s_mm[0][w]);
+    vmax = fmaxf(vmax, s_mm[1][w]);
+  }
+  const float cmax = vmax;
+  const float cscale = vmax > vmin ? 1024.0f / (vmax - vmin) : 0.f;
+  // ---- pass 2: the coarse histogram
+  for_keys([&](int, float v) { atomicAdd(&s_coarse[min(1023, max(0, (int)((cmax - v) * cscale)))], 1u); });
+  __syncthreads();
+  auto block_excl = [&](int v) {
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if ((t & 63) >= off) incl += u;
+    }
+    __syncthreads();
+    if ((t & 63) == 63) s_scan[t >> 6] = (uint32_t)incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += (int)s_scan[w];
+    return base + incl - v;
+  };
+  s_cum[t] = (uint32_t)block_excl((int)s_coarse[t]);
+  {
+    const unsigned long long crowded = __ballot(s_coarse[t] > (uint32_t)BIN_CROWD);
+    if ((t & 63) == 0 && crowded != 0ull) {
+      atomicMin(&s_hull[0], (t & ~63) + __ffsll(crowded) - 1);
+      atomicMax(&s_hull[1], (t & ~63) + 63 - __clzll(crowded));
+    }
+  }
+  __syncthreads();
+  const int h_lo = s_hull[0], h_hi = s_hull[1];
+  const float ftop = cmax - (float)h_lo / cscale;
+  const float fscale = cscale * (1024.0f / (float)max(h_hi - h_lo + 1, 1));
+  // ---- pass 3: the second level over the crowded stretch
+  for_keys([&](int, float v) {
+    const int cb = min(1023, max(0, (int)((cmax - v) * cscale)));
+    if (cb >= h_lo && cb <= h_hi) atomicAdd(&s_fine[min(1023, max(0, (int)((ftop - v) * fscale)))], 1u);
+  });
+  __syncthreads();
+  s_fcum[t] = (uint32_t)block_excl((int)s_fine[t]);
+  __syncthreads();
+  const float hull_above = h_lo <= h_hi ? (float)s_cum[h_lo] : 0.f;
+  const int all_bins = G * SPLIT_BINS;
+  const float bscale = (float)all_bins / (float)n;
+  const int my_lo = g * SPLIT_BINS;
+  auto bin_of = [&](float v) {  // the key's bin among all G x SPLIT_BINS: k_sort_binned's arithmetic
+    const float x = (cmax - v) * cscale;
+    const int cb = min(1023, max(0, (int)x));
+    const bool inside = cb >= h_lo && cb <= h_hi;
+    const float x2 = (ftop - v) * fscale;
+    const int fb = min(1023, max(0, (int)x2));
+    const float frac = fminf(fmaxf(inside ? x2 - (float)fb : x - (float)cb, 0.f), 0.999f);
+    const float r = inside ? hull_above + ((float)s_fcum[fb] + frac * (float)s_fine[fb])
+                           : (float)s_cum[cb] + frac * (float)s_coarse[cb];
+    return min(all_bins - 1, max(0, (int)(r * bscale)));
+  };
+  // ---- pass 4: this stretch's bins counted, and the keys above the stretch
+  int above = 0;
+  for_keys([&](int, float v) {
+    const int b = bin_of(v) - my_lo;
+    above += b < 0 ? 1 : 0;
+    if (b >= 0 && b < SPLIT_BINS) atomicAdd(&s_hist[b], 1u);
+  });
+  __syncthreads();
+  {
+    const int before = block_excl(above);
+    if (t == 1023) s_tot[0] = before + above;
+    uint32_t c4[BPT];
+    int mine = 0, biggest = 0;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      c4[q] = s_hist[t * BPT + q];
+      mine += (int)c4[q];
+      biggest = max(biggest, (int)c4[q]);
+    }
+    if (biggest > BIN_MAX) atomicMax(&s_big, biggest);
+    int at = block_excl(mine);
+    if (t == 1023) s_tot[1] = at + mine;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      s_hist[t * BPT + q] = (uint32_t)at;  // the bin's first position: the fill pass counts it up
+      if (c4[q] != 0u && at < CAP) atomicOr(&s_flag[at >> 5], 1u << (at & 31));
+      at += (int)c4[q];
+    }
+  }
+  __syncthreads();
+  const int rank0 = s_tot[0], n_mine = s_tot[1];
+  if (s_big != 0 || cscale <= 0.f || n_mine > CAP) {  // (uniform over the block)
+    if (t == 0) meta[2 * f] = -1;
+    return;
+  }
+  if (t == 0) atomicOr(&s_flag[n_mine >> 5], 1u << (n_mine & 31));  // the end counts as a bin's first entry
+  if (t < 4) s_key[n_mine + t] = 0u;                                 // ... and past it the smallest orderable key
+  // ---- pass 5: fill
+  for_keys([&](int l, float v) {
+    const int b = bin_of(v) - my_lo;
+    if (b >= 0 && b < SPLIT_BINS) {
+      const int at = (int)atomicAdd(&s_hist[b], 1u);
+      s_key[at] = orderable_desc(v);
+      s_id[at] = (uint16_t)l;
+    }
+  });
+  __syncthreads();
+  // ---- ranking inside the bins, position by position (k_sort_binned's; a window's flags are one 64-bit word)
+  const int lane = t & 63;
+  uint32_t out[SITEMS];  // final position << 16 | id ... two words past 32,767 items: position and id apart
+  uint32_t oid[SITEMS];
+  {
+    int base = (t >> 6) * SITEMS * 64;
+    const unsigned long long upto = (2ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < SITEMS; ++k) {
+      const int p = base + lane;
+      const bool valid = p < n_mine;
+      const int w = base >> 5;  // (base is a multiple of 64)
+      const unsigned long long bc = (unsigned long long)s_flag[w] | ((unsigned long long)s_flag[w + 1] << 32);
+      const unsigned long long bp = base >= 64 ? (unsigned long long)s_flag[w - 2] | ((unsigned long long)s_flag[w - 1] << 32) : 0ull;
+      const unsigned long long bn = base + 64 <= CAP ? (unsigned long long)s_flag[w + 2] | ((unsigned long long)s_flag[w + 3] << 32) : 0ull;
+      const unsigned long long at_or_before = bc & upto, after = bc & ~upto;
+      int lo = at_or_before ? base + 63 - __clzll(at_or_before) : base - 1 - __clzll(bp);
+      int hi = after ? base + __ffsll(after) - 1 : bn ? base + 63 + __ffsll(bn) : n_mine;
+      if (!valid) lo = hi = 0;
+      const uint32_t u = valid ? s_key[p] : 0u;
+      const int id = valid ? (int)s_id[p] : 0;
+      int rank = 0, equal = 0;
+#pragma unroll 1
+      for (int j = lo; j < hi; j += 4) {
+        const uint32_t o0 = s_key[j], o1 = s_key[j + 1], o2 = s_key[j + 2], o3 = s_key[j + 3];
+        rank += (o0 > u ? 1 : 0) + (o1 > u ? 1 : 0) + (o2 > u ? 1 : 0) + (o3 > u ? 1 : 0);
+        equal += (o0 == u ? 1 : 0) + (o1 == u ? 1 : 0) + (o2 == u ? 1 : 0) + (o3 == u ? 1 : 0);
+      }
+      if (equal > 1) {
+#pragma unroll 1
+        for (int j = lo; j < hi; ++j) rank += s_key[j] == u && (int)s_id[j] < id ? 1 : 0;
+      }
+      out[k] = (uint32_t)(lo + rank);
+      oid[k] = (uint32_t)id;
+      base += 64;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SITEMS; ++k)
+    if (((t >> 6) * SITEMS + k) * 64 + lane < n_mine) s_id[out[k]] = (uint16_t)oid[k];
+  __syncthreads();
+  int32_t* col = order + (int64_t)f * I + rank0;
+  for (int k = t; k < n_mine; k += 1024) col[k] = (int32_t)s_id[k];
+}
+
+template <int SITEMS>
+static int launch_sort_binned_split(bpr_ctx* c, hipStream_t st, int G, int nf, const float* keysT, int32_t* order,
+                                    float* sigma, int32_t* meta) {
+  BPR_HIP_CHECK(hipMemsetAsync(meta, 0, sizeof(int32_t) * 2 * nf, st));  // a workgroup that gives up writes -1
+  hipLaunchKernelGGL((k_sort_binned_split<SITEMS>), dim3(G, nf), dim3(1024), 0, st, keysT, c->I, order, sigma, meta);
+  return BPR_OK;
 }
 
 template <int ITEMS>
@@ -1732,9 +1994,28 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
   if (force_sub == 1 || force_sub == 2 || force_sub == 4) sub = force_sub;
   // BINNED sort (r5): a column of <= 20,480 keys is ordered exactly by one workgroup in about a third of the radix
   // sort's time (k_sort_binned) — whole columns then beat split-and-merge on the idle chip too
-  const bool binned = c->tune_binned != 0 && !no_fast && force_sub == 0 && I <= 1024 * 20 && I >= 2048 &&
-                      !(split && !part && c->tune_partial != 0);
-  if (binned) sub = 1;
+  const bool binned_ok = c->tune_binned != 0 && !no_fast && force_sub == 0 && I >= 2048 &&
+                         !(split && !part && c->tune_partial != 0);
+  // ... with G workgroups per column (k_sort_binned_split) when a column does not fit one workgroup's LDS
+  // (I <= 65,535: 16-bit ids)
+  int binned_g = 0, binned_sitems = 0;
+  if (binned_ok && I <= 65535) {
+    if (c->tune_binned_split > 0) binned_g = c->tune_binned_split;  // (tests)
+    else if (I > 1024 * 20) binned_g = (int)((I * 106 / 100 + 20 * 1024 - 1) / (20 * 1024));
+    else binned_g = 1;  // (two workgroups per column on the idle chip were measured: 54.6 against 50.7 us per
+                        // ML-20M refresh — every workgroup repeats the histogram passes)
+    if (binned_g > 1) {
+      for (;; ++binned_g) {  // the staged stretch (I / G keys + 6 % + a window) in 8 / 12 / 16 / 20 k entries
+        const int64_t need = (I / binned_g) * 106 / 100 + 64;
+        binned_sitems = need <= 8 * 1024 ? 8 : need <= 12 * 1024 ? 12 : need <= 16 * 1024 ? 16 : need <= 20 * 1024 ? 20 : 0;
+        if (binned_sitems != 0) break;
+      }
+    } else if (I > 1024 * 20) {
+      binned_g = 0;  // (forced to one workgroup per column but the column does not fit: the radix sort)
+    }
+  }
+  const bool binned = binned_g == 1;
+  if (binned || (binned_g > 1 && I <= 1024 * 36)) sub = 1;  // (the fallback of a flagged column: k_sort_flagged)
   int64_t len = (I + sub - 1) / sub;
   len = (len + 15) / 16 * 16;
   // PARTIAL order (r5): the split refresh of a column that one workgroup holds — the exact ends + a
@@ -1763,6 +2044,27 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
     else if (items <= 16) launch_sort_binned<16>(c, st, nf, keysT, order, sigma, meta);
     else launch_sort_binned<20>(c, st, nf, keysT, order, sigma, meta);
     BPR_HIP_CHECK(hipGetLastError());
+  } else {
+  // the radix path: every column, or — behind the split binned sort — the columns it flagged
+  const int32_t* only_flagged = nullptr;
+  if (binned_g > 1) {
+    int32_t* meta = c->snap_meta[back] + 2 * f_lo;
+    int rc = binned_sitems == 8    ? launch_sort_binned_split<8>(c, st, binned_g, nf, keysT, order, sigma, meta)
+             : binned_sitems == 12 ? launch_sort_binned_split<12>(c, st, binned_g, nf, keysT, order, sigma, meta)
+             : binned_sitems == 16 ? launch_sort_binned_split<16>(c, st, binned_g, nf, keysT, order, sigma, meta)
+                                   : launch_sort_binned_split<20>(c, st, binned_g, nf, keysT, order, sigma, meta);
+    if (rc != BPR_OK) return rc;
+    BPR_HIP_CHECK(hipGetLastError());
+    only_flagged = meta;
+  }
+  if (only_flagged != nullptr && sub == 1) {  // a flagged column fits one workgroup: k_sort_flagged
+    const int items = (int)((len + 1023) / 1024);
+    int32_t* meta = c->snap_meta[back] + 2 * f_lo;
+    if (items <= 10) hipLaunchKernelGGL((k_sort_flagged<10>), dim3(nf), dim3(1024), 0, st, keysT, c->I, order, meta);
+    else if (items <= 20) hipLaunchKernelGGL((k_sort_flagged<20>), dim3(nf), dim3(1024), 0, st, keysT, c->I, order, meta);
+    else if (items <= 28) hipLaunchKernelGGL((k_sort_flagged<28>), dim3(nf), dim3(1024), 0, st, keysT, c->I, order, meta);
+    else hipLaunchKernelGGL((k_sort_flagged<36>), dim3(nf), dim3(1024), 0, st, keysT, c->I, order, meta);
+    BPR_HIP_CHECK(hipGetLastError());
   } else
   if (len <= 1024 * 36 && !no_fast) {
     float* keysA = reinterpret_cast<float*>(c->keys_sorted);
@@ -1771,26 +2073,26 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
     int32_t* idsB = reinterpret_cast<int32_t*>(keysB + n);
     keysA += foff; idsA += foff; keysB += foff; idsB += foff;  // (the kernels index columns from 0)
     const int items = (int)((len + 1023) / 1024);
-    if (items <= 6) launch_sort_sub<6>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 10) launch_sort_sub<10>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 12) launch_sort_sub<12>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 16) launch_sort_sub<16>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 20) launch_sort_sub<20>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 24) launch_sort_sub<24>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else if (items <= 28) launch_sort_sub<28>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
-    else launch_sort_sub<36>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA);
+    if (items <= 6) launch_sort_sub<6>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA, only_flagged);
+    else if (items <= 10) launch_sort_sub<10>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA, only_flagged);
+    else if (items <= 12) launch_sort_sub<12>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA, only_flagged);
+    else if (items <= 16) launch_sort_sub<16>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA, only_flagged);
+    else if (items <= 20) launch_sort_sub<20>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA, only_flagged);
+    else if (items <= 24) launch_sort_sub<24>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA, only_flagged);
+    else if (items <= 28) launch_sort_sub<28>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA, only_flagged);
+    else launch_sort_sub<36>(c, st, nf, keysT, sig_acc, order, sigma, sub, len, keysA, idsA, only_flagged);
     int64_t run = len;
     for (int level = sub; level > 1; level /= 2, run *= 2) {
       const int last = level == 2;
       const int tiles_per_pair = (int)((2 * run + MERGE_TILE - 1) / MERGE_TILE);
       const unsigned mgrid = (unsigned)(((I + 2 * run - 1) / (2 * run)) * tiles_per_pair);
       hipLaunchKernelGGL(k_merge_runs, dim3(mgrid, nf), dim3(MERGE_THREADS), 0, st, keysA, idsA, I,
-                         run, tiles_per_pair, keysB, last ? order : idsB, last, sigma, sig_acc);
+                         run, tiles_per_pair, keysB, last ? order : idsB, last, sigma, sig_acc, only_flagged);
       std::swap(keysA, keysB);
       std::swap(idsA, idsB);
     }
     BPR_HIP_CHECK(hipGetLastError());
-  } else {  // device-wide sort: always every column (a sharded refresh is merely redundant here)
+  } else if (only_flagged == nullptr) {  // device-wide sort: always every column (a sharded refresh is merely redundant here)
     hipLaunchKernelGGL(k_sigma, dim3(d), dim3(256), 0, st, keysT - foff, I, sigma - f_lo);
     uint64_t* k64 = reinterpret_cast<uint64_t*>(c->keys_sorted);
     hipLaunchKernelGGL(k_compose_keys, dim3(2048), dim3(256), 0, st, keysT - foff, k64, n, I);
@@ -1800,6 +2102,7 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
     BPR_HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp, bytes, k64, k64 + n, c->ids_in,
                                                      order - foff, (int)n, 0, key_bits, st));
     BPR_HIP_CHECK(hipGetLastError());
+  }
   }
   if (part) {  // the caller fills the other columns and publishes (refresh_publish_impl)
     c->part_pending = true;

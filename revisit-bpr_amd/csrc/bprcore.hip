@@ -1357,6 +1357,7 @@ int bpr_set_tuning(bpr_ctx* c, const char* key, int32_t value) {
   else if (k == "adam_closed" && (value == 0 || value == 1)) c->tune_adam_closed = value;
   else if (k == "partial_snapshot" && (value == 0 || value == 1)) c->tune_partial = value;
   else if (k == "binned_sort" && (value == 0 || value == 1)) c->tune_binned = value;
+  else if (k == "binned_split" && value >= 0 && value <= 4) c->tune_binned_split = value;
   else if (k == "partial_target" && value >= 1 && value <= 1024) c->partial_target = value;
   else if (k == "refresh_sub" && (value == 0 || value == 1 || value == 2 || value == 4)) c->tune_refresh_sub = value;
   else return fail(BPR_ERR_INVALID, "bpr_set_tuning: unknown key or value out of range");

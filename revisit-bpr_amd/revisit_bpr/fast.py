@@ -19,9 +19,13 @@ from revisit_bpr import engine as eng
 def sort_cu_ms(I: int, d: int) -> float:
     """CU-milliseconds of one snapshot sort (one 1,024-thread workgroup per column, measured on MI355X): the
     binned sort of r5 (columns of 2,048 .. 20,480 keys: ~2.0 ns per key + 3 us per column — 42 us for ML-20M's
-    20,108) or the in-LDS radix sort (~5.05 ns per key, 1.3x when columns are split and merged: I > 36,864)."""
+    20,108; up to 65,535 keys with G workgroups per column: MSD's 41,141 in 3 x 70 us) or the in-LDS radix sort
+    (~5.05 ns per key, 1.3x when columns are split and merged: I > 36,864)."""
     if 2048 <= I <= 20480:
         return d * (2.0e-6 * I + 0.003)
+    if I <= 65535:  # the binned sort with G workgroups per column, each reading the whole column (MSD: G = 3, 70 us each)
+        G = -(-(I * 106 // 100) // (20 * 1024))
+        return G * d * (1.6e-6 * I + 0.005)
     return 5.05e-6 * I * d * (1.3 if I > 36864 else 1.0)
 
 
@@ -31,6 +35,9 @@ def auto_refresh_cus(I: int, d: int, launch_triples: int, total_cus: int = 256) 
     Calibrated on MI355X (profiles/shapes_r03.txt, r05_binned_sort.md): `sort_cu_ms`, a launch ~0.72 / 0.8 / 1.1 /
     1.8 / 3.5 ns per triple at d <= 32 / 64 / 128 / 256 / 512; measured optima: 32 CUs for ML-20M d=128 since
     the binned sort (64 before it), 96 for MSD d=256."""
+    lag, cus = auto_schedule(I, d, launch_triples, total_cus)
+    if lag > 0.0 and cus > 0:  # the split the cost model of the whole step picks
+        return cus
     per_triple = 0.72e-6 if d <= 32 else 0.8e-6 if d <= 64 else 1.1e-6 if d <= 128 else \
         1.8e-6 if d <= 256 else 3.5e-6 * d / 512
     launch_ms = max(launch_triples, 1) * per_triple

@@ -224,7 +224,7 @@ def test_staleness_budget_and_schedule_rules():
             k = fast.launches_per_period(lr, w, period)
             assert k == 4 * w or lr * w * (period / k) <= fast.STALENESS_BUDGET
     assert fast.auto_schedule(20109, 128, period) == (1.0, 32)  # (64 until the binned sort of r5)
-    assert fast.auto_schedule(41141, 256, 436_992) == (1.0, 96)
+    assert fast.auto_schedule(41141, 256, 436_992) == (1.0, 64)  # (96 until the split binned sort of r5)
     lag, cus = fast.auto_schedule(4800, 64, 40_704)
     assert lag == 1.0 and cus == 32
     # r5: a lagged snapshot misses up to two launches of updates and is held to the same budget —

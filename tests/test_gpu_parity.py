@@ -919,6 +919,37 @@ def test_binned_sort_is_the_stable_descending_order(I, d, kind):
     assert np.array_equal(e.adaptive_snapshot()[0].cpu().numpy(), order_o)
 
 
+@pytest.mark.parametrize("I,d,split", [(41141, 16, 0), (30001, 8, 0), (65535, 4, 0), (20481, 8, 0), (36865, 8, 0),
+                                       (20108, 128, 0), (20108, 16, 2), (20108, 16, 3), (20480, 8, 4), (9999, 24, 2),
+                                       (2048, 16, 2), (50000, 4, 3)])
+@pytest.mark.parametrize("kind", ["normal", "few-ties", "ties", "spike", "skewed", "equal"])
+def test_split_binned_sort_is_the_stable_descending_order(I, d, split, kind):
+    """k_sort_binned_split — G workgroups per column, each ordering a stretch of ranks: columns past one workgroup's
+    LDS (20,480 < I <= 65,535: MSD's 41,141 items); `binned_split` forces G on smaller tables.  Same order as the
+    oracle's stable descending argsort and as the radix path, same sigma as the one-workgroup kernel; heavily tied /
+    all-equal columns take the per-column fallback (k_sort_flagged up to 36,864 items, the filtered split radix sort +
+    merge beyond)."""
+    rng = np.random.default_rng(I * 11 + d + len(kind) + split)
+    Q = _binned_tables(I, d, kind, rng)
+    P = np.zeros((4, d), np.float32)
+    QT, sigma_o = oracle.adaptive_stats(Q)
+    order_o = oracle.adaptive_order(QT)
+    sig = {}
+    for name, tune in (("split", {"binned_split": split}), ("radix", {"binned_sort": 0}),
+                       ("one", {"binned_split": 1})):
+        e = make_engine(P, Q)
+        for k, v in tune.items():
+            e.set_tuning(k, v)
+        e.adaptive_refresh()
+        order, sigma = e.adaptive_snapshot()
+        assert np.array_equal(order.cpu().numpy(), order_o), (name, kind)
+        sig[name] = sigma.cpu().numpy()
+        if np.all(sigma_o > 0):
+            assert close(sig[name], sigma_o, 2e-6)
+    if I <= 20480:
+        assert np.array_equal(sig["split"], sig["one"])  # the same sums in the same order
+
+
 def test_atomics_lose_nothing_under_chip_wide_contention():
     """100k triples hammering 50 item rows from every CU / XCD at once: the accumulated gradients
     must be the exact sums (device-scope fp32 atomics resolve below the per-XCD L2s)."""
