@@ -392,7 +392,9 @@ int bpr_set_hot_rows(bpr_ctx* ctx, int32_t hot_rows, int32_t replicas);
  *   "partial_snapshot" 0 / 1, "partial_target" 1..1024: bpr_adaptive_snapshot_partial above;
  *   "binned_sort" 1 (default) / 0: tables of 2,048 .. 20,480 items have their snapshot columns ordered by
  *               k_sort_binned (equi-depth bins + ranking inside the bin: the same stable descending order as
- *               the radix sort, bit for bit, in ~0.4 of its time) / by the radix sort (a test and measurement aid). */
+ *               the radix sort, bit for bit, in ~0.4 of its time; up to 65,535 items with several workgroups per
+ *               column, k_sort_binned_split) / by the radix sort (a test and measurement aid);
+ *   "binned_split" 0 (default: workgroups per column by table size) / 1..4 (tests force the split kernel on small tables). */
 int bpr_set_tuning(bpr_ctx* ctx, const char* key, int32_t value);
 /* The item_bias during STREAM launches (models/bpr/model.py:101-110; the RQ configs switch it on).
  * k_stream works on a table of its own with ONE item per 128-B line (in the dense vector 32 items share a
