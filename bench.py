@@ -130,7 +130,7 @@ WORKLOADS = {
 # HBM-side bytes per k_stream launch measured by separate rocprofv3 --pmc passes (profiles/*_pmc_traffic.md)
 # of exactly these commands: (workload, d, sampler, optimizer) -> file under profiles/
 TRAFFIC_FILES = {
-    ("ml-20m", 128, "adaptive", "sgd"): "traffic_r05b.json",
+    ("ml-20m", 128, "adaptive", "sgd"): "traffic_r05d.json",
     ("msd", 256, "adaptive", "sgd"): "traffic_r05_msd_d256.json",
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # r5, second half (binned sort, sorter on 32 CUs): the bench lines and rocprofv3 summaries profiles/ is built from.
 # A trimmed tools/profile_round.sh: the MSD / Adam / calibration passes are unchanged kernels (profiles/r05_*).
-T=r05b
+T=${1:-r05b}
 R=/root/repo; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench_final.log 2>&1; tail -1 $O/bench_final.log > $O/bench_${T}_final.json
