@@ -36,8 +36,7 @@ def test_bins_are_monotone_in_the_key_and_small(n):
         assert np.all(np.diff(bins[by_key]) >= 0), name  # larger key -> same or earlier bin
         same = col[by_key][1:] == col[by_key][:-1]
         assert np.all(bins[by_key][1:][same] == bins[by_key][:-1][same]), name  # equal keys share a bin
-        if name != "two-clusters":  # (two far clusters: the crowded stretch spans the gap; the kernel falls back)
-            assert np.bincount(bins).max() <= 24, (name, np.bincount(bins).max())
+        assert np.bincount(bins).max() <= 24, (name, np.bincount(bins).max())  # (limit 64; two far clusters: 11)
 
 
 @pytest.mark.parametrize("n", [2048, 9999])
