@@ -7,7 +7,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[2]
 src = (ROOT / "revisit-bpr_amd/csrc/bpr_refresh.hip").read_text()
-body = src[src.index("constexpr int BIN_MAX = 64;"):src.index("template <int ITEMS>\nstatic void launch_sort_binned")]
+body = src[src.index("constexpr int BIN_MAX = 64;"):src.index("// The binned sort with G workgroups per column")]
+body = body[:body.rindex("// -----")]  # (the one-workgroup kernel only)
 
 
 def variant(name, text):
