@@ -382,6 +382,25 @@ int bpr_stream_run_len(bpr_ctx* ctx);
  * as updating Q directly, up to the association of fp32 sums.  hot_rows = 0 turns it off.  Takes
  * effect at the next bpr_plan_epoch. */
 int bpr_set_hot_rows(bpr_ctx* ctx, int32_t hot_rows, int32_t replicas);
+/* The LDS tier of the hot block (r6).  Once the adaptive sampler has a trained model to adapt to, its
+ * negatives concentrate on the head of the dominant factors' orders (neg_samplers.py:84-121) — 40-60 % of
+ * them, and half of the positives, fall on a few hundred item rows, ~800 updates per row and launch, each one
+ * four memory-side line requests plus the read of a delta row those requests keep dropping from the L2s.
+ * With rows > 0, STREAM launches that fill the chip at least twice run ONE workgroup per CU (up to 1,024
+ * threads, persistent over its share of the runs) that keeps a private fp32 delta block for the `rows` most
+ * popular hot rows in LDS beside its groups' seen bitmaps (as many as fit the CU's 160 KiB; d = 128, ML-20M:
+ * 128 rows): an update of such a row is an LDS add, its value is Q + the workgroup's own LDS delta, and the
+ * rows a workgroup touched are added to the global delta block at its exit (so the fold, the cut, the hot tier
+ * of several GPUs and the exact-sum property are what they were).  SEMANTICS: a workgroup sees the other
+ * workgroups' updates of these rows one launch late — the staleness `learning rate x triples per launch`
+ * that the multi-GPU budget prices (revisit_bpr/fast.py lag_within_budget: inside at the
+ * reference's lr 0.001 and 0.01, outside at 0.05), which is why it is off by default and the trainers switch
+ * it on by that rule.  With max_inflight = 1 (one group) it is exactly sequential SGD.  always = 1: also for
+ * launches that do not fill the chip (tests).  Needs a hot block (bpr_plan_epoch / bpr_set_hot_items), the
+ * LDS seen bitmap or given negatives, d in {32, 64, 128, 256, 512, 1024}, a snapshot sorted whole; otherwise
+ * the plain kernel runs.  bpr_stream_lds_rows: LDS rows of the last STREAM launch (0 = the plain kernel ran). */
+int bpr_set_hot_lds(bpr_ctx* ctx, int32_t rows, int32_t always);
+int bpr_stream_lds_rows(bpr_ctx* ctx);
 /* Test and measurement aids, per ctx (nothing in the library reads the environment per launch):
  *   "seen"      0 = by shape (default), 1 = binary search in the CSR, 2 = LDS bitmap, 3 = staged list —
  *               the structure the sampling kernels answer "has u seen c?" from;

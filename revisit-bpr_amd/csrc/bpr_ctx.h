@@ -145,6 +145,13 @@ struct bpr_ctx {
   float* defer_out = nullptr;
   bool defer_pending = false;
   int32_t* hot_canon = nullptr;  // [hot_H]
+  // LDS tier of the hot block (k_stream LDSHOT, bpr_hotlds.hip): hot_code[i] = -1 | (popularity rank << 16 | slot),
+  // hot_by_rank[rank] = slot; tune_hot_lds = rows asked for per workgroup (0: off), tune_hot_lds_force: also for
+  // launches that do not fill the chip (tests)
+  int32_t* hot_code = nullptr;     // [I]
+  int32_t* hot_by_rank = nullptr;  // [hot_H]
+  int tune_hot_lds = 0, tune_hot_lds_force = 0;
+  int last_lds_rows = 0;           // LDS rows of the last STREAM launch (0: the plain kernel ran)
   int64_t hot_key_n = 0;
   // heavy users' seen bitmaps (built once per seen CSR, by the first sampling STREAM launch)
   uint32_t* heavy_off = nullptr;   // [U] word offset of the user's row in heavy_bits, ~0u = light

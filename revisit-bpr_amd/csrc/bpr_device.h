@@ -654,7 +654,7 @@ __device__ __forceinline__ float neg_logsigmoid(float x) {
 __device__ __forceinline__ void reduce_scalars(float* partials, float s_loss, float s_reg,
                                                float s_abs, float s_cnt, int lane,
                                                bool accumulate = false) {
-  __shared__ float red[4][4];
+  __shared__ float red[16][4];  // up to 1,024 threads (k_stream LDSHOT)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     s_loss += __shfl_xor(s_loss, off, 64);

@@ -1551,7 +1551,9 @@ void hot_free(bpr_ctx* c) {
   hipFree(c->hot_items);
   hipFree(c->hot_delta_alloc);
   hipFree(c->hot_canon);
-  c->hot_canon = nullptr;
+  hipFree(c->hot_code);
+  hipFree(c->hot_by_rank);
+  c->hot_canon = c->hot_code = c->hot_by_rank = nullptr;
   c->hot_explicit = false;
   c->hot_tier = false;
   c->hot_delta_alloc = nullptr;
@@ -1620,6 +1622,7 @@ static int hot_build_from(bpr_ctx* c, std::vector<uint32_t>& cnt, const int32_t*
   for (int k = 0; k < H; ++k) place[k] = k;
   std::stable_sort(place.begin(), place.end(), [&](int x, int y) { return cnt[by[x]] > cnt[by[y]]; });
   std::vector<int32_t> slot_of((size_t)I, -1), item_of((size_t)H, -1), canon_of((size_t)H, -1);
+  std::vector<int32_t> code_of((size_t)I, -1), by_rank((size_t)H, -1);  // LDS tier: rank = placement order, heaviest first
   std::vector<char> used((size_t)H, 0);
   const uint64_t hbase = (uint64_t)(uintptr_t)c->hot_delta;
   static const bool naive = getenv("BPR_HOT_NAIVE") != nullptr;  // measurement aid: slot = rank
@@ -1647,6 +1650,8 @@ static int hot_build_from(bpr_ctx* c, std::vector<uint32_t>& cnt, const int32_t*
     slot_of[it] = best;
     item_of[best] = it;
     canon_of[best] = k;
+    if (H < 32768) code_of[it] = (int32_t)(((uint32_t)kk << 16) | (uint32_t)best);
+    by_rank[kk] = best;
     for (int l = 0; l < lines; ++l)
       load[channel_of(hbase + (uint64_t)(best * row_bytes + l * 128))] += w;
   }
@@ -1670,6 +1675,13 @@ static int hot_build_from(bpr_ctx* c, std::vector<uint32_t>& cnt, const int32_t*
                                hipMemcpyHostToDevice, c->stream));
   BPR_HIP_CHECK(hipMemcpyAsync(c->hot_canon, canon_of.data(), sizeof(int32_t) * H,
                                hipMemcpyHostToDevice, c->stream));
+  if (H < 32768) {
+    BPR_HIP_CHECK(hipMalloc(&c->hot_code, sizeof(int32_t) * I));
+    BPR_HIP_CHECK(hipMalloc(&c->hot_by_rank, sizeof(int32_t) * H));
+    BPR_HIP_CHECK(hipMemcpyAsync(c->hot_code, code_of.data(), sizeof(int32_t) * I, hipMemcpyHostToDevice, c->stream));
+    BPR_HIP_CHECK(hipMemcpyAsync(c->hot_by_rank, by_rank.data(), sizeof(int32_t) * H, hipMemcpyHostToDevice,
+                                 c->stream));
+  }
   BPR_HIP_CHECK(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
   c->hot_H = H;
   c->hot_R = R;

@@ -384,9 +384,44 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       nblk = (2 * nblk + 2) / 3;  // 1.5 runs per group
     const int64_t max_blk = std::min<int64_t>(stream_grid_cap() * (256 / block), STREAM_MAX_GRID);
     if (nblk > max_blk) nblk = max_blk;
-    const unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
+    unsigned grid = (unsigned)(nblk < 1 ? 1 : nblk);
     a.bm_words = lds_words;
     const bool hot = a.hot_slot != nullptr;
+    // ---- the LDS tier of the hot block (k_stream LDSHOT, bpr_hotlds.hip; bpr_set_tuning "hot_lds" = rows asked
+    // for): ONE workgroup per CU — up to 1,024 threads, its groups' seen bitmaps and an [L, d] fp32 delta block in
+    // LDS — persistent over its share of the runs.  Taken when the launch fills the chip at least twice (a smaller
+    // one is over when its slowest group is: the plain kernel's short runs win there), the shape has a FULL
+    // instantiation, the snapshot is sorted whole and the per-group bitmaps leave room for >= 8 rows.
+    bool use_lds = false;
+    size_t shmem_l = 0;
+    unsigned block_l = E <= 4 ? 1024 : 512;  // (E >= 8: 64+ registers of rows per lane — two waves per SIMD)
+    c->last_lds_rows = 0;
+    if (c->tune_hot_lds > 0 && hot && c->hot_code != nullptr && c->d == G * E && a.snap_meta == nullptr &&
+        (sampler == NEG_GIVEN || (force != "csr" && force != "list"))) {
+      if (cap_groups > 0 && cap_groups * G < block_l) block_l = (unsigned)(((cap_groups * G + 63) / 64) * 64);
+      const size_t bm_bytes = sampler == NEG_GIVEN ? 0 : (size_t)(block_l / G) * words * sizeof(uint32_t);
+      const size_t row_bytes = sizeof(float) * (size_t)c->d + sizeof(uint32_t);
+      int64_t L = bm_bytes < LDS_TIER_MAX_BYTES ? (int64_t)((LDS_TIER_MAX_BYTES - bm_bytes) / row_bytes) : 0;
+      L = std::min<int64_t>(L, std::min<int64_t>(c->tune_hot_lds, c->hot_H));
+      const int64_t per_block_l = (int64_t)(block_l / 64) * a.gpw_active;
+      const int64_t runs8 = (a.n + 7) / 8;
+      const bool fills = runs8 >= 2 * (int64_t)stream_cus(c) * per_block_l;
+      if (L >= 8 && (fills || c->tune_hot_lds_force)) {
+        use_lds = true;
+        if (c->run_len <= 0) a.run_len = 8;
+        c->last_run_len = a.run_len;
+        const int64_t n_runs_l = (a.n + a.run_len - 1) / a.run_len;
+        int64_t want_l = n_runs_l;
+        if (cap_groups > 0 && want_l > cap_groups) want_l = cap_groups;
+        grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(stream_cus(c), (want_l + per_block_l - 1) / per_block_l));
+        a.bm_words = sampler == NEG_GIVEN ? 0 : words;
+        a.lds_L = (int32_t)L;
+        a.hot_by_rank = c->hot_by_rank;
+        a.hot_slot = c->hot_code;
+        shmem_l = bm_bytes + (size_t)L * row_bytes;
+        c->last_lds_rows = (int)L;
+      }
+    }
     // hot tier + cut: fold, reconciliation passes and snapshot cut are ONE pass, bpr_sync_cut, which the
     // caller issues next; the launch leaves it its loss partials too
     const bool defer = cut && hot && c->hot_tier;
@@ -428,6 +463,9 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       Timer tm(c, true);
       (void)tm;
       hipEvent_t stop = acut ? c->ev_launch : nullptr;
+      if (use_lds) {
+        if (int rc = launch_stream_lds(c, a, sampler, grid, block_l, shmem_l, stop)) return rc;
+      }
       auto go = [&](auto smp, auto sn) {
         constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
         if constexpr (SMP == NEG_ADAPTIVE) {
@@ -448,7 +486,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
           hipExtLaunchKernelGGL((k_stream<G, E, SMP, SN, false>), dim3(grid), dim3(block), shmem,
                                 c->stream, nullptr, stop, 0, a);
       };
-      pick(go);
+      if (!use_lds) pick(go);
     }
     if (a.bias != nullptr && !bias_in_epilogue)
       hipLaunchKernelGGL(k_bias_narrow, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream,
@@ -1237,6 +1275,18 @@ int bpr_set_hot_rows(bpr_ctx* c, int32_t hot_rows, int32_t replicas) {
   c->hot_rows_opt = hot_rows;
   c->hot_reps_opt = hot_rows > 0 ? replicas : 0;
   return BPR_OK;
+}
+
+int bpr_set_hot_lds(bpr_ctx* c, int32_t rows, int32_t always) {
+  if (c == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_hot_lds: ctx is NULL");
+  if (rows < 0 || rows > 32767) return fail(BPR_ERR_INVALID, "bpr_set_hot_lds: rows must be in [0, 32767]");
+  c->tune_hot_lds = rows;
+  c->tune_hot_lds_force = always != 0;
+  return BPR_OK;
+}
+
+int bpr_stream_lds_rows(bpr_ctx* c) {
+  return c == nullptr ? 0 : c->last_lds_rows;
 }
 
 int bpr_set_hot_items(bpr_ctx* c, const int32_t* items_host, int32_t H, const uint32_t* counts_host) {

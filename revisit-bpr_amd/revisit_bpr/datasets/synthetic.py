@@ -194,3 +194,22 @@ def generate_named(name: str, eval_users: int = 0, seed: int = 13, scale: float 
     if scale != 1.0:
         users, actions = max(16, int(users * scale)), max(64, int(actions * scale))
     return generate(users, items, actions, med, mn, eval_users=eval_users, seed=seed, **kw)
+
+
+def leave_one_out(data: Interactions, seed: int = 13) -> Interactions:
+    """The Netflix protocol of the reference (configs/RQ1/ours.yaml.j2: `OnePosCollator` + `RocAucOne`,
+    `skip_seen: false`): every user gives up ONE of its interactions as the evaluation positive, the rest
+    train.  The user's seen set (the CSR) stays WHOLE — the reference's `seen_items` of a user holds the
+    held-out item too (experiments/bpr/dataset.py:201-207: the positive is addressed as an index into it),
+    so the samplers never draw it and the evaluation ranks it against the items outside the seen set."""
+    rng = np.random.default_rng(seed)
+    cnt = np.diff(data.indptr)[1:]
+    pick = data.indptr[1:-1] + (rng.random(cnt.shape[0]) * cnt).astype(np.int64)
+    pick = pick[cnt > 1]  # (a user with a single interaction keeps it)
+    held = np.zeros(data.nnz, bool)
+    held[pick] = True
+    ev = data.users[pick]
+    return Interactions(
+        num_users=data.num_users, num_items=data.num_items, users=data.users[~held], items=data.items[~held],
+        indptr=data.indptr, indices=data.indices, eval_users=ev.astype(np.int32),
+        eval_indptr=np.arange(len(ev) + 1, dtype=np.int64), eval_items=data.items[pick].astype(np.int32))

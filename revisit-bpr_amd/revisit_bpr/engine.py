@@ -142,6 +142,9 @@ class Engine:
             self.set_tuning("adam_closed", 0)
         if os.environ.get("BPR_REFRESH_SUB") in ("1", "2", "4"):
             self.set_tuning("refresh_sub", int(os.environ["BPR_REFRESH_SUB"]))
+        if os.environ.get("BPR_HOT_LDS"):  # "rows" or "rows,always"
+            v = os.environ["BPR_HOT_LDS"].split(",")
+            self.set_hot_lds(int(v[0]), len(v) > 1 and v[1] == "1")
         if os.environ.get("BPR_HEAVY_T"):
             native.check(self._lib.bpr_set_heavy_users(self._ctx, int(os.environ["BPR_HEAVY_T"]), 0))
 
@@ -543,6 +546,16 @@ class Engine:
     def stream_run_len(self) -> int:
         """Run length the last STREAM launch used (run_len = 0 lets the library pick it)."""
         return int(self._lib.bpr_stream_run_len(self._ctx))
+
+    def set_hot_lds(self, rows: int, always: bool = False) -> None:
+        """``bpr_set_hot_lds``: the `rows` most popular hot rows take a CU's updates in LDS (flushed at the
+        workgroup's exit): a hot row is one launch stale across CUs — switch it on by ``fast.lag_within_budget``.
+        ``always``: also for launches that do not fill the chip (tests)."""
+        native.check(self._lib.bpr_set_hot_lds(self._ctx, int(rows), int(always)))
+
+    def stream_lds_rows(self) -> int:
+        """LDS rows of the last STREAM launch (0: the plain kernel ran)."""
+        return int(self._lib.bpr_stream_lds_rows(self._ctx))
 
     def hot_fold(self) -> None:
         """Fold the hot rows' deltas an asynchronous cut left in the block (no-op otherwise): after it

@@ -112,6 +112,19 @@ STALENESS_BUDGET = 4_000.0
 
 MAX_CHUNKS_PER_RANK_SHARE = 4  # chunks may shrink to period / (4 x world), no further
 
+# LDS tier of the hot block (r6, `bpr_set_hot_lds`): rows asked for — the library keeps as many as fit a CU's
+# LDS beside the seen bitmaps (ML-20M, d = 128: 128) and takes the tier only for launches that fill the chip
+HOT_LDS_ROWS = 512
+
+
+def hot_lds_rows(lr: float, launch_triples: int, world: int = 1, budget: Optional[float] = None) -> int:
+    """Rows of the hot block a CU may keep in LDS for a launch of this size at this learning rate (0: none).
+    With the tier a workgroup sees the OTHER workgroups' updates of those rows one launch late — what a rank of a
+    multi-rank job sees of the other ranks — so it is held to the same staleness budget as the lagged snapshot:
+    lr x 2 x (job triples per launch) <= STALENESS_BUDGET (inside at the reference configs' lr 0.001 and at 0.01 for
+    an ML-20M period, outside at 0.05; tests/test_gpu_fullscale_reference.py gates both sides of the rule)."""
+    return HOT_LDS_ROWS if lag_within_budget(lr, launch_triples * max(world, 1), budget) else 0
+
 
 def launches_per_period(lr: float, world: int, period: int, budget: Optional[float] = None) -> int:
     """Chunks a rank cuts a refresh period into so that lr x world x chunk stays inside the budget:
@@ -132,7 +145,8 @@ class StreamTrainer:
                  item_sync=None, sync_every: int = 1, world: Optional[int] = None,
                  refresh_lag: float | str = 0.0, refresh_split: int = 1, refresh_cus: int = 0,
                  shard_refresh: bool = False, cadence: str = "job", hot_split: int = 1,
-                 rounds: Optional[int] = None, jit_plan: bool = False, async_cut: bool = False) -> None:
+                 rounds: Optional[int] = None, jit_plan: bool = False, async_cut: bool = False,
+                 hot_lds: int | str = "auto") -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
         adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302.
@@ -173,6 +187,9 @@ class StreamTrainer:
         the model; the sorter idles ~40 us per step), and `adaptive_refresh_commit` waits for both.
         Same chunks as `bpr_plan_epoch` makes (same members, grouped by user).
 
+        hot_lds: rows of the hot block a CU keeps in LDS during a launch (`bpr_set_hot_lds`; r6): "auto" =
+        `hot_lds_rows` — on inside the staleness budget, off outside; 0 = off; n = asked for whatever the rate.
+
         async_cut (refresh_lag = 1, one GPU): the cut of the next snapshot leaves the launch stream —
         a read-only pass on the side stream beside the NEXT launch (`bpr_train_stream_acut`); the
         launch stream runs launch after launch.  The hot rows are folded at the end of the epoch."""
@@ -206,6 +223,8 @@ class StreamTrainer:
                       launches_per_period(lr, max(world, 1), every * batch_size, STALENESS_BUDGET))
         self.chunk = max(1, min(every * batch_size // (per_period * refresh_split), self.n))
         self.hot_split = max(1, int(hot_split))
+        self.hot_lds = hot_lds_rows(lr, self.chunk, max(world, 1)) if isinstance(hot_lds, str) else int(hot_lds)
+        self.engine.set_hot_lds(self.hot_lds)
         U = self.engine.U
         # staleness budget: at most ~U/4 triples in flight against one parameter cut
         self.max_inflight = max(64, U // 4) if max_inflight is None else max_inflight

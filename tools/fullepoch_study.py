@@ -41,6 +41,12 @@ VARIANTS = {
     "ref_inflight512": dict(max_inflight=512),
     "ref_inflight256": dict(max_inflight=256),
     "ref_split2": dict(refresh_split=2),
+    # r6: the LDS tier of the hot block, forced on whatever the learning rate ("auto" = what the trainer picks)
+    "auto": dict(refresh_lag="auto"),
+    "timed_lds": dict(refresh_lag=1.0, refresh_cus=-1, hot_lds=512),
+    "timed_nolds": dict(refresh_lag=1.0, refresh_cus=-1, hot_lds=0),
+    "reference_lds": dict(hot_lds=512),
+    "reference_nolds": dict(hot_lds=0),
 }
 
 
