@@ -413,7 +413,11 @@ int bpr_stream_lds_rows(bpr_ctx* ctx);
  *               k_sort_binned (equi-depth bins + ranking inside the bin: the same stable descending order as
  *               the radix sort, bit for bit, in ~0.4 of its time; up to 65,535 items with several workgroups per
  *               column, k_sort_binned_split) / by the radix sort (a test and measurement aid);
- *   "binned_split" 0 (default: workgroups per column by table size) / 1..4 (tests force the split kernel on small tables). */
+ *   "binned_split" 0 (default: workgroups per column by table size) / 1..4 (tests force the split kernel on small tables);
+ *   "lds_block" 0 (default: 1,024 threads for d <= 256 at 32-lane groups, 512 above) / a multiple of 64: threads per
+ *               workgroup of the LDS-tier kernel (bpr_set_hot_lds) — fewer groups leave more LDS for hot rows;
+ *   "lds_tail"  0..50 (default 12): percent of a launch's triples the LDS-tier kernel deals in runs of run_len / 2 and
+ *               run_len / 4 at the end of every persistent workgroup's share (a workgroup is over when its last run is). */
 int bpr_set_tuning(bpr_ctx* ctx, const char* key, int32_t value);
 /* The item_bias during STREAM launches (models/bpr/model.py:101-110; the RQ configs switch it on).
  * k_stream works on a table of its own with ONE item per 128-B line (in the dense vector 32 items share a

@@ -75,6 +75,8 @@ struct StreamArgs {
   // updates in a delta block in LDS, flushed into slot hot_by_rank[rank] of the global block at exit
   int32_t lds_L;
   const int32_t* hot_by_rank;
+  int32_t lds_only;      // 1: hot rows past lds_L are updated in Q like cold rows (no hot tier that wants their deltas)
+  int32_t tail1, tail2;  // LDSHOT: first triple of the zones of runs of run_len / 2 and run_len / 4 (n: no such zone)
 };
 
 // A hot row's value is its base row plus its replica delta rows; returns where this wave adds its
@@ -159,7 +161,14 @@ void k_stream(const StreamArgs a) {
   const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
   const int d = FULL ? G * E : a.d;
   const int L = a.run_len;
-  const int n_runs = (a.n + L - 1) / L;
+  // The chunk as runs: [0, tail1) in runs of L triples, [tail1, tail2) in runs of L / 2, [tail2, n) in runs of
+  // L / 4 (LDSHOT: a persistent workgroup is over when its last run is, so the last tickets are short ones —
+  // guided self-scheduling; the plain kernel's launches have tail1 = tail2 = n).  The zones hold whole wave-loads
+  // of runs, so the run length is wave-uniform.
+  const int L2 = L >= 2 ? L >> 1 : 1, L3 = L >= 4 ? L >> 2 : 1;
+  const int R1 = LDSHOT ? a.tail1 / L : (a.n + L - 1) / L;
+  const int R2 = LDSHOT ? R1 + (a.tail2 - a.tail1) / L2 : R1;
+  const int n_runs = LDSHOT ? R2 + (a.n - a.tail2 + L3 - 1) / L3 : R1;
   const bool stats = a.partials != nullptr;
   float s_loss = 0.f, s_reg = 0.f, s_abs = 0.f, s_cnt = 0.f;
   // per-group LDS scratch of W words: the seen-items bitmap of the current user (I bits, one
@@ -205,8 +214,18 @@ void k_stream(const StreamArgs a) {
     if (rbase >= n_runs) break;
     const int run = rbase + gw;
     const bool run_act = gw < gpw && run < n_runs;
-    const int t0 = run_act ? run * L : 0;
-    const int t1 = run_act ? min(t0 + L, a.n) : 0;
+    int Lr = L, t0r = run * L;
+    if constexpr (LDSHOT) {
+      if (rbase >= R2) {
+        Lr = L3;
+        t0r = a.tail2 + (run - R2) * Lr;
+      } else if (rbase >= R1) {
+        Lr = L2;
+        t0r = a.tail1 + (run - R1) * Lr;
+      }
+    }
+    const int t0 = run_act ? t0r : 0;
+    const int t1 = run_act ? min(t0 + Lr, a.n) : 0;
     // ---- run prologue: ONE coalesced load brings the ids of the whole run (lane k holds triple
     // t0+k; lane L the successor, lane G-1 the predecessor) and one more the users' CSR bounds,
     // so the per-triple dependent chain starts at the row gathers instead of at the ids.
@@ -215,8 +234,8 @@ void k_stream(const StreamArgs a) {
     int32_t my_cnt = 0;  // the user's seen items: indices[my_lo .. my_lo + my_cnt)
     {
       const int tk = (gl == G - 1) ? t0 - 1 : t0 + gl;
-      const bool in_run = run_act && gl < L && tk < t1;
-      const bool neighbour = run_act && ((gl == L && tk < a.n) || (gl == G - 1 && tk >= 0));
+      const bool in_run = run_act && gl < Lr && tk < t1;
+      const bool neighbour = run_act && ((gl == Lr && tk < a.n) || (gl == G - 1 && tk >= 0));
       if (in_run || neighbour) my_u = a.users[tk];
       if (in_run) {
         my_i = a.pos[tk];
@@ -251,7 +270,7 @@ void k_stream(const StreamArgs a) {
 
     float x_mine = 0.f;  // statistics: logit of step gl of this run
     bool x_have = false;
-    for (int step = 0; step < L; ++step) {
+    for (int step = 0; step < Lr; ++step) {
       const int t = t0 + step;
       const bool act = run_act && t < t1;
       const int tt = act ? t : (a.n - 1);
@@ -375,13 +394,15 @@ void k_stream(const StreamArgs a) {
       if constexpr (LDSHOT) {
         // codes (StreamArgs::lds_L): rank < lds_L -> this workgroup's LDS delta row, else the global block
         const int32_t sj = a.hot_slot[j];
+        // (without a hot tier the rest of the block is left alone: beside the LDS rows a global delta row costs a
+        // read under atomic fire and buys no balance — 733 against 708 M triples/s, profiles/r06_hotlds_sweep.txt)
         if (si >= 0) {
           if ((si >> 16) < a.lds_L) irow = lds_row<G, E>(qi, hl, si >> 16, d, gl);
-          else irow = hot_row<G, E>(qi, a.hot_delta, si & 0xFFFF, a.hot_H, a.hot_rmask, wave, d, gl);
+          else if (!a.lds_only) irow = hot_row<G, E>(qi, a.hot_delta, si & 0xFFFF, a.hot_H, a.hot_rmask, wave, d, gl);
         }
         if (sj >= 0) {
           if ((sj >> 16) < a.lds_L) jrow = lds_row<G, E>(qj, hl, sj >> 16, d, gl);
-          else jrow = hot_row<G, E>(qj, a.hot_delta, sj & 0xFFFF, a.hot_H, a.hot_rmask, wave, d, gl);
+          else if (!a.lds_only) jrow = hot_row<G, E>(qj, a.hot_delta, sj & 0xFFFF, a.hot_H, a.hot_rmask, wave, d, gl);
         }
       } else {
         if (si >= 0) irow = hot_row<G, E>(qi, a.hot_delta, si, a.hot_H, a.hot_rmask, wave, d, gl);
@@ -469,7 +490,9 @@ void k_stream(const StreamArgs a) {
     __syncthreads();
     float* const dst = a.hot_delta + (uint32_t)(((int)blockIdx.x & a.hot_rmask) * a.hot_H) * (uint32_t)d;
     const int n_groups = (int)(blockDim.x / G);
-    for (int l = (int)(threadIdx.x / G); l < a.lds_L; l += n_groups) {
+    for (int k = (int)(threadIdx.x / G); k < a.lds_L; k += n_groups) {
+      // (workgroups finish together: each starts its flush at another row)
+      const int l = (int)(((uint32_t)k + blockIdx.x * 7u) % (uint32_t)a.lds_L);
       if (hl_dirty[l] == 0u) continue;
       float* const row = dst + (uint32_t)a.hot_by_rank[l] * (uint32_t)d;
 #pragma unroll

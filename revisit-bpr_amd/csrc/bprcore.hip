@@ -395,6 +395,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     bool use_lds = false;
     size_t shmem_l = 0;
     unsigned block_l = E <= 4 ? 1024 : 512;  // (E >= 8: 64+ registers of rows per lane — two waves per SIMD)
+    if (c->tune_lds_block > 0) block_l = std::min<unsigned>(block_l, (unsigned)c->tune_lds_block);
     c->last_lds_rows = 0;
     if (c->tune_hot_lds > 0 && hot && c->hot_code != nullptr && c->d == G * E && a.snap_meta == nullptr &&
         (sampler == NEG_GIVEN || (force != "csr" && force != "list"))) {
@@ -410,13 +411,24 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
         use_lds = true;
         if (c->run_len <= 0) a.run_len = 8;
         c->last_run_len = a.run_len;
-        const int64_t n_runs_l = (a.n + a.run_len - 1) / a.run_len;
+        // the last tickets of a persistent workgroup are short runs (k_stream: tail1 / tail2), whole wave-loads each
+        // (zones hold whole wave-loads of runs: what is left of the chunk past the last whole wave-load of full
+        // runs always goes in the shortest runs)
+        const int64_t len2 = std::max(1, a.run_len / 2), len3 = std::max(1, a.run_len / 4);
+        const int64_t wl = (int64_t)a.run_len * a.gpw_active;  // triples of a wave-load of full runs
+        int64_t t1 = (int64_t)((double)a.n * (1.0 - c->tune_lds_tail / 100.0)) / wl * wl;
+        int64_t t2 = t1 + (int64_t)((double)(a.n - t1) * 0.6) / (len2 * a.gpw_active) * (len2 * a.gpw_active);
+        if (c->tune_lds_tail <= 0) t1 = t2 = a.n / wl * wl;
+        a.tail1 = (int32_t)t1;
+        a.tail2 = (int32_t)t2;
+        const int64_t n_runs_l = t1 / a.run_len + (t2 - t1) / len2 + (a.n - t2 + len3 - 1) / len3;
         int64_t want_l = n_runs_l;
         if (cap_groups > 0 && want_l > cap_groups) want_l = cap_groups;
         grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(stream_cus(c), (want_l + per_block_l - 1) / per_block_l));
         a.bm_words = sampler == NEG_GIVEN ? 0 : words;
         a.lds_L = (int32_t)L;
         a.hot_by_rank = c->hot_by_rank;
+        a.lds_only = c->hot_tier ? 0 : 1;
         a.hot_slot = c->hot_code;
         shmem_l = bm_bytes + (size_t)L * row_bytes;
         c->last_lds_rows = (int)L;
@@ -1410,6 +1422,8 @@ int bpr_set_tuning(bpr_ctx* c, const char* key, int32_t value) {
   else if (k == "binned_split" && value >= 0 && value <= 4) c->tune_binned_split = value;
   else if (k == "partial_target" && value >= 1 && value <= 1024) c->partial_target = value;
   else if (k == "refresh_sub" && (value == 0 || value == 1 || value == 2 || value == 4)) c->tune_refresh_sub = value;
+  else if (k == "lds_block" && value >= 0 && value <= 1024 && value % 64 == 0) c->tune_lds_block = value;
+  else if (k == "lds_tail" && value >= 0 && value <= 50) c->tune_lds_tail = value;
   else return fail(BPR_ERR_INVALID, "bpr_set_tuning: unknown key or value out of range");
   c->stream_occ.clear();
   return BPR_OK;

