@@ -235,6 +235,12 @@ def parse_args():
                          "negatives concentrate on popular rows and its walks get deeper once the model has moved "
                          "(DESIGN.md §4.1 r5; tools/trained_state_probe.py): a long job sees this number, the first "
                          "epochs from random init see `value`")
+    ap.add_argument("--steady-timed-epochs", type=int, default=100,
+                    help="whole epochs timed for the steady state — the headline `value` (r6): epochs steady-epochs + 1 .. "
+                         "steady-epochs + this many of the same job, by wall clock between barriers")
+    ap.add_argument("--hot-lds", type=int, default=-1,
+                    help="rows of the hot block a CU keeps in LDS during a launch (bpr_set_hot_lds, r6): -1 = by the "
+                         "staleness budget (fast.hot_lds_rows: on at lr 0.001 / 0.01, off at 0.05), 0 = off, n = forced")
     ap.add_argument("--partial-snapshot", type=int, default=0,
                     help="1: the split refresh sorts only the two ends of every snapshot column and buckets the middle "
                          "(bpr_set_tuning partial_snapshot; DESIGN.md §4.3 r5)")
@@ -508,6 +514,10 @@ def main():
         e.set_tuning("partial_target", args.partial_target)
     if args.hot_rows is not None:
         e.set_hot_rows(args.hot_rows, args.hot_replicas)
+    from revisit_bpr.fast import hot_lds_rows
+    lds_rows_asked = hot_lds_rows(args.lr, chunk, cad_world) if args.hot_lds < 0 else args.hot_lds
+    if not batched:
+        e.set_hot_lds(lds_rows_asked)
     main_stream = side_stream = None
     if lag > 0.0 and cus != 0:
         total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -723,8 +733,9 @@ def main():
                 step(k)
             barrier()
             e.timing_enable(max(1, args.time_every))
+            st_epochs = max(1, args.steady_timed_epochs)
             tq = time.perf_counter()
-            for k in range(k_end, k_end + n_chunks):
+            for k in range(k_end, k_end + st_epochs * n_chunks):
                 step(k)
             if sync is not None:
                 sync.hot_finish()
@@ -736,15 +747,17 @@ def main():
             barrier()
             st_kernel_ms, st_launches = e.timing_read()
             e.timing_enable(False)
-            steady_steps = k_end + n_chunks - k_now
+            steady_steps = k_end + st_epochs * n_chunks - k_now
             if world > 1:
                 tt = torch.tensor([st_dt], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 st_dt = float(tt.item())
-            steady = {"epochs_trained_before": k_end // n_chunks, "steps": n_chunks, "ms_per_step": st_dt * 1e3 / n_chunks,
-                      "value": n_chunks * chunk * world / st_dt, "kernel_ms_avg": st_kernel_ms,
-                      "note": "one whole epoch by wall clock after that many epochs of the same job (lr as configured): "
-                              "the state a long training run is in"}
+            steady = {"epochs_trained_before": k_end // n_chunks, "epochs": st_epochs, "steps": st_epochs * n_chunks,
+                      "ms_per_step": st_dt * 1e3 / (st_epochs * n_chunks),
+                      "value": st_epochs * n_chunks * chunk * world / st_dt, "kernel_ms_avg": st_kernel_ms,
+                      "kernel_launches_timed": st_launches,
+                      "note": "whole epochs by wall clock (every bpr_plan_epoch in place, nothing modelled) after that many "
+                              "epochs of the same job (lr as configured): the state a long training run is in"}
         # the epoch plan, timed on its own (3 calls; it does not touch the model)
         tp = time.perf_counter()
         for r in range(3):
@@ -788,9 +801,26 @@ def main():
         triples = args.steps * chunk * world
         region_value = args.steps * chunk * world / dt_measured  # the K-step region as measured (no plan inside unless an epoch began there)
         region_value_with_plan = triples / dt
-        # headline: whole epochs by wall clock (every plan in place, nothing modelled) when they were run
-        value = (sus_epochs * n_chunks * chunk * world / sus_dt) if sus_epochs > 0 else region_value_with_plan
-        ms_per_step = (sus_dt * 1e3 / (sus_epochs * n_chunks)) if sus_epochs > 0 else dt * 1e3 / args.steps
+        # headline (r6): the TRAINED state — whole epochs by wall clock after `--steady-epochs` epochs
+        # of the same job (every plan in place, nothing modelled) — when that leg ran; else the early whole epochs
+        # (`sustained`); else the K-step region.  The early number rides along as `early_state`.
+        early_value = (sus_epochs * n_chunks * chunk * world / sus_dt) if sus_epochs > 0 else region_value_with_plan
+        early_ms = (sus_dt * 1e3 / (sus_epochs * n_chunks)) if sus_epochs > 0 else dt * 1e3 / args.steps
+        early_kernel_ms = kernel_ms
+        if steady is not None:
+            value, ms_per_step, steps_behind = steady["value"], steady["ms_per_step"], steady["steps"]
+            kernel_ms, launches = steady["kernel_ms_avg"], steady["kernel_launches_timed"]
+            value_source = ("steady state: epochs %d..%d of the job (%d whole epochs = %d steps) by wall clock between "
+                            "barriers, every bpr_plan_epoch in place, nothing modelled" %
+                            (steady["epochs_trained_before"] + 1, steady["epochs_trained_before"] + steady["epochs"],
+                             steady["epochs"], steady["steps"]))
+        elif sus_epochs > 0:
+            value, ms_per_step, steps_behind = early_value, early_ms, sus_epochs * n_chunks
+            value_source = ("sustained: %d whole epochs = %d steps from random init by wall clock between barriers, every "
+                            "bpr_plan_epoch in place, nothing modelled" % (sus_epochs, sus_epochs * n_chunks))
+        else:
+            value, ms_per_step, steps_behind = region_value_with_plan, dt * 1e3 / args.steps, args.steps
+            value_source = "the K-step region (+ the plan's amortised share when no epoch began inside it)"
         # SGD reads and writes 3 rows (+ 2 int32 ids); Adam reads and writes w, m, v of 3
         # rows (+ ids + 24 B of per-row step marks); momentum / RMSprop carry one state table
         bytes_per_triple = {"sgd": 24 * d + 8, "adam": 72 * d + 32, "momentum": 48 * d + 32,
@@ -811,13 +841,16 @@ def main():
             "value": value,
             "unit": "triples/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps_behind,  # the steps behind `value` (the driver's K: timed_region.steps)
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "value_source": ("sustained: %d whole epochs = %d steps by wall clock between barriers, every bpr_plan_epoch "
-                             "in place, nothing modelled" % (sus_epochs, sus_epochs * n_chunks)) if sus_epochs > 0 else
-                            "the K-step region (+ the plan's amortised share when no epoch began inside it)",
-            "timed_region": {"steps": args.steps, "ms_per_step_measured": dt_measured * 1e3 / args.steps,
+            "value_source": value_source,
+            "early_state": {"value": early_value, "ms_per_step": early_ms, "kernel_ms_avg": early_kernel_ms,
+                            "roofline_frac": ((bytes_per_triple * chunk) / (early_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                              if early_kernel_ms > 0 else None),
+                            "note": "the same job on tables a few epochs from their random init (what r1-r5 reported as "
+                                    "`value`): the adaptive sampler's negatives are still uniform over the items there"},
+            "timed_region": {"steps": args.steps, "warmup": args.warmup, "ms_per_step_measured": dt_measured * 1e3 / args.steps,
                              "value_measured": region_value, "plans_inside": plans_timed,
                              "value_with_amortised_plan": region_value_with_plan},
             "higher_is_better": True,
@@ -835,6 +868,9 @@ def main():
                             + ("" if lag == 0.0 else f" (snapshot sorted beside the launch: lag {lag:g}, "
                                f"{split} launch(es) per refresh period, sort masked to {cus} CUs)"),
                 "item_bias": bool(args.item_bias),
+                "hot_lds": {"rows_asked": lds_rows_asked if not batched else 0, "rows_in_lds_last_launch": e.stream_lds_rows(),
+                            "rule": "fast.hot_lds_rows: on while lr x 2 x job triples per launch <= 4,000 (a CU sees the other "
+                                    "CUs' updates of these rows one launch late)"},
                 "triples_per_step_per_gpu": chunk,
                 "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus,
                                      "sharded_over_ranks": bool(shard_refresh and not batched)},

@@ -88,6 +88,7 @@ struct bpr_ctx {
   const float* snap_keys[2] = {nullptr, nullptr};
   const int32_t* meta_front = nullptr;
   const float* keys_front = nullptr;
+  bool keys_front_stale = false;  // a later cut has overwritten the key buffer the partial FRONT snapshot was sorted from
   // split refresh (bpr_adaptive_refresh_begin / _commit): the keys are cut on `stream`, the sort
   // runs on `side` while the caller keeps launching on `stream`, commit orders the swap
   hipStream_t side = nullptr;

@@ -2130,6 +2130,7 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
   c->sigma = sigma;
   c->meta_front = c->snap_partial[back] ? c->snap_meta[back] : nullptr;
   c->keys_front = c->snap_keys[back];
+  c->keys_front_stale = false;
   c->have_snapshot = true;
   return BPR_OK;
 }
@@ -2138,6 +2139,14 @@ int refresh_impl(bpr_ctx* c, bool split, int f_lo, int f_hi) {
 // k_stream (the sampler kernels behind the Python API, the batched STREAM kernel, bpr_adaptive_get_snapshot).
 int snapshot_complete_impl(bpr_ctx* c) {
   if (c->meta_front == nullptr || !c->have_snapshot) return BPR_OK;
+  if (c->keys_front_stale) {
+    // the lag-1 pipeline's next cut writes the buffer this partial front was sorted from (the launch that
+    // read the front is over by then); completing it now would sort NEWER keys into an order k_stream never walked
+    set_error("the partial snapshot in front can no longer be completed: a later cut (bpr_train_stream_cut / _acut) "
+              "overwrote the keys it was sorted from — commit the pending refresh (bpr_adaptive_refresh_commit) or "
+              "refresh again before sampling through the API");
+    return BPR_ERR_INVALID;
+  }
   const int front = c->snap_front;
   const int64_t I = c->I;
   int64_t len = (I + 15) / 16 * 16;
@@ -2172,6 +2181,7 @@ int refresh_publish_impl(bpr_ctx* c) {
   c->sigma = c->sigma_buf[back];
   c->meta_front = nullptr;  // (a sharded refresh is always sorted whole)
   c->keys_front = c->snap_keys[back];
+  c->keys_front_stale = false;
   c->have_snapshot = true;
   c->part_pending = false;
   return BPR_OK;
@@ -2189,6 +2199,7 @@ int refresh_commit_impl(bpr_ctx* c) {
   c->sigma = c->sigma_buf[back];
   c->meta_front = c->snap_partial[back] ? c->snap_meta[back] : nullptr;
   c->keys_front = c->snap_keys[back];
+  c->keys_front_stale = false;
   c->have_snapshot = true;
   c->refresh_pending = false;
   return BPR_OK;

@@ -519,6 +519,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       hipExtLaunchKernelGGL(k_stream_epilogue_cut, eg, dim3(256), 0, c->side, nullptr, c->ev_keys, 0, ea);
       BPR_HIP_CHECK(hipGetLastError());
       c->keys_cut = true;
+      if (c->meta_front != nullptr && c->keysT == c->keys_front) c->keys_front_stale = true;
       c->keys_event = true;
       c->keys_on_side = true;  // whoever sorts these keys on the launch stream waits for ev_keys
       c->acut_pending = true;
@@ -551,6 +552,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
         hipLaunchKernelGGL(k_stream_epilogue_cut, eg, dim3(256), 0, c->stream, ea);
       }
       c->keys_cut = true;
+      if (c->meta_front != nullptr && c->keysT == c->keys_front) c->keys_front_stale = true;
       c->keys_event = ride;
     } else if (out_scalars != nullptr || (hot && !c->hot_tier) || bias_in_epilogue) {
       const bool fold = hot && !c->hot_tier;  // hot tier: the deltas stay for bpr_hot_exchange
@@ -957,6 +959,7 @@ int bpr_sample_adaptive(bpr_ctx* c, const int32_t* users, int64_t B, float p, ui
   if (users == nullptr || neg_out == nullptr || B < 0)
     return fail(BPR_ERR_INVALID, "bpr_sample_adaptive: bad argument");
   if (int rc = vs_leave(c)) return rc;  // reads the live user rows
+  if (int rc = snapshot_complete_impl(c)) return rc;  // (sample_args cannot report it)
   SampleArgs a = sample_args(c);
   a.users = users; a.n = B; a.seed = seed; a.offset = offset;
   a.neg = neg_out; a.factor_out = factor_out; a.rank_out = rank_out;
@@ -971,6 +974,7 @@ int bpr_adaptive_pick(bpr_ctx* c, const int32_t* users, const int32_t* factor, c
     return fail(BPR_ERR_INVALID, "bpr_adaptive_pick: seen CSR / snapshot missing");
   if (!users || !factor || !rank || !neg_out || B < 0)
     return fail(BPR_ERR_INVALID, "bpr_adaptive_pick: bad argument");
+  if (int rc = snapshot_complete_impl(c)) return rc;  // (sample_args cannot report it)
   SampleArgs a = sample_args(c);
   a.users = users; a.factor_in = factor; a.rank_in = rank; a.n = B; a.neg = neg_out;
   return launch_sample(c, SAMPLE_PICK, a);
@@ -1101,6 +1105,9 @@ static int train_stream_impl(bpr_ctx* c, const int32_t* users, const int32_t* po
   a.P = c->P; a.Q = c->Q; a.bias = c->bias;
   a.indptr = c->indptr; a.indices = c->indices;
   a.order = c->order; a.sigma = c->sigma;
+  if (c->meta_front != nullptr && c->keys_front_stale)
+    return fail(BPR_ERR_INVALID, "bpr_train_stream: the partial snapshot in front was sorted from keys a later cut has "
+                                 "overwritten; commit the pending refresh first");
   a.snap_meta = c->meta_front;
   a.snap_keys = c->meta_front != nullptr ? c->keys_front : nullptr;
   a.users = users; a.pos = pos; a.neg = neg;

@@ -389,8 +389,14 @@ class StreamTrainer:
         if self._main is not None:
             self._main.torch.wait_stream(torch.cuda.current_stream(self.users.device))
         # from here to epoch_end nobody but the launches writes the item_bias: they may keep their
-        # one-item-per-line copy of it instead of re-reading the vector every launch
-        self.engine.set_bias_tracking(True)
+        # one-item-per-line copy of it instead of re-reading the vector every launch — unless an item
+        # reconciliation carries the bias too (several ranks): ItemSync folds the other ranks' bias deltas into
+        # the vector BETWEEN launches, through entry points that know no ctx, so every launch must refill
+        # (with tracking on, the next launch's epilogue wrote its stale copy back over the
+        # reconciled vector and the replicas drifted)
+        sync_writes_bias = self.item_sync is not None and self.engine.item_bias is not None and any(
+            t.data_ptr() == self.engine.item_bias.data_ptr() for t in self.item_sync.tensors)
+        self.engine.set_bias_tracking(not sync_writes_bias)
 
     def epoch_end(self) -> dict:
         self.engine.set_bias_tracking(False)

@@ -23,7 +23,8 @@ def _line(res):
 
 def test_bench_single_gpu_line():
     res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--scale", "0.05", "--steps", "6",
-                          "--warmup", "2", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900)
+                          "--warmup", "2", "--cpu-seconds", "1", "--steady-timed-epochs", "3"],
+                         capture_output=True, text=True, timeout=900)
     j = _line(res)
     assert j["n_gpus"] == 1 and j["unit"] == "triples/s" and j["value"] > 1e6 and j["dtype"] == "f32"
     assert j["vs_baseline"] is None and j["higher_is_better"] is True and j["data"] == "synthetic"
@@ -34,16 +35,21 @@ def test_bench_single_gpu_line():
     assert j["cpu_baseline"]["cores"] >= 1 and j["cpu_baseline"]["value"] > 0
     sched = j["config"]["refresh_schedule"]
     assert sched["lag"] == 1.0 and sched["side_stream_cus"] >= 32  # the schedule the gates hold (32 CUs since the binned sort)
-    sus = j["sustained"]  # whole epochs, every plan in place
-    st = j["steady_state"]  # one epoch timed after 30 epochs of the same job: the trained state
+    sus = j["sustained"]  # whole epochs from random init, every plan in place
+    st = j["steady_state"]  # whole epochs timed after 30 epochs of the same job: the trained state, the headline
     spe = j["config"]["steps_per_epoch"]
-    assert st["epochs_trained_before"] >= 30 and st["steps"] == spe and st["value"] > 1e6
-    trained = st["epochs_trained_before"] * spe + spe - ((6 + 2 + 1) // spe + 1 + sus["epochs"]) * spe
+    assert st["epochs_trained_before"] >= 30 and st["steps"] == st["epochs"] * spe and st["value"] > 1e6
+    trained = (st["epochs_trained_before"] + st["epochs"]) * spe - ((6 + 2 + 1) // spe + 1 + sus["epochs"]) * spe
     assert j["config"]["triples_counted_by_kernel"] == (6 + sus["steps"] + trained) * j["config"]["triples_per_step_per_gpu"]
     assert sus["epochs"] >= 3 and sus["value"] > 1e6 and 0 < r["read_only_frac"] < r["frac"]
-    # the headline is the whole-epoch wall-clock number; the K-step region rides along, nothing modelled in it
-    assert j["value"] == sus["value"] and j["value_source"].startswith("sustained")
+    # r6: the headline is the TRAINED state's whole-epoch wall-clock number, `steps` the steps behind it; the early
+    # state and the driver's K-step region ride along, nothing modelled in either
+    assert j["value"] == st["value"] and j["value_source"].startswith("steady state") and j["steps"] == st["steps"]
+    assert j["early_state"]["value"] == sus["value"] and 0 < j["early_state"]["roofline_frac"] < 1
+    assert r["kernel_ms_avg"] == st["kernel_ms_avg"] and j["ms_per_step"] == st["ms_per_step"]
     assert j["timed_region"]["steps"] == 6 and j["timed_region"]["value_measured"] > 1e6
+    lds = j["config"]["hot_lds"]  # lr 0.001: inside the staleness budget -> asked for; a 5 % shard's launches may not fill the chip
+    assert lds["rows_asked"] > 0 and lds["rows_in_lds_last_launch"] >= 0
     assert j["config"]["parity"]["tolerance_north_star"] == 0.002
     port = j["cpu_baseline_c_port"]  # the C restatement with OpenMP over triples
     assert port["kind"] == "port" and port["cores"] >= 1 and port["value"] > 0 and "OpenMP" in port["sample"]

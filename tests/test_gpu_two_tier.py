@@ -263,3 +263,71 @@ def test_cut_launch_under_the_hot_tier_keeps_its_statistics_without_sync_cut():
         totals.append(sc.cpu().numpy())
     # the same triples with the same negatives (max_inflight = 1: sequential): the same sums
     assert np.allclose(totals[0], totals[1], rtol=1e-5) and np.allclose(totals[0], totals[2], rtol=1e-4)
+
+
+def test_two_ranks_with_an_item_bias_keep_the_reconciled_vector(monkeypatch):
+    """`StreamTrainer.epoch_begin` switched the launches' bias tracking on unconditionally — but
+    with several ranks ItemSync folds the other ranks' item_bias deltas into the vector BETWEEN launches (through
+    ctx-less entry points), so the next launch trained on a stale one-item-per-line copy and its epilogue wrote that
+    copy back over the reconciled vector.  Two in-process ranks, the model of the RQ configs (item_bias on),
+    ItemSync([item, item_bias]); one group in flight per launch so that a run is deterministic: the product must
+    equal the same job with tracking forced off (every launch refills), the replicas must agree, the bias must
+    have moved on both."""
+    from revisit_bpr import engine as eng
+    from revisit_bpr.distributed import ItemSync, LocalWorld
+    from revisit_bpr.fast import StreamTrainer
+    from revisit_bpr.models import BPR
+    from revisit_bpr.models.bpr import MF
+
+    U, I, d, n = 300, 120, 64, 2400
+    _, _, indptr, indices, users, pos = _problem(U, I, d, n, seed=11)
+    dev = torch.device("cuda")
+    own = (users >= U // 2).astype(np.int64)
+    u_d, p_d = torch.from_numpy(users).to(dev), torch.from_numpy(pos).to(dev)
+
+    def job(force_off):
+        if force_off:
+            real = eng.Engine.set_bias_tracking
+            monkeypatch.setattr(eng.Engine, "set_bias_tracking", lambda self, on: real(self, False))
+        lw = LocalWorld(2)
+        trs, feats = [], []
+        for r in range(2):
+            torch.manual_seed(13)
+            model = BPR(fuse_forward=True, reg_alphas={"user": 0.0025, "item": 0.0025, "neg": 0.00025},
+                        logits_model=MF(torch.nn.Embedding(U, d, padding_idx=0), torch.nn.Embedding(I, d, padding_idx=0),
+                                        item_bias=True)).to(dev)
+            f = model.logits_model.get_features()
+            mine = torch.from_numpy(own == r).to(dev)
+            sync = ItemSync([f["item"].data, f["item_bias"].data], comm=lw.member(r), engine=model.engine())
+            trs.append(StreamTrainer(model, u_d[mine].contiguous(), p_d[mine].contiguous(), torch.from_numpy(indptr).to(dev),
+                                     torch.from_numpy(indices).to(dev), lr=0.05, sampler="uniform", batch_size=64, seed=3,
+                                     rank=r, item_sync=sync, world=2, max_inflight=1))
+            feats.append(f)
+        assert trs[0].rounds > 2  # several reconciliations inside an epoch
+        for _ in range(3):
+            for tr in trs:
+                tr.epoch_begin()
+            gens = [tr.epoch_iter() for tr in trs]
+            alive = True
+            while alive:
+                alive = False
+                for tr, g in zip(trs, gens):
+                    try:
+                        next(g)
+                        alive = True
+                    except StopIteration:
+                        pass
+            for tr in trs:
+                tr.epoch_end()
+        out = [(f["item"].data.clone(), f["item_bias"].data.clone()) for f in feats]
+        for tr in trs:
+            tr.item_sync.close()
+        monkeypatch.undo()
+        return out
+
+    got, want = job(False), job(True)
+    for r in range(2):
+        assert got[r][1].abs().max().item() > 1e-3  # the bias learned something
+    assert (got[0][1] - got[1][1]).abs().max().item() < 1e-6 and (got[0][0] - got[1][0]).abs().max().item() < 1e-5
+    assert (got[0][1] - want[0][1]).abs().max().item() < 1e-5, (got[0][1] - want[0][1]).abs().max().item()
+    assert (got[0][0] - want[0][0]).abs().max().item() < 1e-5
