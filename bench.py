@@ -507,6 +507,7 @@ def main():
     src_users = torch.from_numpy(data.users).to(dev)
     src_items = torch.from_numpy(data.items).to(dev)
     users_e, items_e = torch.empty_like(src_users), torch.empty_like(src_items)
+    users_sorted = eng.Engine.users_sorted(src_users)  # the triple list in CSR order: bpr_plan_epoch takes one radix pass
     e.set_stream_opts(not args.ungrouped, args.run_len)
     e.set_bias_tracking(True)  # this loop owns the item_bias between its launches (as fast.StreamTrainer's does)
     if args.partial_snapshot:
@@ -618,14 +619,14 @@ def main():
                     cur[0], ev = pre.pop(ep)
                     torch.cuda.current_stream().wait_event(ev)
                 else:
-                    e.plan_epoch(src_users, src_items, chunk, seed + ep, out=ebuf[cur[0]])
+                    e.plan_epoch(src_users, src_items, chunk, seed + ep, out=ebuf[cur[0]], sorted_input=users_sorted)
                 if plan_ahead:
                     nxt = cur[0] ^ 1
                     ev0 = torch.cuda.Event()
                     ev0.record()  # the launches that read that buffer last (the previous epoch's) are all queued
                     with torch.cuda.stream(plan_stream.torch):
                         plan_stream.torch.wait_event(ev0)
-                        e.plan_epoch(src_users, src_items, chunk, seed + ep + 1, out=ebuf[nxt])
+                        e.plan_epoch(src_users, src_items, chunk, seed + ep + 1, out=ebuf[nxt], sorted_input=users_sorted)
                         ev = torch.cuda.Event()
                         ev.record()
                     e._sync_stream()  # the library back on this stream
@@ -764,7 +765,7 @@ def main():
             if batched:
                 e.shuffle_epoch(src_users, src_items, seed + 1000 + r, out=(users_e, items_e))
             else:
-                e.plan_epoch(src_users, src_items, chunk, seed + 1000 + r, out=(users_e, items_e))
+                e.plan_epoch(src_users, src_items, chunk, seed + 1000 + r, out=(users_e, items_e), sorted_input=users_sorted)
         torch.cuda.synchronize()
         plan_ms = (time.perf_counter() - tp) * 1e3 / 3
     plans_timed = sum(1 for k in range(first, first + args.steps) if k % n_chunks == 0)

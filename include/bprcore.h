@@ -416,6 +416,9 @@ int bpr_stream_lds_rows(bpr_ctx* ctx);
  *   "binned_split" 0 (default: workgroups per column by table size) / 1..4 (tests force the split kernel on small tables);
  *   "lds_block" 0 (default: 1,024 threads for d <= 256 at 32-lane groups, 512 above) / a multiple of 64: threads per
  *               workgroup of the LDS-tier kernel (bpr_set_hot_lds) — fewer groups leave more LDS for hot rows;
+ *   "plan_input_sorted" 0 (default) / 1: a PROMISE that the users_in handed to bpr_plan_epoch are sorted by user id (the
+ *               triple list in CSR order, as every loader of this repository makes it): the plan — same output — then
+ *               takes one radix pass over the chunk bits instead of three over (chunk, user);
  *   "lds_tail"  0..50 (default 12): percent of a launch's triples the LDS-tier kernel deals in runs of run_len / 2 and
  *               run_len / 4 at the end of every persistent workgroup's share (a workgroup is over when its last run is). */
 int bpr_set_tuning(bpr_ctx* ctx, const char* key, int32_t value);

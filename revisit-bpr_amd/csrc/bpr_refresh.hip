@@ -1453,16 +1453,18 @@ int plan_epoch_impl(bpr_ctx* c, const int32_t* users_in, const int32_t* pos_in, 
     uint32_t* k32s = reinterpret_cast<uint32_t*>(c->plan_keys_sorted);
     hipLaunchKernelGGL(k_plan_keys<uint32_t>, dim3(grid), dim3(256), 0, c->stream, users_in, n,
                        chunk, half_bits, ubits, seed, k32);
+    // (input promised sorted by user — bpr_set_tuning "plan_input_sorted": a STABLE sort on the chunk bits alone
+    // leaves every chunk grouped by user, the same output in one radix pass instead of three)
     BPR_HIP_CHECK(rocprim::radix_sort_pairs(c->plan_tmp, bytes, k32, k32s, pos_in, pos_out,
-                                                     (int)n, 0, ubits + cbits, c->stream));
+                                                     (int)n, c->tune_plan_sorted ? ubits : 0, ubits + cbits, c->stream));
     hipLaunchKernelGGL(k_plan_users<uint32_t>, dim3(grid), dim3(256), 0, c->stream, k32s, n, ubits,
                        users_out);
   } else {
     hipLaunchKernelGGL(k_plan_keys<uint64_t>, dim3(grid), dim3(256), 0, c->stream, users_in, n,
                        chunk, half_bits, ubits, seed, c->plan_keys);
     BPR_HIP_CHECK(rocprim::radix_sort_pairs(c->plan_tmp, bytes, c->plan_keys,
-                                                     c->plan_keys_sorted, pos_in, pos_out, (int)n, 0,
-                                                     ubits + cbits, c->stream));
+                                                     c->plan_keys_sorted, pos_in, pos_out, (int)n,
+                                                     c->tune_plan_sorted ? ubits : 0, ubits + cbits, c->stream));
     hipLaunchKernelGGL(k_plan_users<uint64_t>, dim3(grid), dim3(256), 0, c->stream,
                        c->plan_keys_sorted, n, ubits, users_out);
   }

@@ -1431,6 +1431,7 @@ int bpr_set_tuning(bpr_ctx* c, const char* key, int32_t value) {
   else if (k == "refresh_sub" && (value == 0 || value == 1 || value == 2 || value == 4)) c->tune_refresh_sub = value;
   else if (k == "lds_block" && value >= 0 && value <= 1024 && value % 64 == 0) c->tune_lds_block = value;
   else if (k == "lds_tail" && value >= 0 && value <= 50) c->tune_lds_tail = value;
+  else if (k == "plan_input_sorted" && (value == 0 || value == 1)) c->tune_plan_sorted = value;
   else return fail(BPR_ERR_INVALID, "bpr_set_tuning: unknown key or value out of range");
   c->stream_occ.clear();
   return BPR_OK;

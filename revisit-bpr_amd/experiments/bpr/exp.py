@@ -80,6 +80,7 @@ class BPRExperiment:
                     counts[rec["item"]] = float(rec["count"]) ** neg_sampling_alpha
             self._item_counts = counts
         self._state = None
+        self._eval_fused = False
         self.history: list[dict] = []
 
     @property
@@ -135,6 +136,8 @@ class BPRExperiment:
         loaders = self._datasets
         if self._train_mode != "api":
             loaders = self._install_fast_epochs(max_iters)
+            if self._can_fuse_eval(max_iters):
+                loaders = self._install_fast_eval(loaders)
         elif isinstance(self._adaptive_p, float):
             self._sampler.update_stats()
         self._state = self.trainer.run(loaders, max_iters=max_iters, epochs=cfg["epochs"])
@@ -144,15 +147,37 @@ class BPRExperiment:
         return self._state
 
     def _pick_train_mode(self) -> str:
-        from torch.utils.data import RandomSampler
+        """`auto`: whole epochs inside the library when nothing can tell the difference — the fused model on a ROCm
+        device, the in-memory sparse dataset behind a plain shuffling DataLoader (default batch sampler, no
+        drop_last), no custom engines, no user handlers on the train engine, not the debug run — and then
+          "stream"  for plain SGD while the launch is inside the staleness budget (`fast.lag_within_budget`: the rule
+                    tests/test_gpu_fullscale_reference.py pins to the reference's own loop and to exact mini-batches),
+          "strict"  otherwise (the reference's mini-batches, any optimizer, any learning rate);
+        else "api", the reference's per-batch loop.  The choice is logged."""
+        from torch.utils.data import BatchSampler, RandomSampler
 
         loader = self._datasets.get("train")
         ds = getattr(loader, "dataset", None)
         fused = hasattr(self._model, "train_strict") and next(self._model.parameters()).is_cuda
         in_memory = hasattr(ds, "_user_ids") and hasattr(ds, "seen_csr")
         shuffled = isinstance(getattr(loader, "sampler", None), RandomSampler)
-        observed = bool(self._events.get("train")) or self._debug
-        return "strict" if (fused and in_memory and shuffled and not observed) else "api"
+        plain_loader = (type(getattr(loader, "batch_sampler", None)) is BatchSampler
+                        and not getattr(loader, "drop_last", False))
+        observed = bool(self._events.get("train")) or self._debug or bool(self._config.get("custom_engines"))
+        mode = "api"
+        if fused and in_memory and shuffled and plain_loader and not observed:
+            mode = "strict"
+            opt = self._optimizer
+            group = opt.param_groups[0]
+            if type(opt).__name__ == "SGD" and group.get("momentum", 0) == 0 and self._item_counts is None:
+                from revisit_bpr.fast import lag_within_budget
+
+                num_items = self._config["num_items"]
+                period = max(1, int(num_items * math.log(num_items) / (loader.batch_size or 1))) * (loader.batch_size or 1)
+                if lag_within_budget(float(group["lr"]), min(period, len(ds))):
+                    mode = "stream"
+        log.info("train_mode auto -> %s", mode)
+        return mode
 
     def interrupt(self) -> None:
         for engine in self.trainer.engines.values():
@@ -269,6 +294,80 @@ class BPRExperiment:
 
         self.trainer.engines["train"]._process = epoch_step
         return {**self._datasets, "train": [{"epoch": True}]}
+
+    # ---- the evaluation as ONE pass (r6) --------------------------------------------------------
+    def _can_fuse_eval(self, max_iters: dict) -> bool:
+        """The eval engine's per-batch loop — DataLoader -> [B, I] target + padded seen matrix on the host ->
+        model(batch) -> 14 metric objects, each ranking the [B, I] scores again (exp.py:369-374 of the reference) —
+        is replaced by `revisit_bpr.evaluation.evaluate_topk` (one GEMM + one top-k per block of users for every
+        NDCG / Recall / Precision at every k; ROC-AUC by counting) when nothing can tell the difference: whole
+        epochs already run inside the library, seen items are masked (`skip_seen`), the eval set is `InMemory`
+        behind `AllItemsCollator`, every metric is one of those (NDCG with the default gain), nobody listens to
+        the eval engine's iterations and no eval iteration cap is set."""
+        from experiments.bpr.dataset import AllItemsCollator, InMemory
+        from revisit_bpr.metrics import NDCG, Precision, Recall
+        from revisit_bpr.metrics.auc import RocAucMany, RocAucManySlow
+
+        loader = self._datasets.get("eval")
+        if loader is None or not self._skip_seen or max_iters.get("eval") is not None or self._events.get("eval"):
+            return False
+        if not isinstance(getattr(loader, "dataset", None), InMemory) or \
+                not isinstance(getattr(loader, "collate_fn", None), AllItemsCollator):
+            return False
+        for m in self._metrics.values():
+            if isinstance(m, NDCG) and getattr(m, "_gain", "exp") != "exp":
+                return False
+            if not isinstance(m, (NDCG, Recall, Precision, RocAucMany, RocAucManySlow)):
+                return False
+        mf = getattr(self._model, "logits_model", None)
+        return bool(self._metrics) and mf is not None and hasattr(mf, "get_features") and \
+            mf.get_features().get("user_bias") is None and next(self._model.parameters()).is_cuda
+
+    def _install_fast_eval(self, loaders: dict) -> dict:
+        from revisit_bpr.evaluation import evaluate_topk
+        from revisit_bpr.metrics import NDCG, Precision, Recall
+
+        dev = self._accelerator.device
+        ds = self._datasets["eval"].dataset
+        num_users = self._config["num_users"]
+        users = np.asarray([smp["user"] for smp in ds._samples], np.int64)
+        tcnt = np.asarray([len(smp["item"]) for smp in ds._samples], np.int64)
+        titems = np.concatenate([np.asarray(smp["item"], np.int64) for smp in ds._samples]) if len(users) else \
+            np.zeros(0, np.int64)
+        if len(np.unique(users)) != len(users):
+            raise ValueError("fused evaluation: an eval user appears twice")
+        scnt = np.zeros(num_users, np.int64)
+        seen_rows = [np.asarray(ds._seen[int(u)], np.int64) for u in users]
+        scnt[users] = [len(r) for r in seen_rows]
+        order = np.argsort(users, kind="stable")
+        sflat = np.concatenate([seen_rows[k] for k in order]) if len(users) else np.zeros(0, np.int64)
+        t = {"users": torch.from_numpy(users.astype(np.int32)).to(dev),
+             "eval_indptr": torch.from_numpy(np.concatenate([[0], np.cumsum(tcnt)])).to(dev),
+             "eval_items": torch.from_numpy(titems.astype(np.int32)).to(dev),
+             "seen_indptr": torch.from_numpy(np.concatenate([[0], np.cumsum(scnt)])).to(dev),
+             "seen_indices": torch.from_numpy(sflat.astype(np.int32)).to(dev)}
+        names = {}
+        for name, m in self._metrics.items():
+            names[name] = (f"ndcg@{m._topk}" if isinstance(m, NDCG) else f"recall@{m._topk}" if isinstance(m, Recall)
+                           else f"precision@{m._topk}" if isinstance(m, Precision) else "auc")
+        ks = tuple(sorted({m._topk for m in self._metrics.values() if hasattr(m, "_topk")})) or (1,)
+        want_auc = "auc" in names.values()
+
+        def eval_step(engine, _batch) -> dict:
+            self._model.eval()
+            f = self._model.logits_model.get_features()
+            out = evaluate_topk(f["user"].detach(), f["item"].detach(),
+                                None if f.get("item_bias") is None else f["item_bias"].detach(), t["users"],
+                                t["eval_indptr"], t["eval_items"], t["seen_indptr"], t["seen_indices"], ks=ks,
+                                auc=want_auc)
+            for name, key in names.items():
+                engine.state.metrics[name] = torch.tensor(out[key], device=dev)
+            return {}
+
+        self.trainer.engines["eval"]._process = eval_step
+        self._eval_fused = True
+        log.info("evaluation fused into one pass over %d users (evaluate_topk)", len(users))
+        return {**loaders, "eval": [{"epoch": True}]}
 
     # ---- handlers ---------------------------------------------------------------------------
     def _to_device(self, engine) -> None:

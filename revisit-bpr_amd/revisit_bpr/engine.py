@@ -611,16 +611,26 @@ class Engine:
         native.check(self._lib.bpr_hot_tier_end(self._ctx))
 
     def plan_epoch(self, users: torch.Tensor, pos: torch.Tensor, chunk: int, seed: int,
-                   out: Optional[tuple[torch.Tensor, torch.Tensor]] = None):
-        """Shuffle the training triples into chunks of `chunk`, each grouped by user (on device)."""
+                   out: Optional[tuple[torch.Tensor, torch.Tensor]] = None, sorted_input: bool = False):
+        """Shuffle the training triples into chunks of `chunk`, each grouped by user (on device).
+        sorted_input: a PROMISE that `users` is sorted by user id (`users_sorted` checks it once per training
+        set): the same plan in one radix pass instead of three (bpr_set_tuning "plan_input_sorted")."""
         self._sync_stream()
         if users.dtype != torch.int32 or pos.dtype != torch.int32:
             raise ValueError("plan_epoch takes int32 id tensors")
+        if bool(sorted_input) != getattr(self, "_plan_sorted", False):
+            self._plan_sorted = bool(sorted_input)
+            self.set_tuning("plan_input_sorted", int(self._plan_sorted))
         uo, po = out if out is not None else (torch.empty_like(users), torch.empty_like(pos))
         native.check(self._lib.bpr_plan_epoch(self._ctx, users.data_ptr(), pos.data_ptr(),
                                               users.numel(), chunk, seed, uo.data_ptr(),
                                               po.data_ptr()))
         return uo, po
+
+    @staticmethod
+    def users_sorted(users: torch.Tensor) -> bool:
+        """Is the triple list in CSR order (sorted by user)?  One pass + one host read: call it once per training set."""
+        return bool(users.numel() < 2 or (users[1:] >= users[:-1]).all().item())
 
     def plan_chunk(self, users: torch.Tensor, pos: torch.Tensor, chunk: int, seed: int, index: int,
                    out: tuple[torch.Tensor, torch.Tensor], on_side: bool = False) -> None:

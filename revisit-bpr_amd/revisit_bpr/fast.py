@@ -146,7 +146,7 @@ class StreamTrainer:
                  refresh_lag: float | str = 0.0, refresh_split: int = 1, refresh_cus: int = 0,
                  shard_refresh: bool = False, cadence: str = "job", hot_split: int = 1,
                  rounds: Optional[int] = None, jit_plan: bool = False, async_cut: bool = False,
-                 hot_lds: int | str = "auto") -> None:
+                 hot_lds: int | str = "auto", launch_split: int | str = 1) -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
         adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302.
@@ -187,6 +187,12 @@ class StreamTrainer:
         the model; the sorter idles ~40 us per step), and `adaptive_refresh_commit` waits for both.
         Same chunks as `bpr_plan_epoch` makes (same members, grouped by user).
 
+        launch_split k (refresh_lag 0, one GPU): a refresh period runs as k launches that read the SAME snapshot —
+        a launch walks its triples grouped by user, so a user's triples of a period are otherwise applied back to
+        back; k launches deal them into k groups placed apart, as the reference's shuffled mini-batches do.  "auto":
+        2 outside the staleness budget (high learning rates: STREAM's Recall@20 at the end of the first lr-0.05
+        epoch at the ML-20M shape, -0.0023 with one launch per period: profiles/r06_parity_study.md), else 1.
+
         hot_lds: rows of the hot block a CU keeps in LDS during a launch (`bpr_set_hot_lds`; r6): "auto" =
         `hot_lds_rows` — on inside the staleness budget, off outside; 0 = off; n = asked for whatever the rate.
 
@@ -204,6 +210,7 @@ class StreamTrainer:
         self.engine = model.engine()
         self.users, self.items = users.contiguous(), items.contiguous()
         self.n = users.numel()
+        self._users_sorted = eng.Engine.users_sorted(self.users)  # (CSR order: the plan takes one radix pass)
         self.engine.bind_seen_csr(seen_indptr, seen_indices)
         model._has_csr = True
         self.engine.set_optimizer(eng.OPT_SGD, lr=lr)
@@ -221,7 +228,15 @@ class StreamTrainer:
         self.cadence = cadence
         per_period = (max(world, 1) if cadence == "job" else 1 if cadence == "rank" else
                       launches_per_period(lr, max(world, 1), every * batch_size, STALENESS_BUDGET))
-        self.chunk = max(1, min(every * batch_size // (per_period * refresh_split), self.n))
+        if isinstance(launch_split, str):
+            if launch_split != "auto":
+                raise ValueError("launch_split must be an int >= 1 or 'auto'")
+            launch_split = 1 if (max(world, 1) > 1 or refresh_split != 1 or (not auto_lag and refresh_lag != 0.0)
+                                 or lag_within_budget(lr, every * batch_size)) else 2
+        self.launch_split = max(1, int(launch_split))
+        if self.launch_split > 1 and (item_sync is not None or refresh_split != 1):
+            raise ValueError("launch_split > 1: one GPU, refresh_split 1")
+        self.chunk = max(1, min(every * batch_size // (per_period * refresh_split * self.launch_split), self.n))
         self.hot_split = max(1, int(hot_split))
         self.hot_lds = hot_lds_rows(lr, self.chunk, max(world, 1)) if isinstance(hot_lds, str) else int(hot_lds)
         self.engine.set_hot_lds(self.hot_lds)
@@ -242,6 +257,8 @@ class StreamTrainer:
                           "(profiles/r05_fullepoch_reference.md); refresh_lag='auto' picks by learning rate",
                           stacklevel=2)
         self.refresh_lag = float(refresh_lag) if self.sampler == eng.NEG_ADAPTIVE else 0.0
+        if self.refresh_lag != 0.0 and self.launch_split > 1:
+            raise ValueError("launch_split > 1 needs refresh_lag 0")
         self.shard_refresh = bool(shard_refresh) and item_sync is not None and item_sync.world > 1
         if self.shard_refresh and self.refresh_lag != 0.0:
             raise ValueError("shard_refresh needs refresh_lag = 0")
@@ -318,7 +335,7 @@ class StreamTrainer:
         if lag == 0.0:
             if self.shard_refresh:
                 e.adaptive_refresh_sharded(self.item_sync.rank, self.item_sync.world, self.item_sync.group)
-            else:
+            elif (lo // self.chunk) % self.launch_split == 0:  # (launch_split: the period's later launches reuse it)
                 e.adaptive_refresh()
             yield from self._launch(lo, hi)
             return
@@ -416,7 +433,7 @@ class StreamTrainer:
         self.model._reset_reg()
         if not self.jit_plan:
             e.plan_epoch(self.users, self.items, self.chunk, self.seed + self.epoch,
-                         out=(self._pu, self._pi))
+                         out=(self._pu, self._pi), sorted_input=self._users_sorted)
         self._scalars.zero_()
         hot = self.item_sync is not None and self.item_sync.hot_tier
         for k in range(self.rounds):

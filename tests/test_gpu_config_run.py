@@ -55,5 +55,51 @@ def test_config_run_learns(tmp_path, variant, mode):
     assert 0.5 < evals[-1]["auc"] <= 1.0
     assert trains[-1]["bpr_loss"] < trains[0]["bpr_loss"]
     assert (tmp_path / "exp" / "history.json").exists()
-    if mode == "auto":  # nothing observes single iterations here: the epochs ran inside the library
-        assert exp._train_mode == "strict"
+    if mode == "auto":  # nothing observes single iterations here: the epochs ran inside the library —
+        # plain SGD inside the staleness budget on the fused STREAM path (r6), anything else as exact mini-batches
+        assert exp._train_mode == ("stream" if variant == "uniform-sgd-bias" else "strict")
+
+
+def test_fused_evaluation_equals_the_eval_engine_loop(tmp_path):
+    """r6: with whole epochs inside the library the evaluation is ONE pass too (`evaluate_topk` instead of the
+    eval engine's DataLoader -> model(batch) -> 4 metric objects): the same numbers for the same model — the
+    untrained one both runs evaluate before their first epoch, and the per-batch run's final model put through
+    the fused pass."""
+    from click.testing import CliRunner
+
+    from experiments import run as run_mod
+    from experiments.bpr.dataset import AllItemsCollator
+    from revisit_bpr.datasets import interactions, synthetic
+
+    data = synthetic.generate_latent(900, 320, 24000, seed=6)
+    interactions.write_dataset(data, tmp_path / "data")
+    extra = (f"dataset={tmp_path / 'data'};num_users={data.num_users - 1};num_items={data.num_items - 1};"
+             "embedding_dim=32;train_batch_size=256;epochs=2")
+    runs = {}
+    for mode in ("api", "strict"):
+        res = CliRunner().invoke(run_mod.main, [str(CONFIG), "--extra-vars", extra, "--train-mode", mode],
+                                 catch_exceptions=False, standalone_mode=False)
+        runs[mode] = res.return_value
+    fused, loop = runs["strict"], runs["api"]
+    assert fused._eval_fused and not loop._eval_fused  # one pseudo-batch per evaluation: the fused pass ran
+    e_f = [r for r in fused.history if r["engine"] == "eval"]
+    e_l = [r for r in loop.history if r["engine"] == "eval"]
+    for key in ("ndcg@100", "recall@20", "precision@10", "auc"):
+        assert abs(e_f[0][key] - e_l[0][key]) < 2e-6, (key, e_f[0][key], e_l[0][key])  # the same untrained model
+    # the same TRAINED model both ways: the api run's model through the fused pass
+    import torch as _t
+
+    from revisit_bpr.evaluation import evaluate_topk
+
+    step = fused.trainer.engines["eval"]._process
+    fused._model.load_state_dict(loop._model.state_dict())
+    _t.cuda.synchronize()
+
+    class _E:
+        class state:
+            metrics = {}
+
+    step(_E, None)
+    for key in ("ndcg@100", "recall@20", "precision@10", "auc"):
+        assert abs(float(_E.state.metrics[key]) - e_l[-1][key]) < 2e-6, (key, float(_E.state.metrics[key]), e_l[-1][key])
+    assert isinstance(loop._datasets["eval"].collate_fn, AllItemsCollator) and evaluate_topk is not None

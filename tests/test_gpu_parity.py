@@ -685,6 +685,28 @@ def test_plan_epoch_is_a_grouped_random_partition():
     assert 0.4 < first_user_share < 0.6, first_user_share
 
 
+@pytest.mark.parametrize("n,chunk,U", [(50_000, 4096, 3000), (1_000_003, 65_536, 140_000), (9_000, 9_000, 500)])
+def test_plan_epoch_sorted_input_promise_gives_the_same_plan(n, chunk, U):
+    """r6: with the triple list in CSR order (sorted by user — what every loader here makes) a STABLE sort on the
+    chunk bits alone leaves every chunk grouped by user: `plan_epoch(sorted_input=True)` is the same plan, bit for
+    bit, in one radix pass instead of three; `Engine.users_sorted` is the check the trainers run once."""
+    from revisit_bpr.engine import Engine
+
+    rng = np.random.default_rng(n)
+    users = np.sort(rng.integers(1, U, n)).astype(np.int32)
+    pos = rng.integers(1, 5000, n).astype(np.int32)
+    P, Q = np.zeros((U, 32), np.float32), np.zeros((5000, 32), np.float32)
+    e = make_engine(P, Q)
+    tu, tp = dev(users), dev(pos)
+    assert Engine.users_sorted(tu) and not Engine.users_sorted(dev(users[::-1].copy()))
+    for seed in (3, 4):
+        a = e.plan_epoch(tu, tp, chunk, seed)
+        b = e.plan_epoch(tu, tp, chunk, seed, sorted_input=True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        c = e.plan_epoch(tu, tp, chunk, seed)  # and back
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+
+
 @pytest.mark.parametrize("d,run_len", [(200, 4), (256, 8), (256, 3), (512, 1), (1024, 5)])
 def test_stream_grouped_sequential_equals_b1_sgd(d, run_len):
     """(G = 64 dims only: one group per wave, so max_inflight=1 is truly sequential.)

@@ -47,6 +47,9 @@ VARIANTS = {
     "timed_nolds": dict(refresh_lag=1.0, refresh_cus=-1, hot_lds=0),
     "reference_lds": dict(hot_lds=512),
     "reference_nolds": dict(hot_lds=0),
+    # r6: a period as 2 / 4 launches reading the same snapshot (a user's triples of a period no longer back to back)
+    "ref_lsplit2": dict(launch_split=2, hot_lds=0),
+    "ref_lsplit4": dict(launch_split=4, hot_lds=0),
 }
 
 
@@ -117,7 +120,7 @@ def main():
                 model = fresh()
                 tr = StreamTrainer(model, t["users"], t["items"], t["indptr"], t["indices"], lr=lr,
                                    sampler="adaptive", adaptive_p=cfg["adaptive_p"], batch_size=cfg["B"], seed=seed, **kw)
-                per = kw.get("refresh_split", 1)
+                per = kw.get("refresh_split", 1) * kw.get("launch_split", 1)
                 curve, done = {}, 0
                 for p in extra:
                     if epochs:
