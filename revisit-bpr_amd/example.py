@@ -84,7 +84,7 @@ def strict_epoch(model, optimizer, sampler, users, items, seen_pad, batch_size, 
 @click.option("--refresh-lag", type=float, default=0.0, show_default=True,
               help="stream mode: 1 = the adaptive snapshot is sorted beside the previous launch "
                    "(StreamTrainer refresh_lag); 0 = the reference's schedule; -1 = by shape and learning rate "
-                   "(fast.auto_schedule: lag 1 only inside the staleness budget lr x 2 x launch <= 4,000)")
+                   "(fast.auto_schedule: lag 1 only inside the staleness budget lr x 2 x launch <= 2,000)")
 @click.option("--refresh-cus", type=int, default=64, show_default=True,
               help="stream mode with --refresh-lag > 0: CUs the snapshot sort is masked to")
 def main(dataset_path, synthetic_name, num_users, num_items, embedding_dim, batch_size, epochs,

@@ -16,12 +16,17 @@ from revisit_bpr.datasets import interactions, synthetic
 CONFIG = ROOT / "tests" / "configs" / "bpr_small.yaml.j2"
 NAME = sys.argv[1] if len(sys.argv) > 1 else "netflix"
 DIM = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-data = synthetic.generate_named(NAME, eval_users=20, seed=3)
+import os
+EVAL_USERS = int(os.environ.get("EVAL_USERS", "20"))  # 10000 = the reference's ML-20M protocol (10 k held-out users)
+LR = os.environ.get("LR", "")                          # "" = the config's default 0.05; the metric's config: 0.001
+FULL = os.environ.get("FULL_METRICS", "")              # 1 = the 14 metrics of the reference's ML-20M config
+data = synthetic.generate_named(NAME, eval_users=EVAL_USERS, seed=3)
 with tempfile.TemporaryDirectory() as tmp:
     interactions.write_dataset(data, Path(tmp) / "data")
     def run(variant, mode, epochs):
         extra = (f"dataset={tmp}/data;num_users={data.num_users - 1};num_items={data.num_items - 1};"
-                 f"embedding_dim={DIM};train_batch_size=256;epochs={epochs};adaptive=1;item_bias=false")
+                 f"embedding_dim={DIM};train_batch_size=256;epochs={epochs};adaptive=1;item_bias=false"
+                 + (f";lr={LR}" if LR else "") + (";full_metrics=1" if FULL else ""))
         if variant == "adam":
             extra += ";optimizer=torch.optim.Adam;lr=0.001"
         torch.cuda.synchronize()
@@ -39,6 +44,7 @@ with tempfile.TemporaryDirectory() as tmp:
             t2, exp = run(variant, mode, e_hi)
             per_epoch = (t2 - t1) / (e_hi - 1)  # one training epoch + one evaluation of 20 users
             evals = [r for r in exp.history if r["engine"] == "eval"]
-            print(f"{variant:5s} --train-mode {mode:6s} ({exp._train_mode}): {per_epoch * 1e3:8.1f} ms per epoch (+ its eval) "
+            print(f"{variant:5s} --train-mode {mode:6s} ({exp._train_mode}{', fused eval' if exp._eval_fused else ''}; {EVAL_USERS} eval users, "
+                  f"{len(exp._metrics)} metrics): {per_epoch * 1e3:8.1f} ms per epoch (+ its eval) "
                   f"= {data.nnz / per_epoch / 1e6:6.2f} M triples/s through Trainer.run; ndcg@100 {evals[0]['ndcg@100']:.3f} -> "
                   f"{evals[-1]['ndcg@100']:.3f}", flush=True)
