@@ -497,6 +497,16 @@ int bpr_set_step(bpr_ctx* ctx, int64_t step);
  * far; 0 at ctx creation.  Settable so a resumed run refreshes at the same iterations. */
 int bpr_set_sampler_iter(bpr_ctx* ctx, int64_t iteration);
 
+/* ---- evaluation (E3): ROC-AUC of a block of score rows — the quantity of the reference's RocAucMany /
+ * RocAucManySlow (revisit_bpr/metrics/auc.py:70-130: every (positive, negative) pair of a row; 1 of the 14 metrics of
+ * its ML-20M / MSD configs) without the [B, I, I] comparison or a sort per row: scores [n, I] fp32 row-major (masked
+ * entries carry their mask value and count as negatives, as in the reference's eval loop), positives of row r =
+ * pos_items[pos_indptr[r] .. pos_indptr[r + 1]); auc_out[r] = sum over the positives of #{negatives scored strictly
+ * below} / (T (I - T)); NaN for a row without positives (0 / 0, as the metric classes) or with more than 4,096.
+ * Context-free: runs on `hip_stream`. */
+int bpr_auc_rows(const float* scores, int64_t n, int64_t I, const int64_t* pos_indptr, const int32_t* pos_items,
+                 float* auc_out, void* hip_stream);
+
 /* ---- multi-GPU item-table reconciliation (no reference counterpart: the reference's DDP path is
  * never enabled by a config, experiments/launcher.py:35-73).  The all-reduce itself is RCCL via
  * torch.distributed; these two fused elementwise kernels bracket it (revisit_bpr/distributed.py).

@@ -397,8 +397,10 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     unsigned block_l = E <= 4 ? 1024 : 512;  // (E >= 8: 64+ registers of rows per lane — two waves per SIMD)
     if (c->tune_lds_block > 0) block_l = std::min<unsigned>(block_l, (unsigned)c->tune_lds_block);
     c->last_lds_rows = 0;
-    if (c->tune_hot_lds > 0 && hot && c->hot_code != nullptr && c->d == G * E && a.snap_meta == nullptr &&
-        (sampler == NEG_GIVEN || (force != "csr" && force != "list"))) {
+    // (not in the asynchronous-cut pipeline: there the deltas stay in the global block from launch to launch and a
+    // hot row's value is Q + that block — which the LDS-tier kernel, reading Q + its own LDS delta, leaves out)
+    if (c->tune_hot_lds > 0 && hot && c->hot_code != nullptr && c->d == G * E && a.snap_meta == nullptr && !acut &&
+        !c->hot_unfolded && (sampler == NEG_GIVEN || (force != "csr" && force != "list"))) {
       if (cap_groups > 0 && cap_groups * G < block_l) block_l = (unsigned)(((cap_groups * G + 63) / 64) * 64);
       const size_t bm_bytes = sampler == NEG_GIVEN ? 0 : (size_t)(block_l / G) * words * sizeof(uint32_t);
       const size_t row_bytes = sizeof(float) * (size_t)c->d + sizeof(uint32_t);

@@ -64,11 +64,18 @@ def evaluate_topk(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch
     experiments/bpr/exp.py:369-374 + metrics/metric.py:110-113).  Same values as the metric classes
     (tests/test_gpu_api.py::test_evaluate_topk_equals_metric_classes).  `auc=True` adds the
     ROC-AUC of the reference's RocAucMany (metrics/auc.py:70-130: all positive / negative pairs of a
-    row) from the same block of scores by rank sums — one sort per block instead of the [B, I, I]
+    row) from the same block of scores: on a ROCm device `bpr_auc_rows` (csrc/bpr_eval.hip, r6: one pass over the
+    scores, the positives ranked in LDS), else by rank sums after one sort per block — instead of the [B, I, I]
     comparison."""
     from revisit_bpr.metrics.auc import RocAucManySlow
 
     auc_metric = RocAucManySlow() if auc else None
+    auc_sum = torch.zeros((), device=P.device, dtype=torch.float32)
+    lib = None
+    if auc and P.is_cuda:  # r6: bpr_auc_rows — one pass over the scores instead of a sort per row
+        from revisit_bpr import native
+
+        lib = native.load()
     dev = P.device
     I = Q.shape[0]
     kmax = min(max(ks), I)
@@ -95,13 +102,23 @@ def evaluate_topk(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch
         logits[:, 0] = -1e13
         t_lo, t_hi = eval_indptr[lo:hi], eval_indptr[lo + 1:hi + 1]
         t_cnt = t_hi - t_lo
-        target = torch.zeros(n, I, device=dev)
+        target = torch.zeros(n, I, device=dev, dtype=torch.bool)  # (1 byte per score; only the top-k look-up reads it)
         if int(t_cnt.sum()) > 0:
             target[torch.repeat_interleave(rows, t_cnt),
-                   eval_items[int(t_lo[0]):int(t_hi[-1])].long()] = 1.0
-        if auc_metric is not None:
-            auc_metric(logits, target)
-        rel = torch.gather(target, 1, torch.topk(logits, kmax, dim=1).indices)  # [n, kmax]
+                   eval_items[int(t_lo[0]):int(t_hi[-1])].long()] = True
+        if auc_metric is not None and lib is None:
+            auc_metric(logits, target.float())
+        elif auc_metric is not None:
+            ptr = (eval_indptr[lo:hi + 1] - eval_indptr[lo]).to(torch.int64).contiguous()
+            items = eval_items[int(t_lo[0]):int(t_hi[-1])].to(torch.int32).contiguous()
+            rows_auc = torch.empty(n, device=dev, dtype=torch.float32)
+            native.check(lib.bpr_auc_rows(logits.data_ptr(), n, I, ptr.data_ptr(), items.data_ptr(), rows_auc.data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream))
+            many = t_cnt > 4096  # (rows the kernel leaves to the sort-based form)
+            if bool(many.any()):
+                rows_auc[many] = auc_metric.compute(logits[many], target[many].float())
+            auc_sum += rows_auc.sum()
+        rel = torch.gather(target, 1, torch.topk(logits, kmax, dim=1).indices).float()  # [n, kmax]
         n_pos = t_cnt.float()
         gains = rel * disc
         for k in ks:
@@ -114,5 +131,5 @@ def evaluate_topk(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch
             sums[f"precision@{k}"] += (hits / kk).double().sum()
     out = {k: float(v / max(E, 1)) for k, v in sums.items()}
     if auc_metric is not None:
-        out["auc"] = float(auc_metric.get_metric())
+        out["auc"] = float(auc_metric.get_metric()) if lib is None else float(auc_sum / max(E, 1))
     return out

@@ -112,6 +112,7 @@ SIGNATURES = {
                               c_void_p]),
     "bpr_set_stream_opts": (c_int, [c_void_p, c_int32, c_int32]),
     "bpr_stream_run_len": (c_int, [c_void_p]),
+    "bpr_auc_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bpr_set_hot_lds": (c_int, [c_void_p, c_int32, c_int32]),
     "bpr_stream_lds_rows": (c_int, [c_void_p]),
     "bpr_item_fold_delta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64,

@@ -486,3 +486,47 @@ def test_samplers_with_several_negatives_per_positive(kind):
     assert abs(res["hip"][0] - res["torch"][0]) <= 2e-5 * abs(res["torch"][0])
     for k in res["torch"][1]:
         assert torch.allclose(res["hip"][1][k], res["torch"][1][k], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("n,I,tmax,ties", [(300, 977, 40, False), (64, 20108, 700, False), (50, 333, 12, True),
+                                           (5, 9000, 5000, False)])
+def test_auc_rows_kernel_equals_the_metric_classes(n, I, tmax, ties):
+    """`bpr_auc_rows` (r6, csrc/bpr_eval.hip) against the product's sort-based RocAucManySlow — itself pinned to the
+    reference's RocAucMany values by tests/golden/metrics.npz — row by row: masked scores (-1e13) count as negatives,
+    ties between a positive and a negative are not wins, rows without positives are NaN in both, rows with more
+    positives than the kernel's LDS holds come back NaN (evaluate_topk routes them to the sort-based form)."""
+    import ctypes
+
+    from revisit_bpr import native
+    from revisit_bpr.metrics.auc import RocAucManySlow
+
+    rng = np.random.default_rng(n + I)
+    scores = rng.normal(0, 1, (n, I)).astype(np.float32)
+    if ties:
+        scores = np.round(scores * 2) / 2  # many equal scores
+    scores[:, 0] = -1e13
+    scores[rng.random((n, I)) < 0.05] = -1e13  # "seen" items
+    cnt = rng.integers(0, tmax + 1, n)
+    cnt[0] = 0  # a row without positives
+    ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    items = np.concatenate([rng.choice(np.arange(1, I), size=int(c), replace=False) for c in cnt] + [np.zeros(0, np.int64)])
+    target = np.zeros((n, I), np.float32)
+    for r in range(n):
+        target[r, items[ptr[r]:ptr[r + 1]]] = 1.0
+    ts, tt = torch.from_numpy(scores).cuda(), torch.from_numpy(target).cuda()
+    want = RocAucManySlow().compute(ts, tt).cpu().numpy()
+    out = torch.empty(n, device="cuda")
+    tp, ti = torch.from_numpy(ptr).cuda(), torch.from_numpy(items.astype(np.int32)).cuda()
+    lib = native.load()
+    native.check(lib.bpr_auc_rows(ts.data_ptr(), n, I, tp.data_ptr(), ti.data_ptr(), out.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream))
+    got = out.cpu().numpy()
+    assert np.isnan(got[0]) and np.isnan(want[0])
+    big = cnt > 4096
+    assert np.isnan(got[big]).all()
+    ok = ~big & (cnt > 0)
+    assert ok.sum() > 0 and np.abs(got[ok] - want[ok]).max() < 2e-6, np.abs(got[ok] - want[ok]).max()
+    assert native.check(lib.bpr_auc_rows(None, 0, I, None, None, None, None)) is None  # n = 0: nothing to do
+    with pytest.raises(native.BprError):
+        native.check(lib.bpr_auc_rows(None, 3, I, None, None, None, None))
+    assert isinstance(ctypes.c_int64(1).value, int)
