@@ -311,7 +311,11 @@ int bpr_train_stream_cut(bpr_ctx* ctx, const int32_t* users, const int32_t* pos,
  * deltas are NOT folded into the item table by the launch — every other entry point of the ctx folds
  * them first (the table is whole for whoever looks through the library), and a caller who reads the
  * item table's storage directly (eval, checkpoint) calls bpr_hot_fold before.  out_scalars is added
- * to by the side-stream pass: read it after bpr_hot_fold or a device synchronisation. */
+ * to by the side-stream pass: read it after bpr_hot_fold or a device synchronisation.
+ * r6 (default; bpr_set_tuning "acut_fold" 0 restores the form above): only the TRANSPOSE of the keys leaves the launch
+ * stream — the fold of the hot block, the loss sums and the item_bias write-back stay on it (k_stream_epilogue, a few
+ * microseconds) — so the item table is whole after every launch (bpr_hot_fold is a no-op), out_scalars arrives on the
+ * launch stream, and the LDS tier (bpr_set_hot_lds) stays in use. */
 int bpr_train_stream_acut(bpr_ctx* ctx, const int32_t* users, const int32_t* pos, int32_t* neg,
                           int64_t n, int32_t sampler, float adaptive_p, uint64_t seed,
                           uint64_t offset, int64_t max_inflight, float* out_scalars);
@@ -419,6 +423,9 @@ int bpr_stream_lds_rows(bpr_ctx* ctx);
  *   "plan_input_sorted" 0 (default) / 1: a PROMISE that the users_in handed to bpr_plan_epoch are sorted by user id (the
  *               triple list in CSR order, as every loader of this repository makes it): the plan — same output — then
  *               takes one radix pass over the chunk bits instead of three over (chunk, user);
+ *   "acut_fold" 1 (default, r6) / 0: bpr_train_stream_acut keeps the fold of the hot block (+ loss sums, bias write-back)
+ *               on the launch stream and sends only the transpose of the snapshot's keys to the side stream / r4's form
+ *               (nothing folded until bpr_hot_fold: the LDS tier is then not used);
  *   "lds_tail"  0..50 (default 12): percent of a launch's triples the LDS-tier kernel deals in runs of run_len / 2 and
  *               run_len / 4 at the end of every persistent workgroup's share (a workgroup is over when its last run is). */
 int bpr_set_tuning(bpr_ctx* ctx, const char* key, int32_t value);

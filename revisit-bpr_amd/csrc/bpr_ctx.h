@@ -152,6 +152,7 @@ struct bpr_ctx {
   int32_t* hot_code = nullptr;     // [I]
   int32_t* hot_by_rank = nullptr;  // [hot_H]
   int tune_hot_lds = 0, tune_hot_lds_force = 0;
+  int tune_acut_fold = 1;          // bpr_train_stream_acut: 1 = the fold stays on the launch stream (r6), 0 = r4's read-only form
   int tune_plan_sorted = 0;        // 1: the caller promises bpr_plan_epoch's users_in sorted by user (one radix pass instead of three)
   int tune_lds_tail = 12;          // percent of a launch's triples dealt in short runs at the end (LDS-tier kernel)
   int tune_lds_block = 0;          // measurement aid: threads per workgroup of the LDS-tier kernel (0: 1,024 / 512 by shape)

@@ -399,8 +399,9 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     c->last_lds_rows = 0;
     // (not in the asynchronous-cut pipeline: there the deltas stay in the global block from launch to launch and a
     // hot row's value is Q + that block — which the LDS-tier kernel, reading Q + its own LDS delta, leaves out)
-    if (c->tune_hot_lds > 0 && hot && c->hot_code != nullptr && c->d == G * E && a.snap_meta == nullptr && !acut &&
-        !c->hot_unfolded && (sampler == NEG_GIVEN || (force != "csr" && force != "list"))) {
+    const bool acut_fold = acut && c->tune_acut_fold != 0;  // r6: the asynchronous cut with the fold kept on this stream
+    if (c->tune_hot_lds > 0 && hot && c->hot_code != nullptr && c->d == G * E && a.snap_meta == nullptr &&
+        (!acut || acut_fold) && !c->hot_unfolded && (sampler == NEG_GIVEN || (force != "csr" && force != "list"))) {
       if (cap_groups > 0 && cap_groups * G < block_l) block_l = (unsigned)(((cap_groups * G + 63) / 64) * 64);
       const size_t bm_bytes = sampler == NEG_GIVEN ? 0 : (size_t)(block_l / G) * words * sizeof(uint32_t);
       const size_t row_bytes = sizeof(float) * (size_t)c->d + sizeof(uint32_t);
@@ -449,9 +450,11 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
         BPR_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         c->side_owned = true;
       }
-      // the launch after next reuses this launch's partials: two sets, used alternately
-      if (a.partials != nullptr) a.partials = c->dev_scalars + (size_t)c->acut_parity * 4 * (STREAM_MAX_GRID + 1);
-      c->acut_parity ^= 1;
+      if (!acut_fold) {
+        // the launch after next reuses this launch's partials: two sets, used alternately
+        if (a.partials != nullptr) a.partials = c->dev_scalars + (size_t)c->acut_parity * 4 * (STREAM_MAX_GRID + 1);
+        c->acut_parity ^= 1;
+      }
     }
     if (a.bias != nullptr) {  // the launch works on the bias with one item per line (bpr_kernels.h)
       if (c->bias_w_rows != c->I) {
@@ -472,11 +475,11 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       a.bias = c->bias_w;
     }
     // the write-back rides on the launch's own epilogue where there is one on this stream
-    const bool bias_in_epilogue = a.bias != nullptr && !acut && !(cut && hot && c->hot_tier);
+    const bool bias_in_epilogue = a.bias != nullptr && (!acut || acut_fold) && !(cut && hot && c->hot_tier);
     {
       Timer tm(c, true);
       (void)tm;
-      hipEvent_t stop = acut ? c->ev_launch : nullptr;
+      hipEvent_t stop = (acut && !acut_fold) ? c->ev_launch : nullptr;
       if (use_lds) {
         if (int rc = launch_stream_lds(c, a, sampler, grid, block_l, shmem_l, stop)) return rc;
       }
@@ -506,6 +509,41 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       hipLaunchKernelGGL(k_bias_narrow, dim3((unsigned)((c->I + 255) / 256)), dim3(256), 0, c->stream,
                          c->bias_w, c->bias, (int32_t)c->I);
     if (a.bias != nullptr) c->bias_w_valid = true;  // dense == wide again once the write-back has run
+    if (acut_fold) {
+      // r6: the launch stream keeps only what the NEXT launch needs — the fold of the hot block (+ loss statistics,
+      // + the item_bias write-back): k_stream_epilogue, a few microseconds — and the 2 x I x d x 4-byte transpose
+      // that only the sorter reads goes to the side stream, behind this epilogue and beside the next launch (it
+      // reads Q while that launch updates it: a snapshot cut during the launch instead of before it — a little
+      // FRESHER than lag 1, inside the same budget).  Unlike the r4 form below the block is folded after every
+      // launch, so the LDS-tier kernel (which reads a hot row as Q + its own LDS delta) stays valid.
+      const bool fold = hot && !c->hot_tier;
+      EpilogueArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.partials = a.partials; ea.n_blocks = (int)grid; ea.out = out_scalars;
+      ea.Q = c->Q; ea.delta = c->hot_delta; ea.hot_items = c->hot_items;
+      ea.H = fold ? c->hot_H : 0; ea.R = c->hot_R; ea.d = c->d;
+      ea.fold_blocks = fold ? (int)std::min<int64_t>(((int64_t)c->hot_H * c->d + 255) / 256, 64) : 0;
+      if (bias_in_epilogue) {
+        ea.bias_w = c->bias_w; ea.bias = c->bias; ea.I = (int32_t)c->I;
+        ea.bias_blocks = (int)std::min<int64_t>((c->I + 255) / 256, 256);
+      }
+      hipExtLaunchKernelGGL(k_stream_epilogue, dim3(1 + ea.fold_blocks + ea.bias_blocks), dim3(256), 0, c->stream, nullptr,
+                            c->ev_launch, 0, ea);
+      BPR_HIP_CHECK(hipGetLastError());
+      EpilogueCutArgs ec;
+      memset(&ec, 0, sizeof(ec));
+      ec.Q = c->Q; ec.T = c->keysT; ec.sig_acc = c->sig_acc; ec.d = c->d; ec.I = (int32_t)c->I;  // no hot block, no sums
+      dim3 eg((unsigned)((c->I + 31) / 32), (unsigned)((c->d + 31) / 32) + 1u);
+      BPR_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_launch, 0));
+      hipExtLaunchKernelGGL(k_stream_epilogue_cut, eg, dim3(256), 0, c->side, nullptr, c->ev_keys, 0, ec);
+      BPR_HIP_CHECK(hipGetLastError());
+      c->keys_cut = true;
+      if (c->meta_front != nullptr && c->keysT == c->keys_front) c->keys_front_stale = true;
+      c->keys_event = true;
+      c->keys_on_side = true;
+      c->acut_pending = true;  // (a launch outside the pipeline still waits for this cut: it reads Q)
+      return BPR_OK;
+    }
     if (acut) {
       // the cut of the next snapshot on the SIDE stream, behind this launch and beside the next
       // one: read-only (keys = Q + hot deltas, nothing folded), it also sums the loss partials
@@ -1434,6 +1472,7 @@ int bpr_set_tuning(bpr_ctx* c, const char* key, int32_t value) {
   else if (k == "lds_block" && value >= 0 && value <= 1024 && value % 64 == 0) c->tune_lds_block = value;
   else if (k == "lds_tail" && value >= 0 && value <= 50) c->tune_lds_tail = value;
   else if (k == "plan_input_sorted" && (value == 0 || value == 1)) c->tune_plan_sorted = value;
+  else if (k == "acut_fold" && (value == 0 || value == 1)) c->tune_acut_fold = value;
   else return fail(BPR_ERR_INVALID, "bpr_set_tuning: unknown key or value out of range");
   c->stream_occ.clear();
   return BPR_OK;

@@ -15,6 +15,7 @@ import json
 import logging
 import math
 import random
+import time
 from pathlib import Path
 from typing import Any, Callable, Literal, Optional
 
@@ -424,14 +425,14 @@ class BPRExperiment:
                 if not k.startswith("_")}
 
     def _log_train(self, engine) -> None:
-        row = {"engine": "train", "epoch": engine.state.epoch, **self._public(engine.state.metrics)}
+        row = {"engine": "train", "epoch": engine.state.epoch, "t": time.perf_counter(), **self._public(engine.state.metrics)}
         self.history.append(row)
         log.info("train epoch %d | %s", engine.state.epoch,
                  " ".join(f"{k}={v:.4f}" for k, v in row.items() if isinstance(v, float)))
 
     def _log_eval(self, engine) -> None:
         train_epoch = self.trainer.engines["train"].state.epoch
-        row = {"engine": "eval", "epoch": train_epoch, **self._public(engine.state.metrics)}
+        row = {"engine": "eval", "epoch": train_epoch, "t": time.perf_counter(), **self._public(engine.state.metrics)}
         self.history.append(row)
         log.info("eval before epoch %d | %s", train_epoch,
                  " ".join(f"{k}={v:.4f}" for k, v in row.items() if isinstance(v, float)))

@@ -156,7 +156,7 @@ class StreamTrainer:
                  refresh_lag: float | str = 0.0, refresh_split: int = 1, refresh_cus: int = 0,
                  shard_refresh: bool = False, cadence: str = "job", hot_split: int = 1,
                  rounds: Optional[int] = None, jit_plan: bool = False, async_cut: bool = False,
-                 hot_lds: int | str = "auto", launch_split: int | str = 1) -> None:
+                 hot_lds: int | str = "auto", launch_split: int | str = "auto") -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
         adaptive refresh period int(I·ln I / batch_size) batches, as example.py:302.
@@ -199,9 +199,11 @@ class StreamTrainer:
 
         launch_split k (refresh_lag 0, one GPU): a refresh period runs as k launches that read the SAME snapshot —
         a launch walks its triples grouped by user, so a user's triples of a period are otherwise applied back to
-        back; k launches deal them into k groups placed apart, as the reference's shuffled mini-batches do.  "auto":
-        2 outside the staleness budget (high learning rates: STREAM's Recall@20 at the end of the first lr-0.05
-        epoch at the ML-20M shape, -0.0023 with one launch per period: profiles/r06_parity_study.md), else 1.
+        back; k launches deal them into k groups placed apart, as the reference's shuffled mini-batches do.  "auto"
+        (default): 2 outside the one-rank budget (high learning rates: at the end of the first lr-0.05 epoch at the
+        ML-20M shape STREAM reads -0.0013 / -0.0018 nDCG@100 / Recall@20 against the reference's own loop with one
+        launch per period, -0.0012 / -0.0012 with two, 12 seeds each: profiles/r06_parity_study.md), else 1.
+        With the uniform sampler (no snapshot to share) it only halves the launches.
 
         hot_lds: rows of the hot block a CU keeps in LDS during a launch (`bpr_set_hot_lds`; r6): "auto" =
         `hot_lds_rows` — on inside the staleness budget, off outside; 0 = off; n = asked for whatever the rate.

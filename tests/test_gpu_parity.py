@@ -1334,8 +1334,11 @@ def test_stream_cut_at_full_concurrency_sees_the_final_table(d, sampler, n):
     assert torch.isfinite(e.Q).all() and torch.isfinite(sc).all()
 
 
-def test_async_cut_reads_the_table_whole_and_folds_on_demand():
-    """bpr_train_stream_acut: the cut is a read-only pass on the side stream (keys = Q + hot deltas) and
+@pytest.mark.parametrize("fold", [1, 0])
+def test_async_cut_reads_the_table_whole_and_folds_on_demand(fold):
+    """(fold = 1, r6 default: only the transpose of the keys goes to the side stream, the hot block is folded on the
+    launch stream after every launch — the same contract from outside; fold = 0: r4's form, below.)
+    bpr_train_stream_acut: the cut is a read-only pass on the side stream (keys = Q + hot deltas) and
     the launch folds nothing.  With nothing running beside it the snapshot it yields is exactly the
     oracle's order of the table the launch left; any other entry point (here: the synchronous
     refresh, the item table read through hot_fold) sees the table whole; the loss statistics arrive
@@ -1357,6 +1360,7 @@ def test_async_cut_reads_the_table_whole_and_folds_on_demand():
         e.bind_seen_csr(dev(indptr), dev(np.zeros(0, np.int32)))
         e.set_optimizer(kind=0, lr=0.01)
         e.set_stream_opts(True, 0)
+        e.set_tuning("acut_fold", fold)
         pu, pi = e.plan_epoch(dev(users), dev(pos), n, seed=3)  # builds the hot block
         sc = torch.zeros(4, device="cuda")
         e.adaptive_refresh()

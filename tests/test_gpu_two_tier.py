@@ -291,6 +291,9 @@ def test_two_ranks_with_an_item_bias_keep_the_reconciled_vector(monkeypatch):
             monkeypatch.setattr(eng.Engine, "set_bias_tracking", lambda self, on: real(self, False))
         lw = LocalWorld(2)
         trs, feats = [], []
+        every = max(1, int(I * np.log(I) / 64))
+        chunk = max(1, every * 64 // 2)  # cadence "job": a period of the job = two rank chunks
+        rounds = max(-(-int((own == r).sum()) // chunk) for r in range(2))  # (LocalWorld has no blocking collectives)
         for r in range(2):
             torch.manual_seed(13)
             model = BPR(fuse_forward=True, reg_alphas={"user": 0.0025, "item": 0.0025, "neg": 0.00025},
@@ -301,9 +304,9 @@ def test_two_ranks_with_an_item_bias_keep_the_reconciled_vector(monkeypatch):
             sync = ItemSync([f["item"].data, f["item_bias"].data], comm=lw.member(r), engine=model.engine())
             trs.append(StreamTrainer(model, u_d[mine].contiguous(), p_d[mine].contiguous(), torch.from_numpy(indptr).to(dev),
                                      torch.from_numpy(indices).to(dev), lr=0.05, sampler="uniform", batch_size=64, seed=3,
-                                     rank=r, item_sync=sync, world=2, max_inflight=1))
+                                     rank=r, item_sync=sync, world=2, max_inflight=1, rounds=rounds))
             feats.append(f)
-        assert trs[0].rounds > 2  # several reconciliations inside an epoch
+        assert trs[0].chunk == chunk and trs[0].rounds > 2  # several reconciliations inside an epoch
         for _ in range(3):
             for tr in trs:
                 tr.epoch_begin()

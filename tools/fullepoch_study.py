@@ -45,6 +45,7 @@ VARIANTS = {
     "auto": dict(refresh_lag="auto"),
     "timed_lds": dict(refresh_lag=1.0, refresh_cus=-1, hot_lds=512),
     "timed_nolds": dict(refresh_lag=1.0, refresh_cus=-1, hot_lds=0),
+    "timed_lds_acut": dict(refresh_lag=1.0, refresh_cus=-1, hot_lds=512, async_cut=True),
     "reference_lds": dict(hot_lds=512),
     "reference_nolds": dict(hot_lds=0),
     # r6: a period as 2 / 4 launches reading the same snapshot (a user's triples of a period no longer back to back)
