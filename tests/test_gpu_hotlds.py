@@ -113,10 +113,13 @@ def test_lds_tier_loses_nothing_under_chip_wide_contention(hot_rows, replicas, l
     assert int(sc[3]) == n
 
 
-@pytest.mark.parametrize("d,sampler,n", [(128, 2, 120_000), (128, 1, 60_000), (64, 2, 90_000), (256, 2, 40_000),
-                                          (32, 0, 50_000)])
-def test_lds_tier_cut_at_full_concurrency_sees_the_final_table(d, sampler, n):
-    """The fused cut behind an LDS-tier launch: the snapshot committed afterwards is the oracle's order of the
+@pytest.mark.parametrize("d,sampler,n,cut", [(128, 2, 120_000, True), (128, 1, 60_000, True), (64, 2, 90_000, True),
+                                              (256, 2, 40_000, True), (32, 0, 50_000, True), (128, 2, 120_000, "async"),
+                                              (64, 1, 70_000, "async")])
+def test_lds_tier_cut_at_full_concurrency_sees_the_final_table(d, sampler, n, cut):
+    """(cut = "async": the transpose on the side stream, the fold on the launch stream — with nothing running beside
+    it here, the same exact snapshot.)
+    The fused cut behind an LDS-tier launch: the snapshot committed afterwards is the oracle's order of the
     item table as the launch left it — every workgroup's flush folded in — launch after launch; the statistics
     count every triple; sampled negatives are valid (uniform: the plain kernel's picks triple by triple; adaptive
     picks read the live user rows, which at lr 0.05 and 20 triples per user have moved apart within the launch)."""
@@ -140,7 +143,7 @@ def test_lds_tier_cut_at_full_concurrency_sees_the_final_table(d, sampler, n):
     for launch in range(3):
         neg = given if sampler == 0 else torch.zeros_like(pu)
         e.train_stream(pu, pi, sampler=sampler, neg=neg, adaptive_p=0.05, seed=5, offset=launch * n, scalars=sc,
-                       cut=True)
+                       cut=cut)
         assert e.stream_lds_rows() > 0
         if launch == 0 and sampler != 0:
             neg0 = torch.zeros_like(pu)
