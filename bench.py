@@ -217,9 +217,11 @@ def parse_args():
                          "lost (profiles/r05b_plan_ahead.txt: 711 against 799 M triples/s — the plan's radix sort holds the "
                          "sorter's CUs for milliseconds and the snapshot sort becomes the critical path); 0 (default): "
                          "between the epochs on the launch stream")
-    ap.add_argument("--async-cut", type=int, default=0,
-                    help="1: the cut of the next snapshot runs on the side stream beside the next launch "
-                         "(bpr_train_stream_acut) instead of between two launches")
+    ap.add_argument("--async-cut", type=int, default=-1,
+                    help="1: the transpose of the next snapshot's keys runs on the side stream beside the next launch "
+                         "(bpr_train_stream_acut; the fold of the hot block stays on the launch stream) instead of "
+                         "between two launches; -1 (default): as fast.StreamTrainer's auto — on with the overlapped "
+                         "schedule on masked streams, one GPU; 0: off")
     ap.add_argument("--item-bias", type=int, default=0,
                     help="1: the model carries the reference's optional item_bias (models/bpr/model.py:101-110; "
                          "its RQ configs switch it on).  Single GPU only here (a measurement aid: "
@@ -559,7 +561,7 @@ def main():
     synced = [False]
     # --async-cut: the snapshot cut leaves the launch stream (bpr_train_stream_acut: a read-only pass on the
     # side stream beside the next launch); the hot rows are folded before the tables are read
-    acut = bool(args.async_cut) and fused
+    acut = (bool(args.async_cut) if args.async_cut >= 0 else side_stream is not None) and fused
 
     # --jit-plan (default with the overlapped schedule): no bpr_plan_epoch at all — chunk k + 1 is
     # planned by bpr_plan_chunk on the side stream behind the sort of step k (the plan does not depend

@@ -162,6 +162,11 @@ class Engine:
         """``bpr_set_tuning``: "seen" 0 auto | 1 csr | 2 bitmap | 3 list; "vs_direct" -1 auto | 0 | 1;
         "refresh_sub" 0 | 1 | 2 | 4; "partial_snapshot" 0 | 1; "partial_target" 1..1024; "binned_sort" 1 | 0."""
         native.check(self._lib.bpr_set_tuning(self._ctx, key.encode(), int(value)))
+        self.__dict__.setdefault("_tuning", {})[key] = int(value)
+
+    def tuning(self, key: str, default: int = 0) -> int:
+        """What `set_tuning(key, ...)` was last given through this engine (`default`: never set)."""
+        return self.__dict__.get("_tuning", {}).get(key, default)
 
     # ---- plumbing ---------------------------------------------------------------------------
     def _stream(self) -> int:

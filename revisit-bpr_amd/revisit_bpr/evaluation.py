@@ -57,7 +57,7 @@ def evaluate(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch.Tens
 @torch.no_grad()
 def evaluate_topk(P: torch.Tensor, Q: torch.Tensor, item_bias, eval_users: torch.Tensor,
                   eval_indptr: torch.Tensor, eval_items: torch.Tensor, seen_indptr: torch.Tensor,
-                  seen_indices: torch.Tensor, ks=(5, 10, 20, 50, 100), block: int = 4096,
+                  seen_indices: torch.Tensor, ks=(5, 10, 20, 50, 100), block: int = 8192,
                   auc: bool = False) -> dict:
     """NDCG / Recall / Precision at every k in `ks` from ONE top-max(ks) per block of users (the
     reference runs a full argsort of I scores per metric object: 14 sorts per batch,

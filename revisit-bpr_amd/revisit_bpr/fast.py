@@ -155,7 +155,7 @@ class StreamTrainer:
                  item_sync=None, sync_every: int = 1, world: Optional[int] = None,
                  refresh_lag: float | str = 0.0, refresh_split: int = 1, refresh_cus: int = 0,
                  shard_refresh: bool = False, cadence: str = "job", hot_split: int = 1,
-                 rounds: Optional[int] = None, jit_plan: bool = False, async_cut: bool = False,
+                 rounds: Optional[int] = None, jit_plan: bool = False, async_cut: bool | str = "auto",
                  hot_lds: int | str = "auto", launch_split: int | str = "auto") -> None:
         """model: revisit_bpr.models.BPR on a ROCm device; users/items: int32 training triples on
         the device; seen CSR: int64 indptr [U+1], int32 indices.  `batch_size` only sets the
@@ -208,9 +208,10 @@ class StreamTrainer:
         hot_lds: rows of the hot block a CU keeps in LDS during a launch (`bpr_set_hot_lds`; r6): "auto" =
         `hot_lds_rows` — on inside the staleness budget, off outside; 0 = off; n = asked for whatever the rate.
 
-        async_cut (refresh_lag = 1, one GPU): the cut of the next snapshot leaves the launch stream —
-        a read-only pass on the side stream beside the NEXT launch (`bpr_train_stream_acut`); the
-        launch stream runs launch after launch.  The hot rows are folded at the end of the epoch."""
+        async_cut (refresh_lag = 1, one GPU): the transpose of the next snapshot's keys leaves the launch stream —
+        a read-only pass on the side stream beside the NEXT launch (`bpr_train_stream_acut`; r6: the fold of the
+        hot block stays on the launch stream, so the LDS tier stays in use): +1.4 % on the metric's configuration,
+        the same curves (profiles/r06_parity_study.md).  "auto" (default): on with a masked side stream."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
             raise ValueError("users / items must be int32 device tensors")
         auto_lag = isinstance(refresh_lag, str)
@@ -297,6 +298,10 @@ class StreamTrainer:
             self._pi = torch.empty_like(self.items)
         self._scalars = torch.zeros(4, dtype=torch.float32, device=users.device)
         self._synced = False  # this chunk's reconciliation already ran (fused into the launch's cut)
+        if isinstance(async_cut, str):
+            if async_cut != "auto":
+                raise ValueError("async_cut must be a bool or 'auto'")
+            async_cut = self._side is not None
         self.async_cut = bool(async_cut) and self.refresh_lag >= 1.0 and item_sync is None
         self.item_sync, self.sync_every = item_sync, sync_every
         # shards are balanced by interactions, not equal: every rank runs the same number of
@@ -431,7 +436,9 @@ class StreamTrainer:
         self.engine.set_bias_tracking(False)
         if self._main is not None:
             torch.cuda.current_stream(self.users.device).wait_stream(self._main.torch)
-        if self.async_cut:  # the tables are read next: fold what the asynchronous cuts left, wait for their sums
+        if self.async_cut and self.engine.tuning("acut_fold", 1) == 0:
+            # r4's form of the asynchronous cut: fold what the cuts left, wait for the sums they deliver on the side
+            # stream (r6's default keeps fold and sums on the launch stream: nothing to do)
             self.engine.hot_fold()
             torch.cuda.synchronize(self.users.device)
         sc = self._scalars.tolist()

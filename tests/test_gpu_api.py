@@ -530,3 +530,38 @@ def test_auc_rows_kernel_equals_the_metric_classes(n, I, tmax, ties):
     with pytest.raises(native.BprError):
         native.check(lib.bpr_auc_rows(None, 3, I, None, None, None, None))
     assert isinstance(ctypes.c_int64(1).value, int)
+
+
+def test_stream_trainer_launch_split_shares_one_snapshot_per_period(golden_dir):
+    """r6 `launch_split`: a refresh period runs as k launches that read the SAME snapshot (a user's triples of a period
+    are no longer applied back to back) — k times as many launches of 1 / k the size, the snapshot retaken only before
+    the first launch of every period; "auto" = 2 outside the one-rank budget (fast.lag_within_budget), else 1, and 1
+    whenever the snapshot is lagged or several ranks share the job."""
+    from revisit_bpr import fast
+    from revisit_bpr.models import BPR
+    from revisit_bpr.models.bpr import MF
+
+    d = np.load(golden_dir / "e2e_data.npz")
+    U, I = int(d["num_users"]), int(d["num_items"])
+    t = {k: torch.from_numpy(d[k]).cuda() for k in ("users", "items", "indptr", "indices")}
+
+    def trainer(**kw):
+        torch.manual_seed(1)
+        model = BPR(fuse_forward=True, reg_alphas={"user": 0.001, "item": 0.001, "neg": 0.001},
+                    logits_model=MF(torch.nn.Embedding(U, 32, padding_idx=0), torch.nn.Embedding(I, 32, padding_idx=0))).cuda()
+        return fast.StreamTrainer(model, t["users"], t["items"], t["indptr"], t["indices"], sampler="adaptive",
+                                  adaptive_p=0.05, seed=3, **kw)
+
+    one, two = trainer(lr=0.05, launch_split=1), trainer(lr=0.05, launch_split=2)
+    assert two.chunk * 2 == one.chunk and two.rounds in (2 * one.rounds, 2 * one.rounds - 1)
+    calls = []
+    real = two.engine.adaptive_refresh
+    two.engine.adaptive_refresh = lambda: (calls.append(1), real())[1]
+    stats = two.train_epoch()
+    assert stats["triples"] == t["users"].numel() and len(calls) == -(-two.rounds // 2)  # one snapshot per PERIOD
+    # auto: this set's period (10.9 k triples) is inside the budget at lr 0.05, far outside at lr 0.5
+    assert trainer(lr=0.05, launch_split="auto").launch_split == 1
+    assert trainer(lr=0.5, launch_split="auto").launch_split == 2
+    assert trainer(lr=0.5, launch_split="auto", refresh_lag=1.0).launch_split == 1
+    with pytest.raises(ValueError):
+        trainer(lr=0.05, launch_split=2, refresh_lag=1.0)

@@ -9,8 +9,11 @@ ten epochs.  Here, on the same data and initial tables:
   * STRICT — the reference's mini-batches of 16 through the library, replaying the reference's order every epoch
              (our Philox sampler instead of torch's generator): every epoch of the curve, all three metrics, raw
              +-0.002 + 2 se;
-  * STREAM — the uniform throughput path with its own device shuffle and launches of int(I ln I / 16) * 16 = 40,912
-             triples (4 triples per user row in flight against mini-batches of 16): same gate.
+  * STREAM — the uniform throughput path as the product configures itself (`refresh_lag="auto"`, `launch_split="auto"`:
+             lr 0.05 x 2 x 40,928 is outside the one-rank budget, so a period runs as two launches of 20,464 triples —
+             2 per user row in flight against mini-batches of 16), its own device shuffle: same gate.  (One launch
+             per period trails the reference's take-off at epochs 4 - 6 by 0.1 epoch — Recall@20 -0.0087 / -0.0075 —
+             and meets it again from epoch 8 on: profiles/r06_cfg2.md.)
 """
 import json
 import math
@@ -154,4 +157,5 @@ def test_stream_matches_the_reference_loop_at_cfg2(setting):
             assert stats["triples"] == data.nnz
             curve[ep] = metrics(model, t)
         ours[seed] = curve
+    assert tr.launch_split == 2 and tr.hot_lds == 0
     compare("STREAM[uniform, launches of %d]" % tr.chunk, fix, ours, range(1, cfg["epochs"] + 1))
