@@ -130,7 +130,7 @@ WORKLOADS = {
 # HBM-side bytes per k_stream launch measured by separate rocprofv3 --pmc passes (profiles/*_pmc_traffic.md)
 # of exactly these commands: (workload, d, sampler, optimizer) -> file under profiles/
 TRAFFIC_FILES = {
-    ("ml-20m", 128, "adaptive", "sgd"): "traffic_r05d.json",
+    ("ml-20m", 128, "adaptive", "sgd"): "traffic_r06.json",  # the trained state with the LDS tier (r05d: without it, early state)
     ("msd", 256, "adaptive", "sgd"): "traffic_r05_msd_d256.json",
 }
 
@@ -240,6 +240,9 @@ def parse_args():
     ap.add_argument("--steady-timed-epochs", type=int, default=100,
                     help="whole epochs timed for the steady state — the headline `value` (r6): epochs steady-epochs + 1 .. "
                          "steady-epochs + this many of the same job, by wall clock between barriers")
+    ap.add_argument("--launch-split", type=int, default=0,
+                    help="launches per refresh period that read the same snapshot (fast.StreamTrainer launch_split); 0 = "
+                         "auto: 2 outside the one-rank budget lr x 2 x period <= 2,000, else 1")
     ap.add_argument("--hot-lds", type=int, default=-1,
                     help="rows of the hot block a CU keeps in LDS during a launch (bpr_set_hot_lds, r6): -1 = by the "
                          "staleness budget (fast.hot_lds_rows: on at lr 0.001 / 0.01, off at 0.05), 0 = off, n = forced")
@@ -500,7 +503,13 @@ def main():
     cad_world = emu if emu else world
     ranks_per_period = (cad_world if args.cadence == "job" else 1 if args.cadence == "rank" else
                         launches_per_period(args.lr, cad_world, period))
-    chunk = max(1, period // (split * ranks_per_period))
+    # r6, as fast.StreamTrainer(launch_split="auto"): outside the one-rank budget (high learning rates) a period runs as
+    # TWO launches that read the same snapshot, so that a user's triples of a period are not applied back to back
+    from revisit_bpr.fast import lag_within_budget
+    lsplit = args.launch_split if args.launch_split > 0 else (
+        1 if (cad_world > 1 or split != 1 or batched or (args.refresh_lag or 0.0) != 0.0
+              or lag_within_budget(args.lr, period)) else 2)
+    chunk = max(1, period // (split * ranks_per_period * lsplit))
     n_chunks = max(1, data.nnz // chunk)
     if world > 1:  # every rank's own shard: the same number of steps per epoch everywhere, or the collectives of
         tn = torch.tensor([n_chunks], device=dev)  # a sustained / steady epoch stop matching up
@@ -639,7 +648,7 @@ def main():
         elif lag == 0.0:
             if shard_refresh and not batched:
                 e.adaptive_refresh_sharded(rank, world, force=forced)
-            else:
+            elif c % lsplit == 0:  # (launch_split: the period's later launches reuse the snapshot)
                 e.adaptive_refresh()  # batched: brings the item rows to "now" first
             launch(k, lo, lo + chunk, lo)
         else:  # the same schedule as fast.StreamTrainer._chunk
@@ -838,6 +847,8 @@ def main():
             tj = json.loads(tfile.read_text())
             if tj.get("triples_per_launch") == chunk:
                 traffic = tj["traffic_bytes_per_launch"]
+                if tname == "traffic_r06.json" and (e.lds_launches == 0 or steady is None):
+                    traffic = None  # (that file is the LDS-tier kernel on the trained state: not this run)
         achieved = (bytes_per_triple * chunk) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
             "metric": "BPR triples/sec at d=128 (1/2/4/8 GPU) + nDCG@100 parity vs reference",
@@ -875,7 +886,8 @@ def main():
                             "rule": "fast.hot_lds_rows: on while lr x 2 x job triples per launch <= 2,000 (a CU sees the other "
                                     "CUs' updates of these rows one launch late)"},
                 "triples_per_step_per_gpu": chunk,
-                "refresh_schedule": {"lag": lag, "launches_per_period": split, "side_stream_cus": cus,
+                "refresh_schedule": {"lag": lag, "launches_per_period": split, "launches_sharing_a_snapshot": lsplit,
+                                     "side_stream_cus": cus,
                                      "sharded_over_ranks": bool(shard_refresh and not batched)},
                 "cadence": (f"{args.cadence}: {ranks_per_period} chunk(s) of {chunk} triples per rank and refresh "
                             f"period (lr x N x chunk = {args.lr * cad_world * chunk:.0f}, N = {cad_world}"
@@ -912,9 +924,9 @@ def main():
                                    if kernel_ms > 0 and args.optimizer == "sgd" else None),
                 "traffic": traffic,
                 "traffic_measured_in_this_run": False,
-                "traffic_source": (f"replayed from profiles/{tfile.stem.replace('traffic_', '').split('_')[0]}_pmc_traffic.md "
-                                   "(separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
-                                   "MI355X, bytes per launch, gfx950 x2 read correction)") if traffic else None,
+                "traffic_source": (f"REPLAYED, not measured by this run: profiles/{tname} (separate rocprofv3 --pmc FETCH_SIZE / "
+                                   "WRITE_SIZE passes of this command on an MI355X, bytes per launch of the same state, "
+                                   "gfx950 x2 read correction; rocprofv3 cannot wrap a run from inside it)") if traffic else None,
                 "algorithmic_bytes_per_launch": bytes_per_triple * chunk,
                 "bytes_per_triple": bytes_per_triple,
                 "kernel_ms_avg": kernel_ms,

@@ -1794,7 +1794,7 @@ int heavy_build_impl(bpr_ctx* c) {
     // until they do
     const uint64_t cap_words = std::min<uint64_t>((uint64_t)1 << 31, (uint64_t)c->heavy_max_bytes / 4);
     if ((uint64_t)n_heavy * words < cap_words) break;
-    T *= 2;
+    T = T > 0 ? T * 2 : 1;
   }
   hipFree(counter);
   c->heavy_T = T;

@@ -130,12 +130,15 @@ class Engine:
         self._keep: dict[str, object] = {}
         self._scalars = torch.zeros(native.SCALARS, dtype=torch.float32, device=self.device)
         self.opt_kind = OPT_SGD
+        self.lds_launches = 0
         # test / measurement aids: the environment is read HERE, once per engine, never by the library
         import os
 
         seen = os.environ.get("BPR_SEEN") or ("csr" if os.environ.get("BPR_NO_BITMAP") else "")
         if seen:
-            self.set_tuning("seen", {"csr": 1, "bitmap": 2, "list": 3}[seen])
+            self.set_tuning("seen", {"csr": 1, "bitmap": 2, "list": 3, "global": 4}[seen])
+            if seen == "global":  # a bitmap row in HBM for EVERY user (up to 16 GiB of them)
+                native.check(self._lib.bpr_set_heavy_users(self._ctx, 0, 16 << 30))
         if os.environ.get("BPR_VS_DIRECT") in ("0", "1"):
             self.set_tuning("vs_direct", int(os.environ["BPR_VS_DIRECT"]))
         if os.environ.get("BPR_NO_ADAM_CLOSED"):
@@ -493,6 +496,7 @@ class Engine:
               self._lib.bpr_train_stream_cut if cut else self._lib.bpr_train_stream)
         native.check(fn(self._ctx, users.data_ptr(), pos.data_ptr(), _ptr(neg), users.numel(),
                         sampler, adaptive_p, seed, offset, max_inflight, _ptr(scalars)))
+        self.lds_launches += self._lib.bpr_stream_lds_rows(self._ctx) > 0  # launches the LDS-tier kernel ran (r6)
 
     def set_bias_tracking(self, on: bool) -> None:
         """item_bias during STREAM launches (``bpr_set_bias_tracking``): on = a launch skips re-reading the
