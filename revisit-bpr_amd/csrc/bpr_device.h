@@ -197,18 +197,7 @@ struct SeenList {
     return b < n && lst[b] == c;
   }
 };
-// every user's I-bit seen bitmap in HBM (bpr_set_heavy_users threshold 0: 288 GB make U x I / 8 bytes cheap — 344 MB
-// for ML-20M, 2.9 GB for MSD): no per-group structure in LDS at all, which leaves the CU's LDS to the hot rows of
-// the LDS tier (k_stream LDSHOT); a user without seen items has no row
-struct SeenGlobal {
-  const uint32_t* __restrict__ gbits;
-  uint32_t hoff;
-  __device__ __forceinline__ bool operator()(int32_t c) const {
-    if (hoff == NOT_HEAVY) return false;
-    return ((gbits[hoff + (uint32_t)(c >> 5)] >> (c & 31)) & 1u) != 0u;
-  }
-};
-enum { SEEN_CSR = 0, SEEN_BITMAP = 1, SEEN_LIST = 2, SEEN_GLOBAL = 3 };
+enum { SEEN_CSR = 0, SEEN_BITMAP = 1, SEEN_LIST = 2 };
 
 // ---------------------------------------------------------------------------------------------
 // Uniform negative: UniformSampler.sample (reference revisit_bpr/modules/neg_samplers.py:31-37),

@@ -50,8 +50,8 @@ inline int dispatch_ge(int G, int E, F&& f) {
 // declare dynamically beside the kernels' static LDS (sigma: 4 d bytes, reduction scratch) of a CU's 160 KiB
 constexpr size_t LDS_TIER_MAX_BYTES = 160 * 1024 - 6 * 1024;
 struct StreamArgs;
-int launch_stream_lds(bpr_ctx* c, const StreamArgs& a, int sampler, int seen, unsigned grid, unsigned block,
-                      size_t shmem, hipEvent_t stop);
+int launch_stream_lds(bpr_ctx* c, const StreamArgs& a, int sampler, unsigned grid, unsigned block, size_t shmem,
+                      hipEvent_t stop);
 
 struct Timer {
   bpr_ctx* c;

@@ -339,13 +339,10 @@ void k_stream(const StreamArgs a) {
       } else {
         using Seen = typename std::conditional<
             BM, SeenBitmap,
-            typename std::conditional<SEEN == SEEN_LIST, SeenList,
-                                      typename std::conditional<SEEN == SEEN_GLOBAL, SeenGlobal, SeenCsr>::type>::type>::type;
+            typename std::conditional<SEEN == SEEN_LIST, SeenList, SeenCsr>::type>::type;
         Seen seen;
         if constexpr (BM) {
           seen = SeenBitmap{bm, a.heavy_bits, hoff};
-        } else if constexpr (SEEN == SEEN_GLOBAL) {
-          seen = SeenGlobal{a.heavy_bits, hoff};
         } else if constexpr (SEEN == SEEN_LIST) {
           seen = SeenList{reinterpret_cast<const int32_t*>(bm), list_n, a.indices, cur_lo,
                           cur_lo + cur_n, a.heavy_bits, hoff};

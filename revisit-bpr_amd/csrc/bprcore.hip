@@ -304,7 +304,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     // (LIST_CAP entries per group, heavier users search the CSR in HBM).  bpr_set_tuning("seen", ...)
     // forces a structure (tests, measurements); a forced bitmap shrinks the block to fit.
     const int words = (int)(((c->I + 31) / 32 + 3) / 4 * 4);  // multiple of 4: 16-byte LDS wipes
-    static const char* const seen_names[] = {"", "csr", "bitmap", "list", "global"};
+    static const char* const seen_names[] = {"", "csr", "bitmap", "list"};
     const std::string force = seen_names[c->tune_seen];  // bpr_set_tuning (tests, measurements)
     constexpr int LIST_CAP = 512;
     int seen = SEEN_CSR;
@@ -393,7 +393,6 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     // one is over when its slowest group is: the plain kernel's short runs win there), the shape has a FULL
     // instantiation, the snapshot is sorted whole and the per-group bitmaps leave room for >= 8 rows.
     bool use_lds = false;
-    int seen_l = SEEN_BITMAP;
     size_t shmem_l = 0;
     unsigned block_l = E <= 4 ? 1024 : 512;  // (E >= 8: 64+ registers of rows per lane — two waves per SIMD)
     if (c->tune_lds_block > 0) block_l = std::min<unsigned>(block_l, (unsigned)c->tune_lds_block);
@@ -404,11 +403,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     if (c->tune_hot_lds > 0 && hot && c->hot_code != nullptr && c->d == G * E && a.snap_meta == nullptr &&
         (!acut || acut_fold) && !c->hot_unfolded && (sampler == NEG_GIVEN || (force != "csr" && force != "list"))) {
       if (cap_groups > 0 && cap_groups * G < block_l) block_l = (unsigned)(((cap_groups * G + 63) / 64) * 64);
-      // "seen" = global: every user's bitmap lives in HBM (bpr_set_heavy_users(0, ...) built a row per user) — no
-      // LDS bitmaps, all of the CU's LDS goes to hot rows
-      const bool seen_global = sampler != NEG_GIVEN && force == "global" && c->heavy_off != nullptr && c->heavy_T == 0;
-      seen_l = seen_global ? SEEN_GLOBAL : SEEN_BITMAP;
-      const size_t bm_bytes = (sampler == NEG_GIVEN || seen_global) ? 0 : (size_t)(block_l / G) * words * sizeof(uint32_t);
+      const size_t bm_bytes = sampler == NEG_GIVEN ? 0 : (size_t)(block_l / G) * words * sizeof(uint32_t);
       const size_t row_bytes = sizeof(float) * (size_t)c->d + sizeof(uint32_t);
       int64_t L = bm_bytes < LDS_TIER_MAX_BYTES ? (int64_t)((LDS_TIER_MAX_BYTES - bm_bytes) / row_bytes) : 0;
       L = std::min<int64_t>(L, std::min<int64_t>(c->tune_hot_lds, c->hot_H));
@@ -433,7 +428,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
         int64_t want_l = n_runs_l;
         if (cap_groups > 0 && want_l > cap_groups) want_l = cap_groups;
         grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(stream_cus(c), (want_l + per_block_l - 1) / per_block_l));
-        a.bm_words = (sampler == NEG_GIVEN || seen_l == SEEN_GLOBAL) ? 0 : words;
+        a.bm_words = sampler == NEG_GIVEN ? 0 : words;
         a.lds_L = (int32_t)L;
         a.hot_by_rank = c->hot_by_rank;
         a.lds_only = c->hot_tier ? 0 : 1;
@@ -486,7 +481,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       (void)tm;
       hipEvent_t stop = (acut && !acut_fold) ? c->ev_launch : nullptr;
       if (use_lds) {
-        if (int rc = launch_stream_lds(c, a, sampler, seen_l, grid, block_l, shmem_l, stop)) return rc;
+        if (int rc = launch_stream_lds(c, a, sampler, grid, block_l, shmem_l, stop)) return rc;
       }
       auto go = [&](auto smp, auto sn) {
         constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;
@@ -1466,7 +1461,7 @@ int bpr_sync_cut(bpr_ctx* c, float* hot_base, float* hot_tot, int32_t hot_fold_p
 int bpr_set_tuning(bpr_ctx* c, const char* key, int32_t value) {
   if (c == nullptr || key == nullptr) return fail(BPR_ERR_INVALID, "bpr_set_tuning: NULL argument");
   const std::string k = key;
-  if (k == "seen" && value >= 0 && value <= 4) c->tune_seen = value;
+  if (k == "seen" && value >= 0 && value <= 3) c->tune_seen = value;
   else if (k == "vs_direct" && value >= -1 && value <= 1) c->tune_vs_direct = value;
   else if (k == "adam_closed" && (value == 0 || value == 1)) c->tune_adam_closed = value;
   else if (k == "partial_snapshot" && (value == 0 || value == 1)) c->tune_partial = value;

@@ -136,9 +136,7 @@ class Engine:
 
         seen = os.environ.get("BPR_SEEN") or ("csr" if os.environ.get("BPR_NO_BITMAP") else "")
         if seen:
-            self.set_tuning("seen", {"csr": 1, "bitmap": 2, "list": 3, "global": 4}[seen])
-            if seen == "global":  # a bitmap row in HBM for EVERY user (up to 16 GiB of them)
-                native.check(self._lib.bpr_set_heavy_users(self._ctx, 0, 16 << 30))
+            self.set_tuning("seen", {"csr": 1, "bitmap": 2, "list": 3}[seen])
         if os.environ.get("BPR_VS_DIRECT") in ("0", "1"):
             self.set_tuning("vs_direct", int(os.environ["BPR_VS_DIRECT"]))
         if os.environ.get("BPR_NO_ADAM_CLOSED"):
