@@ -200,6 +200,9 @@ int bpr_adaptive_snapshot_ptrs(bpr_ctx* ctx, int32_t back, void** order_host, vo
 #define BPR_COMM_ID_BYTES 128
 int bpr_comm_unique_id(void* id_host);
 int bpr_comm_init(bpr_ctx* ctx, const void* id_host, int32_t rank, int32_t world);
+/* bpr_comm_destroy closes a hot tier still open (folds the exchange in flight and this rank's uncut deltas into the
+ * item table) — call it while the tables are alive; bpr_ctx_destroy frees the communicator too but writes NOTHING
+ * into the caller's tables (they may be gone by then). */
 int bpr_comm_destroy(bpr_ctx* ctx);
 int bpr_item_sync(bpr_ctx* ctx);
 int bpr_item_sync_finish(bpr_ctx* ctx);

@@ -95,13 +95,19 @@ static int comm_hot_close(bpr_ctx* c, Comm* m) {
   return bpr_hot_tier_end(c);
 }
 
-void comm_free(bpr_ctx* c) {
+// tables_alive: the caller's tables are known to exist (bpr_comm_destroy / a re-init: explicit calls) — only then is
+// the hot tier closed by folding the exchange in flight and this rank's uncut deltas into Q.  From bpr_ctx_destroy
+// (a garbage collector may have freed the caller's tensors already) nothing is written: a hot tier still
+// open at that point is the caller's to close first (bpr_comm_destroy, or ItemSync.close in the Python layer).
+void comm_free(bpr_ctx* c, bool tables_alive) {
   Comm* m = static_cast<Comm*>(c->comm);
   if (m == nullptr) return;
-  if (m->stream) hipStreamSynchronize(m->stream);
-  // the launches must not go on leaving hot-row deltas in a block nobody folds
-  if (c->P != nullptr && c->Q != nullptr) (void)comm_hot_close(c, m);
-  hipStreamSynchronize(c->stream);
+  if (m->stream) hipStreamSynchronize(m->stream);  // library-owned: always safe
+  if (tables_alive) {
+    // the launches must not go on leaving hot-row deltas in a block nobody folds
+    if (c->P != nullptr && c->Q != nullptr) (void)comm_hot_close(c, m);
+    hipStreamSynchronize(c->stream);
+  }
   Rccl* l = rccl();
   if (m->comm && l) l->CommDestroy(m->comm);
   hipFree(m->base); hipFree(m->own); hipFree(m->tot);
@@ -280,7 +286,7 @@ int bpr_comm_init(bpr_ctx* c, const void* id_host, int32_t rank, int32_t world) 
   Rccl* l = rccl();
   if (l == nullptr) return fail(BPR_ERR_UNSUPPORTED, "bpr_comm_init: librccl.so not found");
   BPR_HIP_CHECK(hipSetDevice(c->device));
-  comm_free(c);
+  comm_free(c, true);
   Comm* m = new (std::nothrow) Comm();
   if (m == nullptr) return fail(BPR_ERR_NOMEM, "bpr_comm_init: out of host memory");
   c->comm = m;
@@ -343,7 +349,7 @@ int bpr_hot_sync(bpr_ctx* c) {
 int bpr_comm_destroy(bpr_ctx* c) {
   if (c == nullptr) return BPR_OK;
   hipSetDevice(c->device);
-  comm_free(c);
+  comm_free(c, true);
   return BPR_OK;
 }
 

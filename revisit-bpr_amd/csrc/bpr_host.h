@@ -21,7 +21,7 @@ int strict_flush_impl(bpr_ctx* c);                          // STRICT lazy-repla
 int vs_flush(bpr_ctx* c, bool users, bool items);           // bpr_vstream.hip
 int vs_leave(bpr_ctx* c);                                   // bpr_vstream.hip
 void vs_free(bpr_ctx* c);                                   // bpr_vstream.hip
-void comm_free(bpr_ctx* c);                                 // bpr_comm.hip
+void comm_free(bpr_ctx* c, bool tables_alive);              // bpr_comm.hip
 int comm_world(const bpr_ctx* c);                           // bpr_comm.hip (1 without a communicator)
 int comm_rank(const bpr_ctx* c);
 int comm_gather_snapshot(bpr_ctx* c, int32_t* order_back, float* sigma_back, int per);  // bpr_comm.hip

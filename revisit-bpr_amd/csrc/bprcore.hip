@@ -702,7 +702,7 @@ int bpr_ctx_destroy(bpr_ctx* c) {
   c->stream = nullptr;
   if (!c->side_owned) c->side = nullptr;
   free_strict_scratch(c);
-  comm_free(c);
+  comm_free(c, false);  // (no fold into tables that may be gone)
   refresh_free(c);
   side_free(c);
   vs_free(c);

@@ -176,14 +176,19 @@ class Engine:
     def _sync_stream(self) -> None:
         native.check(self._lib.bpr_set_stream(self._ctx, self._stream()))
 
-    def close(self) -> None:
+    def close(self, fold: bool = True) -> None:
+        """Destroy the ctx.  fold (an explicit call: the tables are alive): a communicator with its hot tier still
+        open is closed first — `bpr_comm_destroy` folds the exchange in flight and this rank's uncut deltas into the
+        item table; the garbage collector's call passes False and `bpr_ctx_destroy` then writes nothing."""
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            if fold:
+                self._lib.bpr_comm_destroy(self._ctx)
             self._lib.bpr_ctx_destroy(self._ctx)
             self._ctx = ctypes.c_void_p()
 
     def __del__(self) -> None:  # pragma: no cover
         try:
-            self.close()
+            self.close(fold=False)
         except Exception:
             pass
 
