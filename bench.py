@@ -570,7 +570,8 @@ def main():
     synced = [False]
     # --async-cut: the snapshot cut leaves the launch stream (bpr_train_stream_acut: a read-only pass on the
     # side stream beside the next launch); the hot rows are folded before the tables are read
-    acut = (bool(args.async_cut) if args.async_cut >= 0 else side_stream is not None) and fused
+    from revisit_bpr.fast import auto_async_cut
+    acut = (bool(args.async_cut) if args.async_cut >= 0 else (side_stream is not None and auto_async_cut(I, cus))) and fused
 
     # --jit-plan (default with the overlapped schedule): no bpr_plan_epoch at all — chunk k + 1 is
     # planned by bpr_plan_chunk on the side stream behind the sort of step k (the plan does not depend

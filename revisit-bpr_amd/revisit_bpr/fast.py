@@ -34,7 +34,8 @@ def auto_refresh_cus(I: int, d: int, launch_triples: int, total_cus: int = 256) 
     keys finishes inside one STREAM launch, as few as possible because the launch loses them.
     Calibrated on MI355X (profiles/shapes_r03.txt, r05_binned_sort.md): `sort_cu_ms`, a launch ~0.72 / 0.8 / 1.1 /
     1.8 / 3.5 ns per triple at d <= 32 / 64 / 128 / 256 / 512; measured optima: 32 CUs for ML-20M d=128 since
-    the binned sort (64 before it), 96 for MSD d=256."""
+    the binned sort (64 before it), 64 for MSD d=256 since the split binned sort (96 before it; r6 re-measured:
+    462 M triples/s on 64 against 403 on 96)."""
     lag, cus = auto_schedule(I, d, launch_triples, total_cus)
     if lag > 0.0 and cus > 0:  # the split the cost model of the whole step picks
         return cus
@@ -47,6 +48,15 @@ def auto_refresh_cus(I: int, d: int, launch_triples: int, total_cus: int = 256) 
     # 570 M triples/s, 64 CUs 632 M)
     floor = 32 if 2048 <= I <= 20480 else 64
     return int(min(max(32 * math.ceil(want / 32 - 0.25), floor), total_cus // 2))
+
+
+def auto_async_cut(I: int, refresh_cus: int) -> bool:
+    """Should the transpose of the next snapshot's keys leave the launch stream (`bpr_train_stream_acut`)?  Only where
+    the sorter has slack on its masked CUs — tables the one-workgroup binned sort serves (2,048 .. 20,480 items:
+    ML-20M's sort takes 160 us of a 226-us launch on 32 CUs; +1.4 % steady, +1.7 % early).  MSD's split sort (833 us on
+    64 CUs beside a 905-us launch) and Yelp's radix path have none: there the transpose beside the sort puts the sorter
+    on the critical path (MSD early 508 -> 489 M, Yelp SGD 716 -> 430 M: profiles/r06_msd_sweep.txt)."""
+    return refresh_cus > 0 and 2048 <= I <= 20480
 
 
 def lag_within_budget(lr: float, launch_triples: int, budget: Optional[float] = None) -> bool:
@@ -211,7 +221,8 @@ class StreamTrainer:
         async_cut (refresh_lag = 1, one GPU): the transpose of the next snapshot's keys leaves the launch stream —
         a read-only pass on the side stream beside the NEXT launch (`bpr_train_stream_acut`; r6: the fold of the
         hot block stays on the launch stream, so the LDS tier stays in use): +1.4 % on the metric's configuration,
-        the same curves (profiles/r06_parity_study.md).  "auto" (default): on with a masked side stream."""
+        the same curves (profiles/r06_parity_study.md).  "auto" (default): `auto_async_cut` — on with a masked side
+        stream where the sorter has slack (tables of 2,048 .. 20,480 items)."""
         if users.dtype != torch.int32 or items.dtype != torch.int32:
             raise ValueError("users / items must be int32 device tensors")
         auto_lag = isinstance(refresh_lag, str)
@@ -301,7 +312,7 @@ class StreamTrainer:
         if isinstance(async_cut, str):
             if async_cut != "auto":
                 raise ValueError("async_cut must be a bool or 'auto'")
-            async_cut = self._side is not None
+            async_cut = self._side is not None and auto_async_cut(I, refresh_cus)
         self.async_cut = bool(async_cut) and self.refresh_lag >= 1.0 and item_sync is None
         self.item_sync, self.sync_every = item_sync, sync_every
         # shards are balanced by interactions, not equal: every rank runs the same number of
