@@ -55,7 +55,7 @@ def auto_async_cut(I: int, refresh_cus: int) -> bool:
     the sorter has slack on its masked CUs — tables the one-workgroup binned sort serves (2,048 .. 20,480 items:
     ML-20M's sort takes 160 us of a 226-us launch on 32 CUs; +1.4 % steady, +1.7 % early).  MSD's split sort (833 us on
     64 CUs beside a 905-us launch) and Yelp's radix path have none: there the transpose beside the sort puts the sorter
-    on the critical path (MSD early 508 -> 489 M, Yelp SGD 716 -> 430 M: profiles/r06_msd_sweep.txt)."""
+    on the critical path (MSD early 508 -> 489 M, Yelp SGD 716 -> 430 M: profiles/r06_shapes.txt)."""
     return refresh_cus > 0 and 2048 <= I <= 20480
 
 
