@@ -16,9 +16,18 @@ fused STREAM launch over the next int(I·ln I / 256)·256 shuffled triples (samp
 ML-20M-shaped user shard; the item table is replicated and reconciled by an asynchronous
 all-reduce of item deltas every --sync-every steps (revisit_bpr/distributed.py).
 
-Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the fused stream kernel, HBM
-bound, algorithmic bytes 24·d+8 per triple, duration from hipEvents on the launch stream) and
-`cpu_baseline` (the CPU oracle port timed on this host, 1 thread, bounded sample).
+Prints ONE JSON line (rank 0).  `value` (r6) = the TRAINED state: after the driver's K-step region (`timed_region`)
+and three whole epochs from random init (`early_state` / `sustained`: what r1-r5 called `value`) the job trains on,
+untimed, to 30 epochs, and epochs 31..130 are timed by wall clock between barriers, every `bpr_plan_epoch` in place,
+nothing modelled (`steady_state`; its `first_epoch` is epoch 31 alone) — once the adaptive sampler has a model to
+adapt to its negatives concentrate on popular rows and a launch costs more than on tables fresh from their random
+init: a long job lives in that state.  `steps` = the steps behind `value`.  `roofline`: dominant kernel = the fused
+stream kernel on that state, HBM bound, algorithmic bytes 24·d+8 per triple, duration from hipEvents recorded by
+the library on the launch stream; `traffic` REPLAYED from committed rocprofv3 --pmc passes of the same state
+(profiles/traffic_r06.json), never measured in-run.  `cpu_baseline`: the reference's op sequence restated on CPU
+tensors, `cpu_baseline_c_port`: the C oracle with OpenMP — both on this host's cores over a bounded sample.
+The schedule (snapshot one launch older on 32 masked CUs, asynchronous cut, LDS tier of the hot block) is what
+`fast.StreamTrainer` picks by itself at the workload's learning rate (`fast.lag_within_budget`).
 """
 from __future__ import annotations
 
@@ -748,7 +757,11 @@ def main():
             e.timing_enable(max(1, args.time_every))
             st_epochs = max(1, args.steady_timed_epochs)
             tq = time.perf_counter()
-            for k in range(k_end, k_end + st_epochs * n_chunks):
+            for k in range(k_end, k_end + n_chunks):  # the first timed epoch on its own: r5's `steady_state` was this epoch
+                step(k)
+            torch.cuda.synchronize()
+            st_first = time.perf_counter() - tq
+            for k in range(k_end + n_chunks, k_end + st_epochs * n_chunks):
                 step(k)
             if sync is not None:
                 sync.hot_finish()
@@ -769,6 +782,9 @@ def main():
                       "ms_per_step": st_dt * 1e3 / (st_epochs * n_chunks),
                       "value": st_epochs * n_chunks * chunk * world / st_dt, "kernel_ms_avg": st_kernel_ms,
                       "kernel_launches_timed": st_launches,
+                      "first_epoch": {"epoch": k_end // n_chunks + 1, "ms_per_step": st_first * 1e3 / n_chunks,
+                                      "value": n_chunks * chunk * world / st_first,
+                                      "note": "the first of the timed epochs alone (what r5 reported as steady_state); rank 0's clock"},
                       "note": "whole epochs by wall clock (every bpr_plan_epoch in place, nothing modelled) after that many "
                               "epochs of the same job (lr as configured): the state a long training run is in"}
         # the epoch plan, timed on its own (3 calls; it does not touch the model)
