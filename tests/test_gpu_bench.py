@@ -39,6 +39,7 @@ def test_bench_single_gpu_line():
     st = j["steady_state"]  # whole epochs timed after 30 epochs of the same job: the trained state, the headline
     spe = j["config"]["steps_per_epoch"]
     assert st["epochs_trained_before"] >= 30 and st["steps"] == st["epochs"] * spe and st["value"] > 1e6
+    assert st["first_epoch"]["epoch"] == st["epochs_trained_before"] + 1 and st["first_epoch"]["value"] > 1e6
     trained = (st["epochs_trained_before"] + st["epochs"]) * spe - ((6 + 2 + 1) // spe + 1 + sus["epochs"]) * spe
     assert j["config"]["triples_counted_by_kernel"] == (6 + sus["steps"] + trained) * j["config"]["triples_per_step_per_gpu"]
     assert sus["epochs"] >= 3 and sus["value"] > 1e6 and 0 < r["read_only_frac"] < r["frac"]
