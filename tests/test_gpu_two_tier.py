@@ -32,9 +32,13 @@ def _problem(U, I, d, n, seed):
 
 
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("world,hot_split,H,d", [(2, 1, 16, 64), (3, 2, 40, 128), (4, 3, 8, 256)])
-def test_two_tier_equals_the_dense_protocol(world, hot_split, H, d, fused):
-    """fused: the last launch of a round leaves its epilogue to ONE pass — hot-tier step + cold step +
+@pytest.mark.parametrize("world,hot_split,H,d,lds", [(2, 1, 16, 64, 0), (3, 2, 40, 128, 0), (4, 3, 8, 256, 0),
+                                                     (2, 1, 16, 64, 9), (3, 2, 40, 128, 24), (4, 3, 12, 256, 12)])
+def test_two_tier_equals_the_dense_protocol(world, hot_split, H, d, fused, lds):
+    """lds > 0 (r6): the launches run the LDS-tier kernel (`bpr_set_hot_lds`, forced for these small launches) — the
+    `lds` hottest rows of the tier's H take a workgroup's updates in LDS and are flushed into the block the hot tier
+    exchanges, the rest of the H go through the global block as before: the same protocol, the same tables.
+    fused: the last launch of a round leaves its epilogue to ONE pass — hot-tier step + cold step +
     the cut of the next snapshot's keys (bpr_sync_cut, ItemSync.step_cut) — instead of three kernels;
     same tables, and the snapshot sorted from that cut is the oracle's order of the table."""
     from revisit_bpr import engine as eng
@@ -46,12 +50,13 @@ def test_two_tier_equals_the_dense_protocol(world, hot_split, H, d, fused):
     reg, lr = (0.01, 0.02, 0.03), 0.05
     counts = torch.bincount(torch.from_numpy(pos).long(), minlength=I)
 
-    def engine():
+    def engine(lds_rows=0):
         e = eng.Engine(torch.from_numpy(P0).to(dev), torch.from_numpy(Q0).to(dev))
         e.set_reg(*reg)
         e.set_optimizer(eng.OPT_SGD, lr=lr)
         e.bind_seen_csr(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev))
         e.set_stream_opts(True, 0)
+        e.set_hot_lds(lds_rows, always=True)
         return e
 
     u_d, p_d = torch.from_numpy(users).to(dev), torch.from_numpy(pos).to(dev)
@@ -68,7 +73,7 @@ def test_two_tier_equals_the_dense_protocol(world, hot_split, H, d, fused):
 
     # ---- the product: ItemSync with the hot tier over LocalWorld
     lw = LocalWorld(world)
-    es = [engine() for _ in range(world)]
+    es = [engine(lds) for _ in range(world)]
     syncs = [ItemSync([es[r].Q], comm=lw.member(r), engine=es[r], hot_rows=H, item_counts=counts)
              for r in range(world)]
     assert all(s.hot_tier for s in syncs) and es[0].hot_rows() == H
@@ -97,6 +102,7 @@ def test_two_tier_equals_the_dense_protocol(world, hot_split, H, d, fused):
         syncs[r].hot_finish()
         syncs[r].finish()
     torch.cuda.synchronize()
+    assert all((e.lds_launches > 0) == (lds > 0) for e in es) and (lds == 0 or es[0].stream_lds_rows() == min(lds, H))
 
     # ---- the protocol restated densely: plain engines, deltas as table differences
     ps = [engine() for _ in range(world)]
