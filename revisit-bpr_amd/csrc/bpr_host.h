@@ -46,9 +46,11 @@ inline int dispatch_ge(int G, int E, F&& f) {
   }
 }
 
-// bpr_hotlds.hip: k_stream with the LDS tier of the hot block.  LDS_TIER_MAX_BYTES = what one workgroup may
+// bpr_hotlds.hip: k_stream with the LDS tier of the hot block.  lds_tier_room(d) = what one workgroup may
 // declare dynamically beside the kernels' static LDS (sigma: 4 d bytes, reduction scratch) of a CU's 160 KiB
-constexpr size_t LDS_TIER_MAX_BYTES = 160 * 1024 - 6 * 1024;
+// dynamic LDS a launch of the LDS-tier kernel may use at width d: the CU's 160 KiB less the kernel's static LDS
+// (sigma: 4 d bytes rounded to the group layout, the loss reduction's 256 B, the ticket) and 256 B of slack
+inline size_t lds_tier_room(int d) { return 160 * 1024 - ((size_t)4 * (size_t)((d + 63) / 64 * 64) + 256 + 16 + 256); }
 struct StreamArgs;
 int launch_stream_lds(bpr_ctx* c, const StreamArgs& a, int sampler, unsigned grid, unsigned block, size_t shmem,
                       hipEvent_t stop);

@@ -14,12 +14,12 @@ namespace bpr {
 
 // one workgroup may declare all of a CU's LDS; anything past 64 KiB of dynamic LDS must be asked for per function
 template <typename K>
-static int allow_lds(K kernel, size_t shmem) {
+static int allow_lds(K kernel, size_t shmem, size_t room) {
   static std::set<const void*> done;  // (launches are issued from one host thread per ctx; the set is per instantiation)
   if (shmem <= 64 * 1024) return BPR_OK;
   const void* key = reinterpret_cast<const void*>(kernel);
   if (done.count(key)) return BPR_OK;
-  BPR_HIP_CHECK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TIER_MAX_BYTES));
+  BPR_HIP_CHECK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)room));
   done.insert(key);
   return BPR_OK;
 }
@@ -34,7 +34,7 @@ int launch_stream_lds(bpr_ctx* c, const StreamArgs& a, int sampler, unsigned gri
     using T = decltype(tag);
     constexpr int G = T::G, E = T::E;
     auto go = [&](auto kernel) -> int {
-      if (int rc = allow_lds(kernel, shmem)) return rc;
+      if (int rc = allow_lds(kernel, shmem, lds_tier_room(G * E))) return rc;
       hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, c->stream, nullptr, stop, 0, a);
       BPR_HIP_CHECK(hipGetLastError());
       return BPR_OK;

@@ -405,7 +405,8 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       if (cap_groups > 0 && cap_groups * G < block_l) block_l = (unsigned)(((cap_groups * G + 63) / 64) * 64);
       const size_t bm_bytes = sampler == NEG_GIVEN ? 0 : (size_t)(block_l / G) * words * sizeof(uint32_t);
       const size_t row_bytes = sizeof(float) * (size_t)c->d + sizeof(uint32_t);
-      int64_t L = bm_bytes < LDS_TIER_MAX_BYTES ? (int64_t)((LDS_TIER_MAX_BYTES - bm_bytes) / row_bytes) : 0;
+      const size_t room = lds_tier_room(c->d);
+      int64_t L = bm_bytes < room ? (int64_t)((room - bm_bytes) / row_bytes) : 0;
       L = std::min<int64_t>(L, std::min<int64_t>(c->tune_hot_lds, c->hot_H));
       const int64_t per_block_l = (int64_t)(block_l / 64) * a.gpw_active;
       const int64_t runs8 = (a.n + 7) / 8;
