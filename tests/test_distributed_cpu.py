@@ -240,3 +240,6 @@ def test_staleness_budget_and_schedule_rules():
     # the LDS tier of the hot block (r6) goes by the same rule, counted in triples of the whole job
     assert fast.hot_lds_rows(0.001, period) == fast.HOT_LDS_ROWS and fast.hot_lds_rows(0.001, period, world=8) > 0
     assert fast.hot_lds_rows(0.01, period) == 0 and fast.hot_lds_rows(0.001, period, world=32) == 0
+    # the asynchronous cut only where the sorter has slack on its masked CUs: the one-workgroup binned sort's tables
+    assert fast.auto_async_cut(20109, 32) and not fast.auto_async_cut(20109, 0)
+    assert not fast.auto_async_cut(41141, 64) and not fast.auto_async_cut(92090, 128)
