@@ -595,7 +595,12 @@ def main():
     cur, pre, plan_stream = [0], {}, None
     if plan_ahead:
         ebuf.append((torch.empty_like(src_users), torch.empty_like(src_items)))
-        plan_stream = eng.MaskedStream(dev, eng.cu_mask(0, cus, total_cus))
+        # --plan-ahead 1: on the sorter's CUs (r5: lost; r6 with the one-pass plan: 777 against 830 M); 2 (r6): on the LAUNCH
+        # stream's CUs — the 1,024-thread LDS-tier workgroups leave half of a CU's wave slots free and the plan's kernels
+        # use no LDS: measured NEUTRAL, 827-830 against 830 M (the launches beside the plan slow down by what the plan
+        # saves: profiles/r06_hotlds.md)
+        plan_stream = eng.MaskedStream(dev, eng.cu_mask(0, cus, total_cus) if args.plan_ahead == 1 else
+                                       eng.cu_mask(cus, total_cus - cus, total_cus))
 
     def plan_chunk(kk: int, on_side: bool):
         e.plan_chunk(src_users, src_items, chunk, seed + kk // n_chunks, kk % n_chunks, out=cbuf[kk & 1],
