@@ -52,8 +52,8 @@ inline int dispatch_ge(int G, int E, F&& f) {
 // (sigma: 4 d bytes rounded to the group layout, the loss reduction's 256 B, the ticket) and 256 B of slack
 inline size_t lds_tier_room(int d) { return 160 * 1024 - ((size_t)4 * (size_t)((d + 63) / 64 * 64) + 256 + 16 + 256); }
 struct StreamArgs;
-int launch_stream_lds(bpr_ctx* c, const StreamArgs& a, int sampler, unsigned grid, unsigned block, size_t shmem,
-                      hipEvent_t stop);
+int launch_stream_lds(bpr_ctx* c, const StreamArgs& a, int sampler, int seen, unsigned grid, unsigned block,
+                      size_t shmem, hipEvent_t stop);
 
 struct Timer {
   bpr_ctx* c;

@@ -28,7 +28,7 @@ static int allow_lds(K kernel, size_t shmem, size_t room) {
 // d == G * E (the FULL instantiations: every BASELINE shape)
 // (r6 also measured every user's seen bitmap in HBM instead of the per-group LDS bitmaps — twice the LDS rows, and
 // 612 against 832 M triples/s: the walk's lookups are LDS reads for a reason.  profiles/r06_hotlds.md.  Removed.)
-int launch_stream_lds(bpr_ctx* c, const StreamArgs& a, int sampler, unsigned grid, unsigned block, size_t shmem,
+int launch_stream_lds(bpr_ctx* c, const StreamArgs& a, int sampler, int seen, unsigned grid, unsigned block, size_t shmem,
                       hipEvent_t stop) {
   return dispatch_ge(c->G, c->E, [&](auto tag) -> int {
     using T = decltype(tag);
@@ -40,6 +40,10 @@ int launch_stream_lds(bpr_ctx* c, const StreamArgs& a, int sampler, unsigned gri
       return BPR_OK;
     };
     if (sampler == NEG_GIVEN) return go(k_stream<G, E, NEG_GIVEN, SEEN_CSR, true, false, true>);
+    if (seen == SEEN_LIST) {
+      if (sampler == NEG_UNIFORM) return go(k_stream<G, E, NEG_UNIFORM, SEEN_LIST, true, false, true>);
+      return go(k_stream<G, E, NEG_ADAPTIVE, SEEN_LIST, true, false, true>);
+    }
     if (sampler == NEG_UNIFORM) return go(k_stream<G, E, NEG_UNIFORM, SEEN_BITMAP, true, false, true>);
     return go(k_stream<G, E, NEG_ADAPTIVE, SEEN_BITMAP, true, false, true>);
   });

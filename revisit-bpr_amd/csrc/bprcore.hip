@@ -393,6 +393,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     // one is over when its slowest group is: the plain kernel's short runs win there), the shape has a FULL
     // instantiation, the snapshot is sorted whole and the per-group bitmaps leave room for >= 8 rows.
     bool use_lds = false;
+    int seen_l = SEEN_BITMAP;
     size_t shmem_l = 0;
     unsigned block_l = E <= 4 ? 1024 : 512;  // (E >= 8: 64+ registers of rows per lane — two waves per SIMD)
     if (c->tune_lds_block > 0) block_l = std::min<unsigned>(block_l, (unsigned)c->tune_lds_block);
@@ -401,9 +402,15 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
     // hot row's value is Q + that block — which the LDS-tier kernel, reading Q + its own LDS delta, leaves out)
     const bool acut_fold = acut && c->tune_acut_fold != 0;  // r6: the asynchronous cut with the fold kept on this stream
     if (c->tune_hot_lds > 0 && hot && c->hot_code != nullptr && c->d == G * E && a.snap_meta == nullptr &&
-        (!acut || acut_fold) && !c->hot_unfolded && (sampler == NEG_GIVEN || (force != "csr" && force != "list"))) {
+        (!acut || acut_fold) && !c->hot_unfolded && (sampler == NEG_GIVEN || force != "csr")) {
       if (cap_groups > 0 && cap_groups * G < block_l) block_l = (unsigned)(((cap_groups * G + 63) / 64) * 64);
-      const size_t bm_bytes = sampler == NEG_GIVEN ? 0 : (size_t)(block_l / G) * words * sizeof(uint32_t);
+      // the groups' seen structure beside the rows: the I-bit bitmaps while they leave 32 KB for rows, else (or
+      // forced) the staged sorted lists (LIST_CAP entries per group: item tables past ~60 k items)
+      size_t bm_bytes = sampler == NEG_GIVEN ? 0 : (size_t)(block_l / G) * words * sizeof(uint32_t);
+      if (sampler != NEG_GIVEN && (force == "list" || (force != "bitmap" && bm_bytes + 32 * 1024 > lds_tier_room(c->d)))) {
+        seen_l = SEEN_LIST;
+        bm_bytes = (size_t)(block_l / G) * LIST_CAP * sizeof(uint32_t);
+      }
       const size_t row_bytes = sizeof(float) * (size_t)c->d + sizeof(uint32_t);
       const size_t room = lds_tier_room(c->d);
       int64_t L = bm_bytes < room ? (int64_t)((room - bm_bytes) / row_bytes) : 0;
@@ -429,7 +436,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
         int64_t want_l = n_runs_l;
         if (cap_groups > 0 && want_l > cap_groups) want_l = cap_groups;
         grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(stream_cus(c), (want_l + per_block_l - 1) / per_block_l));
-        a.bm_words = sampler == NEG_GIVEN ? 0 : words;
+        a.bm_words = sampler == NEG_GIVEN ? 0 : (seen_l == SEEN_LIST ? LIST_CAP : words);
         a.lds_L = (int32_t)L;
         a.hot_by_rank = c->hot_by_rank;
         a.lds_only = c->hot_tier ? 0 : 1;
@@ -482,7 +489,7 @@ static int launch_stream(bpr_ctx* c, StreamArgs a, int sampler, int64_t cap_grou
       (void)tm;
       hipEvent_t stop = (acut && !acut_fold) ? c->ev_launch : nullptr;
       if (use_lds) {
-        if (int rc = launch_stream_lds(c, a, sampler, grid, block_l, shmem_l, stop)) return rc;
+        if (int rc = launch_stream_lds(c, a, sampler, seen_l, grid, block_l, shmem_l, stop)) return rc;
       }
       auto go = [&](auto smp, auto sn) {
         constexpr int SMP = decltype(smp)::value, SN = decltype(sn)::value;

@@ -37,12 +37,19 @@ def skewed_problem(U, I, d, n, seed, max_seen=40):
     return P, Q, indptr, np.concatenate(rows), users, pos, rng
 
 
+@pytest.mark.parametrize("seen", ["", "list"])
 @pytest.mark.parametrize("d,run_len,sampler,bias", [(256, 8, 1, False), (256, 3, 2, False), (512, 5, 0, True),
                                                      (1024, 8, 2, True)])
-def test_lds_tier_sequential_equals_b1_sgd(d, run_len, sampler, bias):
-    """One group in flight (G = 64: a whole wave) == the oracle's sequential SGD in planned order, three launches
+def test_lds_tier_sequential_equals_b1_sgd(d, run_len, sampler, bias, seen, monkeypatch):
+    """(seen = "list": the groups' staged sorted seen lists beside the rows instead of the I-bit bitmaps — what the
+    tier takes by itself for item tables too large for bitmaps.)
+    One group in flight (G = 64: a whole wave) == the oracle's sequential SGD in planned order, three launches
     in a row (flush -> fold -> next launch reads the folded table), with 5 of the 12 hot rows in LDS and the other
     7 in the global block."""
+    if seen:
+        if sampler == 0:
+            pytest.skip("given negatives: no seen structure")
+        monkeypatch.setenv("BPR_SEEN", seen)
     P, Q, indptr, indices, users, pos, rng = skewed_problem(120, 80, d, 1400, d + run_len)
     b = (rng.normal(0, 0.1, Q.shape[0]).astype(np.float32)) if bias else None
     reg = (0.01, 0.02, 0.03)
