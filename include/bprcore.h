@@ -403,9 +403,10 @@ int bpr_set_hot_rows(bpr_ctx* ctx, int32_t hot_rows, int32_t replicas);
  * that the multi-GPU budget prices (revisit_bpr/fast.py lag_within_budget: inside at the
  * reference's lr 0.001 and 0.01, outside at 0.05), which is why it is off by default and the trainers switch
  * it on by that rule.  With max_inflight = 1 (one group) it is exactly sequential SGD.  always = 1: also for
- * launches that do not fill the chip (tests).  Needs a hot block (bpr_plan_epoch / bpr_set_hot_items), the
- * LDS seen bitmap or given negatives, d in {32, 64, 128, 256, 512, 1024}, a snapshot sorted whole; otherwise
- * the plain kernel runs.  bpr_stream_lds_rows: LDS rows of the last STREAM launch (0 = the plain kernel ran). */
+ * launches that do not fill the chip (tests).  Needs a hot block (bpr_plan_epoch / bpr_set_hot_items), d in
+ * {32, 64, 128, 256, 512, 1024}, a snapshot sorted whole (the groups' seen structure is the LDS bitmap, or the staged
+ * sorted list when the bitmaps would not leave 32 KB for rows: item tables past ~60 k items); otherwise the plain
+ * kernel runs.  bpr_stream_lds_rows: LDS rows of the last STREAM launch (0 = the plain kernel ran). */
 int bpr_set_hot_lds(bpr_ctx* ctx, int32_t rows, int32_t always);
 int bpr_stream_lds_rows(bpr_ctx* ctx);
 /* Test and measurement aids, per ctx (nothing in the library reads the environment per launch):
